@@ -1,0 +1,138 @@
+/* include/salt_gpu.h -- C ABI of the MI355X (gfx950) implementation of salt's single-end per-read
+ * alignment path.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * What it replaces in the reference (weiquan/salt, paths under Align_src/):
+ *
+ *   salt_gpu_index_attach      one-time upload after alnse_index_reload()        indexio.c:23-49
+ *   salt_gpu_index_detach      alnse_index_destroy() for the device copy         indexio.c:50-60
+ *   salt_gpu_align_se          the per-batch call that stands where the pthread  alnse.c:1419-1429
+ *                              fan-out over alnse_core1() is: for every read      alnse.c:1316-1352
+ *                              alnse_overlap_alt + query_gen_cigar                alnse.c:1045-1104
+ *                                                                                 query.c:282-333
+ *   salt_gpu_align_se_resident same work on buffers that already live in HBM (what bench.py times)
+ *
+ * The reference has no FFI of its own (pure C, one process); INTEGRATION.md shows the ~40-line
+ * patch to alnse.c that binds these entry points in place of alnse_core1().
+ *
+ * Error model: the reference reports nothing upward (any failure is exit(1)); here every entry
+ * point returns 0 on success or a negative SALT_E_* code, and salt_gpu_last_error() gives text.
+ */
+#ifndef SALT_GPU_H
+#define SALT_GPU_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SALT_OK              0
+#define SALT_E_INVAL        -1   /* bad argument / unsupported option value */
+#define SALT_E_HIP          -2   /* a HIP runtime call failed */
+#define SALT_E_NOMEM        -3
+#define SALT_E_INDEX        -4   /* malformed index arrays */
+#define SALT_E_CAPACITY     -5   /* batch larger than the workspace was created for */
+
+#define SALT_MAX_READ_LEN   512  /* bases per read handled by the kernels */
+#define SALT_MAX_HITS       5    /* aln.h:133 */
+#define SALT_MAX_LOCATE     1024 /* upper bound accepted for -m (reference default 1000) */
+#define SALT_MAX_SEED_SLOTS 256  /* seeds per strand: ceil((L-k+1)/overlap) must not exceed this */
+#define SALT_MAX_CIGAR_OPS  64
+
+/* Host-side view of index_t (indexio.h:26-33): the arrays exactly as the index files hold them. */
+typedef struct {
+    /* <P>.C.bwt / <P>.C.sa : bwt_t (bwt.h:40-55, bwtio.c:30-71) */
+    uint32_t c_primary, c_L2[5], c_seq_len, c_bwt_size;
+    const uint32_t *c_bwt;
+    uint32_t c_sa_intv, c_n_sa;
+    const uint32_t *c_sa;                       /* c_sa[0] == 0xFFFFFFFF */
+    /* <P>.C.lkt : lookupTable_t (lookup.h:21-25) */
+    uint32_t lkt_len, lkt_n;
+    const uint32_t *lkt;
+    /* <P>.R.backward.{bwt,occ,sa} : rbwt_t (rbwt.h:60-80) */
+    uint32_t r_text_len, r_inv_sa0, r_cum[6], r_bwt_words;
+    const uint32_t *r_bwt;
+    uint32_t r_occ_words;   const uint32_t *r_occ;
+    uint32_t r_major_words; const uint32_t *r_major;
+    uint32_t r_n_sa;        const uint32_t *r_sa;
+    /* <P>.ref : mixRef_t (metaref.h) */
+    uint32_t ref_len;
+    const uint32_t *ref;
+} salt_host_index_t;
+
+/* The fields of aln_opt_t (aln.h:63-89) the single-end path reads. */
+typedef struct {
+    int32_t  l_seed;         /* <P>.R.seedLen */
+    int32_t  l_overlap;      /* -r (defaults to l_seed) */
+    uint32_t max_seed;       /* -s, 50 */
+    uint32_t max_locate;     /* -m, 1000 */
+    int32_t  max_hits;       /* 5 */
+    int32_t  seed_only_ref;  /* -v */
+    int32_t  collect_counters; /* accumulate the logical-access counters below */
+    int32_t  reserved;
+} salt_aln_opt_t;
+
+/* hit_t (query.h:28-33) */
+typedef struct {
+    uint32_t pos;
+    uint8_t  n_diff, is_gap;
+    uint16_t strand;
+} salt_hit_t;
+
+/* The result fields alnse_core1 leaves in query_t (query.h:37-63).  CIGARs are binary:
+ * (len << 4) | op with op 0=M 1=I 2=D, in the order the text CIGAR lists them. */
+typedef struct {
+    uint32_t pos;                               /* 0xFFFFFFFF = unmapped */
+    uint8_t  strand, n_diff, is_gap, mapq;      /* strand 3 / n_diff 255 / is_gap 255 when unset */
+    int32_t  b0, b1;
+    uint16_t seq_start, seq_end;
+    uint8_t  n_hits[2];                         /* alternative hits kept per strand (<= 5 in all) */
+    uint8_t  n_cigar;                           /* ops in cigar[] (0 when unmapped) */
+    uint8_t  skipped;                           /* 1: > 200 N, read left untouched (alnse.c:1328) */
+    salt_hit_t hits[2][SALT_MAX_HITS];
+    uint8_t  hit_n_cigar[SALT_MAX_HITS];        /* ops of hit_cigar[h]; h counts strand-0 hits, then */
+    uint8_t  pad[3];                            /* strand-1 hits; 0 for gap-free hits ("<L>M")        */
+    uint16_t cigar[SALT_MAX_CIGAR_OPS];
+    uint16_t hit_cigar[SALT_MAX_HITS][SALT_MAX_CIGAR_OPS];
+} salt_result_t;                                /* 880 bytes */
+
+/* logical accesses of the reference algorithm, summed over a batch */
+enum { SALT_CTR_LKT, SALT_CTR_OCC_C, SALT_CTR_OCC_R, SALT_CTR_SA_C, SALT_CTR_SA_R, SALT_CTR_VERIFY,
+       SALT_CTR_VERIFY_WORDS, SALT_CTR_LV, SALT_CTR_READS, SALT_CTR_BASES, SALT_CTR_LOCI, SALT_CTR_N };
+
+typedef struct salt_gpu_index salt_gpu_index_t;
+typedef struct salt_gpu_ws    salt_gpu_ws_t;
+
+/* ---- device index ------------------------------------------------------------------------- */
+/* Re-packs the host arrays into the device layout (DESIGN.md "HBM layout") on `device`. */
+int  salt_gpu_index_attach(const salt_host_index_t *host, int device, salt_gpu_index_t **out);
+void salt_gpu_index_detach(salt_gpu_index_t *ix);
+/* The packed device image is one contiguous, position-independent allocation so that a multi-GPU
+ * driver can broadcast it (RCCL) instead of re-packing on every rank. */
+int  salt_gpu_index_image(const salt_gpu_index_t *ix, void **dev_ptr, uint64_t *bytes);
+int  salt_gpu_index_attach_image(void *dev_ptr, uint64_t bytes, int device, salt_gpu_index_t **out);
+
+/* ---- per-batch work ----------------------------------------------------------------------- */
+int  salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint64_t max_bases, salt_gpu_ws_t **out);
+void salt_gpu_ws_destroy(salt_gpu_ws_t *ws);
+
+/* Host buffers in, host results out; synchronous.  seqs: base codes 0..4 (A C G T N, query.c:177-183),
+ * read i at seqs[offs[i] .. offs[i+1]).  Fills results[0..n_reads). */
+int  salt_gpu_align_se(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, uint32_t n_reads,
+                       const uint8_t *seqs, const uint32_t *offs, salt_result_t *results);
+
+/* Same work on device-resident buffers; only enqueues on `hip_stream` (a hipStream_t, NULL = default). */
+int  salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, uint32_t n_reads,
+                                uint32_t max_read_len, const void *d_seqs, const void *d_offs,
+                                void *d_results, void *hip_stream);
+
+/* counters of the last batch(es) since the previous call; resets them */
+int  salt_gpu_ws_counters(salt_gpu_ws_t *ws, uint64_t out[SALT_CTR_N]);
+
+const char *salt_gpu_last_error(void);
+uint32_t    salt_gpu_result_size(void);         /* sizeof(salt_result_t), for bindings */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

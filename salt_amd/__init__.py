@@ -1,0 +1,7 @@
+"""salt_amd -- MI355X-native implementation of salt's per-read alignment hot path.
+
+Only what the path needs: csrc/ (HIP kernels + the C ABI of include/salt_gpu.h), host/ (index
+files + SAM text, include/salt_host.h) and api.py (ctypes bindings that mirror the reference's
+batch-level interface)."""
+from .api import (AlnOpt, GpuAligner, Index, SaltError, RESULT_DTYPE, read_fastq, sam_text,  # noqa: F401
+                  gpu_lib, host_lib)

@@ -1,0 +1,324 @@
+"""ctypes bindings over the product's two C-ABI libraries (include/salt_gpu.h, include/salt_host.h).
+
+The names follow the reference (weiquan/salt, Align_src/):
+    Index.reload(prefix)          alnse_index_reload            indexio.c:23-49
+    AlnOpt                        aln_opt_t / opt_init defaults aln.h:63-89, aln.c:28-56
+    GpuAligner.alnse_core1(...)   alnse_core1 over one batch    alnse.c:1316-1352
+    sam_header / samse            aln_samhead / aln_samse       sam.c:56-182
+
+There is no CPU fallback here: every compute entry point goes through libsalt_gpu.so and raises
+SaltError when the library or a HIP device is missing.
+"""
+import ctypes
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+MAX_HITS = 5
+MAX_CIGAR_OPS = 64
+CTR_NAMES = ["lkt", "occ_c", "occ_r", "sa_c", "sa_r", "verify", "verify_words", "lv", "reads", "bases", "loci"]
+
+
+class SaltError(RuntimeError):
+    pass
+
+
+HIT_DTYPE = np.dtype([("pos", "<u4"), ("n_diff", "u1"), ("is_gap", "u1"), ("strand", "<u2")])
+RESULT_DTYPE = np.dtype([
+    ("pos", "<u4"), ("strand", "u1"), ("n_diff", "u1"), ("is_gap", "u1"), ("mapq", "u1"),
+    ("b0", "<i4"), ("b1", "<i4"), ("seq_start", "<u2"), ("seq_end", "<u2"),
+    ("n_hits", "u1", (2,)), ("n_cigar", "u1"), ("skipped", "u1"),
+    ("hits", HIT_DTYPE, (2, MAX_HITS)),
+    ("hit_n_cigar", "u1", (MAX_HITS,)), ("pad", "u1", (3,)),
+    ("cigar", "<u2", (MAX_CIGAR_OPS,)),
+    ("hit_cigar", "<u2", (MAX_HITS, MAX_CIGAR_OPS)),
+])
+assert RESULT_DTYPE.itemsize == 880
+
+
+class _HostIndex(ctypes.Structure):
+    _fields_ = [
+        ("c_primary", ctypes.c_uint32), ("c_L2", ctypes.c_uint32 * 5), ("c_seq_len", ctypes.c_uint32),
+        ("c_bwt_size", ctypes.c_uint32), ("c_bwt", ctypes.c_void_p),
+        ("c_sa_intv", ctypes.c_uint32), ("c_n_sa", ctypes.c_uint32), ("c_sa", ctypes.c_void_p),
+        ("lkt_len", ctypes.c_uint32), ("lkt_n", ctypes.c_uint32), ("lkt", ctypes.c_void_p),
+        ("r_text_len", ctypes.c_uint32), ("r_inv_sa0", ctypes.c_uint32), ("r_cum", ctypes.c_uint32 * 6),
+        ("r_bwt_words", ctypes.c_uint32), ("r_bwt", ctypes.c_void_p),
+        ("r_occ_words", ctypes.c_uint32), ("r_occ", ctypes.c_void_p),
+        ("r_major_words", ctypes.c_uint32), ("r_major", ctypes.c_void_p),
+        ("r_n_sa", ctypes.c_uint32), ("r_sa", ctypes.c_void_p),
+        ("ref_len", ctypes.c_uint32), ("ref", ctypes.c_void_p),
+    ]
+
+
+class _AlnOpt(ctypes.Structure):
+    _fields_ = [("l_seed", ctypes.c_int32), ("l_overlap", ctypes.c_int32), ("max_seed", ctypes.c_uint32),
+                ("max_locate", ctypes.c_uint32), ("max_hits", ctypes.c_int32), ("seed_only_ref", ctypes.c_int32),
+                ("collect_counters", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class _SamOpt(ctypes.Structure):
+    _fields_ = [("print_xa_cigar", ctypes.c_int32), ("print_nm_md", ctypes.c_int32), ("rg_id", ctypes.c_char_p)]
+
+
+_gpu = None
+_host = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        path = os.path.join(LIB_DIR, "libsalt_host.so")
+        if not os.path.exists(path):
+            raise SaltError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        lib = ctypes.CDLL(path)
+        lib.salt_index_load.restype = ctypes.c_void_p
+        lib.salt_index_load.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        lib.salt_index_free.argtypes = [ctypes.c_void_p]
+        lib.salt_index_host_view.restype = ctypes.POINTER(_HostIndex)
+        lib.salt_index_host_view.argtypes = [ctypes.c_void_p]
+        lib.salt_index_seed_len.argtypes = [ctypes.c_void_p]
+        lib.salt_index_n_seqs.argtypes = [ctypes.c_void_p]
+        lib.salt_host_last_error.restype = ctypes.c_char_p
+        lib.salt_sam_header.argtypes = [ctypes.c_void_p, ctypes.POINTER(_SamOpt), ctypes.c_char_p, ctypes.c_size_t]
+        lib.salt_sam_se.argtypes = [ctypes.c_void_p, ctypes.POINTER(_SamOpt), ctypes.c_char_p, ctypes.c_void_p,
+                                    ctypes.c_int32, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+        lib.salt_lkt_build.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+        lib.salt_cigar_text.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+        _host = lib
+    return _host
+
+
+def gpu_lib():
+    """The HIP library.  Missing library = hard error (never a silent fallback)."""
+    global _gpu
+    if _gpu is None:
+        path = os.path.join(LIB_DIR, "libsalt_gpu.so")
+        if not os.path.exists(path):
+            raise SaltError("%s is missing: the HIP extension was not built" % path)
+        lib = ctypes.CDLL(path)
+        lib.salt_gpu_last_error.restype = ctypes.c_char_p
+        lib.salt_gpu_result_size.restype = ctypes.c_uint32
+        lib.salt_gpu_index_attach.argtypes = [ctypes.POINTER(_HostIndex), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        lib.salt_gpu_index_detach.argtypes = [ctypes.c_void_p]
+        lib.salt_gpu_index_image.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+        lib.salt_gpu_index_attach_image.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        lib.salt_gpu_ws_create.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+        lib.salt_gpu_ws_destroy.argtypes = [ctypes.c_void_p]
+        lib.salt_gpu_align_se.argtypes = [ctypes.c_void_p, ctypes.POINTER(_AlnOpt), ctypes.c_uint32, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+        lib.salt_gpu_align_se_resident.argtypes = [ctypes.c_void_p, ctypes.POINTER(_AlnOpt), ctypes.c_uint32, ctypes.c_uint32,
+                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.salt_gpu_ws_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        assert lib.salt_gpu_result_size() == RESULT_DTYPE.itemsize
+        _gpu = lib
+    return _gpu
+
+
+def _gpu_check(rc):
+    if rc != 0:
+        raise SaltError("salt_gpu error %d: %s" % (rc, gpu_lib().salt_gpu_last_error().decode()))
+
+
+@dataclass
+class AlnOpt:
+    """aln_opt_t as the SE path reads it; defaults of opt_init()/aln_opt_init() (aln.c:28-56, aln.h:112-145)."""
+    l_seed: int = 25
+    l_overlap: int = -1
+    max_seed: int = 50
+    max_locate: int = 1000
+    max_hits: int = 5
+    seed_only_ref: int = 0
+    print_xa_cigar: int = 0
+    print_nm_md: int = 0
+    rg_id: str = None
+    collect_counters: int = 0
+
+    def _c(self):
+        ov = self.l_overlap if self.l_overlap > 0 else self.l_seed          # aln.c:223
+        return _AlnOpt(self.l_seed, ov, self.max_seed, self.max_locate, self.max_hits, self.seed_only_ref,
+                       self.collect_counters, 0)
+
+    def _sam(self):
+        return _SamOpt(self.print_xa_cigar, self.print_nm_md, self.rg_id.encode() if self.rg_id else None)
+
+    @classmethod
+    def from_argv(cls, argv, l_seed):
+        """Parses salt's option letters (optstring aln.c:102); ignored flags stay ignored."""
+        import getopt
+        opts, rest = getopt.getopt(argv, "t:n:hpa:b:g:em:s:l:cdr:vM:O:E:X:")
+        o = cls(l_seed=l_seed)
+        for k, v in opts:
+            if k == "-s":
+                o.max_seed = int(v)
+            elif k == "-m":
+                o.max_locate = int(v)
+            elif k == "-r":
+                o.l_overlap = int(v)
+            elif k == "-v":
+                o.seed_only_ref = 1
+            elif k == "-c":
+                o.print_xa_cigar = 1
+            elif k == "-d":
+                o.print_nm_md = 1
+            elif k == "-g":
+                o.rg_id = v
+            elif k == "-p":
+                raise SaltError("paired-end mode is not implemented on the GPU path yet")
+        return o, rest
+
+
+class Index:
+    """index_t: the arrays of the index files, on the host."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def reload(cls, prefix, rebuild_lkt=True):
+        h = host_lib().salt_index_load(os.fsencode(prefix), 1 if rebuild_lkt else 0)
+        if not h:
+            raise SaltError(host_lib().salt_host_last_error().decode())
+        return cls(h)
+
+    @property
+    def view(self):
+        return host_lib().salt_index_host_view(self._h)
+
+    @property
+    def l_seed(self):
+        return host_lib().salt_index_seed_len(self._h)
+
+    def destroy(self):
+        if self._h:
+            host_lib().salt_index_free(self._h)
+            self._h = None
+
+    def sam_header(self, opt):
+        buf = ctypes.create_string_buffer(1 << 20)
+        so = opt._sam()
+        n = host_lib().salt_sam_header(self._h, ctypes.byref(so), buf, len(buf))
+        if n < 0:
+            raise SaltError("SAM header too large")
+        return buf.raw[:n]
+
+    def samse(self, opt, name, seq, qual, result_row):
+        """One SAM record (bytes, no newline) for a row of RESULT_DTYPE."""
+        buf = ctypes.create_string_buffer(4096 + 8 * len(seq))
+        so = opt._sam()
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        row = np.ascontiguousarray(result_row)
+        n = host_lib().salt_sam_se(self._h, ctypes.byref(so), name, seq.ctypes.data, len(seq), qual,
+                                   row.ctypes.data, buf, len(buf))
+        if n < 0:
+            raise SaltError("SAM record too large")
+        return buf.raw[:n]
+
+
+class GpuAligner:
+    """Device copy of the index + one batch workspace on one GPU."""
+
+    def __init__(self, index, device=0, max_reads=100000, max_bases=None):
+        lib = gpu_lib()
+        self._ix = ctypes.c_void_p()
+        _gpu_check(lib.salt_gpu_index_attach(index.view, device, ctypes.byref(self._ix)))
+        self._ws = ctypes.c_void_p()
+        self.max_reads = max_reads
+        self.max_bases = max_bases if max_bases is not None else max_reads * 160
+        try:
+            _gpu_check(lib.salt_gpu_ws_create(self._ix, max_reads, self.max_bases, ctypes.byref(self._ws)))
+        except SaltError:
+            lib.salt_gpu_index_detach(self._ix)
+            raise
+        self.device = device
+
+    def image(self):
+        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+        _gpu_check(gpu_lib().salt_gpu_index_image(self._ix, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def alnse_core1(self, opt, seqs, offs):
+        """seqs: uint8 codes 0..4 concatenated; offs: uint32 n+1 offsets.  Returns RESULT_DTYPE[n]."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint32)
+        n = len(offs) - 1
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        co = opt._c()
+        done = 0
+        while done < n:                                   # batches of the workspace size (N_SEQS, aln.h:27)
+            m = min(self.max_reads, n - done)
+            while m > 1 and int(offs[done + m]) - int(offs[done]) > self.max_bases:
+                m //= 2
+            o = (offs[done:done + m + 1] - offs[done]).astype(np.uint32)
+            s = seqs[int(offs[done]):int(offs[done + m])]
+            _gpu_check(gpu_lib().salt_gpu_align_se(self._ws, ctypes.byref(co), m, s.ctypes.data, o.ctypes.data,
+                                                   res[done:].ctypes.data))
+            done += m
+        return res
+
+    def align_resident(self, opt, n_reads, max_read_len, d_seqs, d_offs, d_results, stream=0):
+        co = opt._c()
+        _gpu_check(gpu_lib().salt_gpu_align_se_resident(self._ws, ctypes.byref(co), n_reads, max_read_len, d_seqs, d_offs,
+                                                        d_results, stream))
+
+    def counters(self):
+        out = (ctypes.c_uint64 * len(CTR_NAMES))()
+        _gpu_check(gpu_lib().salt_gpu_ws_counters(self._ws, out))
+        return dict(zip(CTR_NAMES, [int(x) for x in out]))
+
+    def close(self):
+        lib = gpu_lib()
+        if self._ws:
+            lib.salt_gpu_ws_destroy(self._ws)
+            self._ws = None
+        if self._ix:
+            lib.salt_gpu_index_detach(self._ix)
+            self._ix = None
+
+
+_NT4 = np.full(256, 4, dtype=np.uint8)
+for _i, _c in enumerate("ACGT"):
+    _NT4[ord(_c)] = _i
+    _NT4[ord(_c.lower())] = _i
+
+
+def read_fastq(path):
+    """4-line FASTQ (optionally .gz) -> names, seqs (codes), offs, quals.  Names end at the first
+    blank and lose a trailing /1 or /2 like trim_readno (query.c:139-143)."""
+    import gzip
+    op = gzip.open if path.endswith(".gz") else open
+    names, quals, chunks, offs = [], [], [], [0]
+    with op(path, "rb") as f:
+        while True:
+            h = f.readline()
+            if not h:
+                break
+            if not h.startswith(b"@"):
+                continue
+            s = f.readline().rstrip(b"\r\n")
+            f.readline()
+            q = f.readline().rstrip(b"\r\n")
+            nm = h[1:].split()[0] if len(h) > 1 else b""
+            if len(nm) > 2 and nm[-2:-1] == b"/" and nm[-1:].isdigit():
+                nm = nm[:-2]
+            names.append(nm)
+            quals.append(q)
+            chunks.append(_NT4[np.frombuffer(s, dtype=np.uint8)])
+            offs.append(offs[-1] + len(s))
+    seqs = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint8)
+    return names, seqs, np.array(offs, dtype=np.uint32), quals
+
+
+def sam_text(index, opt, names, seqs, offs, quals, results, header=True):
+    """The SAM stream `salt` prints (without @PG): header, then one line per read in input order."""
+    out = []
+    if header:
+        out.append(index.sam_header(opt))
+    for i in range(len(names)):
+        rec = index.samse(opt, names[i], seqs[offs[i]:offs[i + 1]], quals[i], results[i:i + 1])
+        out.append(rec + b"\n")
+    return b"".join(out)

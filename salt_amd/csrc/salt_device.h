@@ -1,0 +1,111 @@
+// salt_amd/csrc/salt_device.h -- device-side index layout and the rank/LF primitives (gfx950).
+//
+// The *file* formats are salt's; the layout in HBM is ours.  Every structure below
+// is a pure function of the index files, so results stay bit-identical to the reference:
+//
+//   COcc   32 B per 64 BWT symbols of the plain-genome ("C") FM-index: 4 running counts + 2 bit
+//          planes.  Occ(k,c) = one 32-byte read + one 64-bit popcount.   (replaces bwt.c:113-175 on
+//          the 48 B / 128-symbol BWA blocks of bwt.h:57-64)
+//   ROcc   64 B per 128 symbols of the SNP local-pattern ("R") FM-index, alphabet {A,C,G,T,#}:
+//          4 running counts + 3 bit planes ('#' count = position - sum).  (replaces rbwt.c:40-191:
+//          major/minor checkpoints + <=128-symbol scan through a 64 K-entry table)
+//   c_sa   the FULL suffix array of the C index (4 B x (G+1)), expanded once at attach time from the
+//          1-in-8 samples by the reference's own LF walk (bwt.c:89-102) -- locate is then one load.
+//   r_pos  for every R suffix-array row the value Rbwt_back_bwt_sa() (rbwt.c:316-333) returns,
+//          again expanded once at attach time.
+//   r_lkt  (k,l) of the R index after backward-searching each 12-mer from the full range, i.e. the
+//          first 12 iterations of Rbwt_exact_match_backward (rbwt.c:619-648), tabulated once.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace salt {
+
+struct COcc { uint32_t cnt[4]; uint64_t lo, hi; };                 // 32 B
+struct ROcc { uint32_t cnt[4]; uint64_t b0[2], b1[2], b2[2]; };    // 64 B
+static_assert(sizeof(COcc) == 32, "COcc");
+static_assert(sizeof(ROcc) == 64, "ROcc");
+
+// Header at the start of the device image; offsets are relative to the image base so that the
+// image can be broadcast to other GPUs byte-for-byte.
+struct ImageHeader {
+    uint64_t magic, bytes;
+    uint32_t c_primary, c_L2[5], c_seq_len, c_sa_intv;
+    uint32_t lkt_len, lkt_n;
+    uint32_t r_text_len, r_inv_sa0, r_cum[6];
+    uint32_t ref_len, r_lkt_len;
+    uint64_t off_c_occ, off_c_sa, off_lkt, off_r_occ, off_r_pos, off_r_lkt, off_ref;
+    uint64_t n_c_blocks, n_r_blocks;
+    uint64_t reserved[8];
+};
+static const uint64_t IMAGE_MAGIC = 0x53414c5447465839ull;          // "SALTGFX9"
+
+// What kernels receive (by value): resolved pointers + scalars.
+struct IndexView {
+    const COcc *c_occ; const uint32_t *c_sa; const uint32_t *lkt;
+    const ROcc *r_occ; const uint32_t *r_pos; const uint2 *r_lkt; const uint32_t *ref;
+    uint32_t c_primary, c_L2[5], c_seq_len;
+    uint32_t r_text_len, r_inv_sa0, r_cum[6];
+    uint32_t ref_len, lkt_len, r_lkt_len;
+};
+
+__device__ __forceinline__ uint32_t sel4(uint4 v, uint32_t c)
+{
+    return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
+}
+
+// Occ(k, c) of the C index: occurrences of c in BWT rows [0, k]  (bwt_occ, bwt.c:113-138)
+__device__ __forceinline__ uint32_t c_occ(const IndexView &ix, uint32_t k, uint32_t c)
+{
+    if (k == ix.c_seq_len) return ix.c_L2[c + 1] - ix.c_L2[c];
+    if (k == 0xFFFFFFFFu) return 0;
+    k -= (k >= ix.c_primary);                       // '$' is not stored (bwt.c:120)
+    const uint4 *p = reinterpret_cast<const uint4 *>(ix.c_occ + (k >> 6));
+    uint4 cnt = p[0];
+    uint4 pl = p[1];
+    uint64_t lo = (uint64_t)pl.x | ((uint64_t)pl.y << 32), hi = (uint64_t)pl.z | ((uint64_t)pl.w << 32);
+    uint32_t m = (k & 63u) + 1u;
+    uint64_t mask = m == 64 ? ~0ull : ((1ull << m) - 1ull);
+    uint64_t eq = ((c & 1) ? lo : ~lo) & ((c & 2) ? hi : ~hi) & mask;
+    return sel4(cnt, c) + (uint32_t)__popcll(eq);
+}
+
+// symbol k of the $-removed C BWT (bwt_B0, bwt.h:64) -- used only by the attach-time SA expansion
+__device__ __forceinline__ uint32_t c_sym(const IndexView &ix, uint32_t k)
+{
+    const COcc *r = ix.c_occ + (k >> 6);
+    uint32_t b = k & 63u;
+    return (uint32_t)((r->lo >> b) & 1ull) | ((uint32_t)((r->hi >> b) & 1ull) << 1);
+}
+
+// Occ(index, c) of the R index: occurrences of c among the first `index` stored symbols
+// (Rbwt_BWTOccValue, rbwt.c:159-191).  c in 0..4 ('#' = 4).
+__device__ __forceinline__ uint32_t r_occ(const IndexView &ix, uint32_t index, uint32_t c)
+{
+    index -= (index > ix.r_inv_sa0);                // '$' is not stored (rbwt.c:165)
+    uint32_t blk = index >> 7, m = index & 127u;
+    const uint4 *p = reinterpret_cast<const uint4 *>(ix.r_occ + blk);
+    uint4 cnt = p[0], q0 = p[1], q1 = p[2], q2 = p[3];
+    uint64_t b0l = (uint64_t)q0.x | ((uint64_t)q0.y << 32), b0h = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
+    uint64_t b1l = (uint64_t)q1.x | ((uint64_t)q1.y << 32), b1h = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
+    uint64_t b2l = (uint64_t)q2.x | ((uint64_t)q2.y << 32), b2h = (uint64_t)q2.z | ((uint64_t)q2.w << 32);
+    uint64_t ml = m >= 64 ? ~0ull : ((1ull << m) - 1ull);
+    uint64_t mh = m > 64 ? ((1ull << (m - 64)) - 1ull) : 0ull;
+    uint64_t el = ((c & 1) ? b0l : ~b0l) & ((c & 2) ? b1l : ~b1l) & ((c & 4) ? b2l : ~b2l) & ml;
+    uint64_t eh = ((c & 1) ? b0h : ~b0h) & ((c & 2) ? b1h : ~b1h) & ((c & 4) ? b2h : ~b2h) & mh;
+    uint32_t base = c < 4 ? sel4(cnt, c) : (blk << 7) - (cnt.x + cnt.y + cnt.z + cnt.w);
+    return base + (uint32_t)__popcll(el) + (uint32_t)__popcll(eh);
+}
+
+// Rbwt_bwt2nt (rbwt.h:103-122): BWT symbol of row pos; the '$' row reads as '#'
+__device__ __forceinline__ uint32_t r_bwt2nt(const IndexView &ix, uint32_t pos)
+{
+    if (pos == ix.r_inv_sa0) return 4;
+    pos -= (pos > ix.r_inv_sa0);
+    const ROcc *r = ix.r_occ + (pos >> 7);
+    uint32_t h = (pos >> 6) & 1u, b = pos & 63u;
+    return (uint32_t)((r->b0[h] >> b) & 1ull) | ((uint32_t)((r->b1[h] >> b) & 1ull) << 1) |
+           ((uint32_t)((r->b2[h] >> b) & 1ull) << 2);
+}
+
+} // namespace salt

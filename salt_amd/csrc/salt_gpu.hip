@@ -1,0 +1,298 @@
+// salt_amd/csrc/salt_gpu.hip -- the C ABI of include/salt_gpu.h: device-index attach (re-packing
+// the file-format arrays into the HBM layout of salt_device.h), per-batch workspaces, and the
+// align entry points.  gfx950 only; fails loudly when no HIP device is usable.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "salt_kernels.h"
+
+using namespace salt;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+    return fail(SALT_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct salt_gpu_index {
+    int device = 0;
+    uint8_t *image = nullptr;      // device
+    uint64_t bytes = 0;
+    bool owns = true;
+    ImageHeader hdr;               // host copy
+    IndexView view;
+};
+
+struct salt_gpu_ws {
+    salt_gpu_index *ix = nullptr;
+    uint32_t max_reads = 0; uint64_t max_bases = 0;
+    uint8_t *d_seqs = nullptr; uint32_t *d_offs = nullptr; salt_result_t *d_results = nullptr;
+    uint4 *d_sai_c = nullptr, *d_sai_r = nullptr; uint64_t sai_cap = 0;
+    unsigned long long *d_ctr = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+static void make_view(salt_gpu_index *ix)
+{
+    const ImageHeader &h = ix->hdr;
+    IndexView &v = ix->view;
+    uint8_t *b = ix->image;
+    v.c_occ = reinterpret_cast<const COcc *>(b + h.off_c_occ);
+    v.c_sa = reinterpret_cast<const uint32_t *>(b + h.off_c_sa);
+    v.lkt = reinterpret_cast<const uint32_t *>(b + h.off_lkt);
+    v.r_occ = reinterpret_cast<const ROcc *>(b + h.off_r_occ);
+    v.r_pos = reinterpret_cast<const uint32_t *>(b + h.off_r_pos);
+    v.r_lkt = reinterpret_cast<const uint2 *>(b + h.off_r_lkt);
+    v.ref = reinterpret_cast<const uint32_t *>(b + h.off_ref);
+    v.c_primary = h.c_primary; memcpy(v.c_L2, h.c_L2, sizeof v.c_L2); v.c_seq_len = h.c_seq_len;
+    v.r_text_len = h.r_text_len; v.r_inv_sa0 = h.r_inv_sa0; memcpy(v.r_cum, h.r_cum, sizeof v.r_cum);
+    v.ref_len = h.ref_len; v.lkt_len = h.lkt_len; v.r_lkt_len = h.r_lkt_len;
+}
+
+extern "C" const char *salt_gpu_last_error(void) { return g_err.c_str(); }
+extern "C" uint32_t salt_gpu_result_size(void) { return (uint32_t)sizeof(salt_result_t); }
+
+extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, salt_gpu_index_t **out)
+{
+    if (!h || !out) return fail(SALT_E_INVAL, "null argument");
+    if (!h->c_bwt || !h->c_sa || !h->lkt || !h->r_bwt || !h->r_sa || !h->ref) return fail(SALT_E_INDEX, "missing index array");
+    if (h->c_sa_intv == 0 || h->c_n_sa != (h->c_seq_len + h->c_sa_intv) / h->c_sa_intv) return fail(SALT_E_INDEX, "inconsistent C suffix-array sampling");
+    if (h->lkt_len < 1 || h->lkt_len > 14 || h->lkt_n != (1u << (2 * h->lkt_len)) + 1) return fail(SALT_E_INDEX, "unsupported lookup-table length");
+    if (h->r_n_sa != h->r_text_len - h->r_cum[4] + 1) return fail(SALT_E_INDEX, "R suffix array size does not match '#' count");
+    if ((uint64_t)h->r_bwt_words * 8 < h->r_text_len) return fail(SALT_E_INDEX, "R BWT shorter than its text length");
+    int n_dev = 0;
+    HIPCHK(hipGetDeviceCount(&n_dev));
+    if (n_dev <= 0) return fail(SALT_E_HIP, "no HIP device visible: the salt GPU path cannot run (there is no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+
+    salt_gpu_index *ix = new salt_gpu_index();
+    ix->device = device;
+    ImageHeader &hd = ix->hdr;
+    memset(&hd, 0, sizeof hd);
+    hd.magic = IMAGE_MAGIC;
+    hd.c_primary = h->c_primary; memcpy(hd.c_L2, h->c_L2, sizeof hd.c_L2); hd.c_seq_len = h->c_seq_len; hd.c_sa_intv = h->c_sa_intv;
+    hd.lkt_len = h->lkt_len; hd.lkt_n = h->lkt_n;
+    hd.r_text_len = h->r_text_len; hd.r_inv_sa0 = h->r_inv_sa0; memcpy(hd.r_cum, h->r_cum, sizeof hd.r_cum);
+    hd.ref_len = h->ref_len; hd.r_lkt_len = h->lkt_len;
+    hd.n_c_blocks = (uint64_t)h->c_seq_len / 64 + 1;
+    hd.n_r_blocks = (uint64_t)h->r_text_len / 128 + 1;
+    const uint64_t ref_words = ((uint64_t)h->ref_len + 7) / 8;
+    uint64_t off = align_up(sizeof(ImageHeader), 256);
+    hd.off_c_occ = off; off = align_up(off + hd.n_c_blocks * sizeof(COcc), 256);
+    hd.off_c_sa = off;  off = align_up(off + ((uint64_t)h->c_seq_len + 1) * 4, 256);
+    hd.off_lkt = off;   off = align_up(off + (uint64_t)h->lkt_n * 4, 256);
+    hd.off_r_occ = off; off = align_up(off + hd.n_r_blocks * sizeof(ROcc), 256);
+    hd.off_r_pos = off; off = align_up(off + ((uint64_t)h->r_text_len + 1) * 4, 256);
+    hd.off_r_lkt = off; off = align_up(off + (1ull << (2 * h->lkt_len)) * 8, 256);
+    hd.off_ref = off;   off = align_up(off + (ref_words + 4) * 4, 256);
+    hd.bytes = off;
+    ix->bytes = off;
+
+    // ---- re-pack on the host ----
+    std::vector<COcc> cocc(hd.n_c_blocks);
+    {
+        uint32_t cnt[4] = { 0, 0, 0, 0 };
+        for (uint64_t b = 0; b < hd.n_c_blocks; ++b) {
+            COcc rec; memcpy(rec.cnt, cnt, sizeof cnt); rec.lo = rec.hi = 0;
+            for (uint32_t i = 0; i < 64; ++i) {
+                uint64_t k = b * 64 + i;
+                if (k >= h->c_seq_len) break;
+                uint64_t widx = k / 128 * 12 + 4 + (k % 128) / 16;
+                if (widx >= h->c_bwt_size) { delete ix; return fail(SALT_E_INDEX, "C BWT array shorter than seq_len"); }
+                uint32_t s = (h->c_bwt[widx] >> ((~k & 15u) << 1)) & 3u;
+                rec.lo |= (uint64_t)(s & 1u) << i; rec.hi |= (uint64_t)(s >> 1) << i;
+                ++cnt[s];
+            }
+            cocc[b] = rec;
+        }
+    }
+    std::vector<ROcc> rocc(hd.n_r_blocks);
+    {
+        uint32_t cnt[5] = { 0, 0, 0, 0, 0 };
+        for (uint64_t b = 0; b < hd.n_r_blocks; ++b) {
+            ROcc rec; memset(&rec, 0, sizeof rec); memcpy(rec.cnt, cnt, 16);
+            for (uint32_t i = 0; i < 128; ++i) {
+                uint64_t k = b * 128 + i;
+                if (k >= h->r_text_len) break;
+                uint32_t s = (h->r_bwt[k >> 3] >> ((7u - (k & 7u)) * 4u)) & 15u;
+                if (s > 4) { delete ix; return fail(SALT_E_INDEX, "R BWT holds a symbol outside {A,C,G,T,#}"); }
+                uint32_t hh = i >> 6, bb = i & 63u;
+                rec.b0[hh] |= (uint64_t)(s & 1u) << bb; rec.b1[hh] |= (uint64_t)((s >> 1) & 1u) << bb; rec.b2[hh] |= (uint64_t)(s >> 2) << bb;
+                ++cnt[s];
+            }
+            rocc[b] = rec;
+        }
+    }
+
+    // ---- upload ----
+    hipError_t e = hipMalloc((void **)&ix->image, ix->bytes);
+    if (e != hipSuccess) { delete ix; return fail(SALT_E_NOMEM, std::string("hipMalloc(index image): ") + hipGetErrorString(e)); }
+    uint32_t *d_sa_s = nullptr, *d_r_sa = nullptr;
+#define CHK2(x) do { hipError_t e2 = (x); if (e2 != hipSuccess) { hipFree(ix->image); hipFree(d_sa_s); hipFree(d_r_sa); delete ix; \
+    return fail(SALT_E_HIP, std::string(#x) + ": " + hipGetErrorString(e2)); } } while (0)
+    CHK2(hipMemset(ix->image, 0, ix->bytes));
+    CHK2(hipMemcpy(ix->image, &hd, sizeof hd, hipMemcpyHostToDevice));
+    CHK2(hipMemcpy(ix->image + hd.off_c_occ, cocc.data(), cocc.size() * sizeof(COcc), hipMemcpyHostToDevice));
+    CHK2(hipMemcpy(ix->image + hd.off_lkt, h->lkt, (uint64_t)h->lkt_n * 4, hipMemcpyHostToDevice));
+    CHK2(hipMemcpy(ix->image + hd.off_r_occ, rocc.data(), rocc.size() * sizeof(ROcc), hipMemcpyHostToDevice));
+    CHK2(hipMemcpy(ix->image + hd.off_ref, h->ref, ref_words * 4, hipMemcpyHostToDevice));
+    make_view(ix);
+    // ---- expand the sampled suffix arrays / tabulate the R 12-mers on the device ----
+    CHK2(hipMalloc((void **)&d_sa_s, (uint64_t)h->c_n_sa * 4));
+    CHK2(hipMalloc((void **)&d_r_sa, (uint64_t)h->r_n_sa * 4));
+    CHK2(hipMemcpy(d_sa_s, h->c_sa, (uint64_t)h->c_n_sa * 4, hipMemcpyHostToDevice));
+    CHK2(hipMemcpy(d_r_sa, h->r_sa, (uint64_t)h->r_n_sa * 4, hipMemcpyHostToDevice));
+    launch_build_c_sa(ix->view, d_sa_s, h->c_sa_intv, reinterpret_cast<uint32_t *>(ix->image + hd.off_c_sa), nullptr);
+    launch_build_r_pos(ix->view, d_r_sa, reinterpret_cast<uint32_t *>(ix->image + hd.off_r_pos), nullptr);
+    launch_build_r_lkt(ix->view, h->lkt_len, reinterpret_cast<uint2 *>(ix->image + hd.off_r_lkt), nullptr);
+    CHK2(hipGetLastError());
+    CHK2(hipDeviceSynchronize());
+    hipFree(d_sa_s); hipFree(d_r_sa);
+#undef CHK2
+    *out = ix;
+    return SALT_OK;
+}
+
+extern "C" void salt_gpu_index_detach(salt_gpu_index_t *ix)
+{
+    if (!ix) return;
+    if (ix->owns && ix->image) { hipSetDevice(ix->device); hipFree(ix->image); }
+    delete ix;
+}
+
+extern "C" int salt_gpu_index_image(const salt_gpu_index_t *ix, void **dev_ptr, uint64_t *bytes)
+{
+    if (!ix || !dev_ptr || !bytes) return fail(SALT_E_INVAL, "null argument");
+    *dev_ptr = ix->image; *bytes = ix->bytes;
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_index_attach_image(void *dev_ptr, uint64_t bytes, int device, salt_gpu_index_t **out)
+{
+    if (!dev_ptr || !out || bytes < sizeof(ImageHeader)) return fail(SALT_E_INVAL, "bad image");
+    HIPCHK(hipSetDevice(device));
+    salt_gpu_index *ix = new salt_gpu_index();
+    ix->device = device; ix->image = static_cast<uint8_t *>(dev_ptr); ix->bytes = bytes; ix->owns = false;
+    hipError_t e = hipMemcpy(&ix->hdr, dev_ptr, sizeof(ImageHeader), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { delete ix; return fail(SALT_E_HIP, std::string("hipMemcpy(image header): ") + hipGetErrorString(e)); }
+    if (ix->hdr.magic != IMAGE_MAGIC || ix->hdr.bytes != bytes) { delete ix; return fail(SALT_E_INDEX, "not a salt device-index image"); }
+    make_view(ix);
+    *out = ix;
+    return SALT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint64_t max_bases, salt_gpu_ws_t **out)
+{
+    if (!ix || !out || max_reads == 0) return fail(SALT_E_INVAL, "bad workspace size");
+    HIPCHK(hipSetDevice(ix->device));
+    salt_gpu_ws *ws = new salt_gpu_ws();
+    ws->ix = ix; ws->max_reads = max_reads; ws->max_bases = max_bases;
+#define CHKW(x) do { hipError_t e2 = (x); if (e2 != hipSuccess) { salt_gpu_ws_destroy(ws); \
+    return fail(SALT_E_NOMEM, std::string(#x) + ": " + hipGetErrorString(e2)); } } while (0)
+    CHKW(hipMalloc((void **)&ws->d_seqs, max_bases + 64));
+    CHKW(hipMalloc((void **)&ws->d_offs, ((uint64_t)max_reads + 1) * 4));
+    CHKW(hipMalloc((void **)&ws->d_results, (uint64_t)max_reads * sizeof(salt_result_t)));
+    CHKW(hipMemset(ws->d_results, 0, (uint64_t)max_reads * sizeof(salt_result_t)));
+    CHKW(hipMalloc((void **)&ws->d_ctr, SALT_CTR_N * sizeof(unsigned long long)));
+    CHKW(hipMemset(ws->d_ctr, 0, SALT_CTR_N * sizeof(unsigned long long)));
+    CHKW(hipStreamCreate(&ws->stream));
+#undef CHKW
+    *out = ws;
+    return SALT_OK;
+}
+
+extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
+{
+    if (!ws) return;
+    hipSetDevice(ws->ix->device);
+    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_ctr);
+    if (ws->stream) hipStreamDestroy(ws->stream);
+    delete ws;
+}
+
+static int check_opt(const salt_gpu_index *ix, const salt_aln_opt_t *o, uint32_t max_len, uint32_t *spr_out)
+{
+    if (o->l_seed < (int32_t)ix->hdr.lkt_len) return fail(SALT_E_INVAL, "l_seed shorter than the lookup-table k-mer");
+    if (o->l_overlap <= 0) return fail(SALT_E_INVAL, "l_overlap must be positive (aln.c:223 sets it to l_seed when -r is absent)");
+    if (o->max_locate == 0 || o->max_locate > SALT_MAX_LOCATE) return fail(SALT_E_INVAL, "max_locate (-m) must be in 1..1024");
+    if (o->max_hits != SALT_MAX_HITS) return fail(SALT_E_INVAL, "max_hits is fixed at 5 (aln.h:133)");
+    if (max_len > SALT_MAX_READ_LEN) return fail(SALT_E_INVAL, "read longer than SALT_MAX_READ_LEN (512)");
+    uint32_t spr = 1;
+    if (max_len >= (uint32_t)o->l_seed) spr = (max_len - (uint32_t)o->l_seed) / (uint32_t)o->l_overlap + 1;
+    if (spr > SALT_MAX_SEED_SLOTS) return fail(SALT_E_INVAL, "more than 256 seeds per strand: raise -r or shorten the reads");
+    *spr_out = spr;
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint32_t n_reads, uint32_t max_read_len,
+                                          const void *d_seqs, const void *d_offs, void *d_results, void *hip_stream)
+{
+    if (!ws || !o || !d_seqs || !d_offs || !d_results) return fail(SALT_E_INVAL, "null argument");
+    if (n_reads == 0) return SALT_OK;
+    uint32_t spr = 0;
+    int rc = check_opt(ws->ix, o, max_read_len, &spr);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ws->ix->device));
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    uint64_t items = (uint64_t)n_reads * 2u * spr;
+    if (items > ws->sai_cap) {                     // grows rarely; not on the steady-state path
+        HIPCHK(hipStreamSynchronize(st));
+        hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); ws->d_sai_c = ws->d_sai_r = nullptr; ws->sai_cap = 0;
+        HIPCHK(hipMalloc((void **)&ws->d_sai_c, items * sizeof(uint4)));
+        HIPCHK(hipMalloc((void **)&ws->d_sai_r, items * sizeof(uint4)));
+        ws->sai_cap = items;
+    }
+    SeedParams sp; sp.n_reads = n_reads; sp.spr = spr; sp.l_seed = o->l_seed; sp.l_overlap = o->l_overlap;
+    sp.max_seed = o->max_seed; sp.seed_only_ref = o->seed_only_ref;
+    AlignParams ap; ap.n_reads = n_reads; ap.spr = spr; ap.l_seed = o->l_seed; ap.max_locate = o->max_locate; ap.max_hits = o->max_hits;
+    unsigned long long *ctr = o->collect_counters ? ws->d_ctr : nullptr;
+    launch_seed(ws->ix->view, sp, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r, ctr, st);
+    launch_align(ws->ix->view, ap, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
+                 static_cast<salt_result_t *>(d_results), ctr, st);
+    HIPCHK(hipGetLastError());
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_align_se(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint32_t n_reads, const uint8_t *seqs,
+                                 const uint32_t *offs, salt_result_t *results)
+{
+    if (!ws || !o || !seqs || !offs || !results) return fail(SALT_E_INVAL, "null argument");
+    if (n_reads == 0) return SALT_OK;
+    if (n_reads > ws->max_reads) return fail(SALT_E_CAPACITY, "more reads than the workspace holds");
+    if (offs[0] != 0) return fail(SALT_E_INVAL, "offs[0] must be 0");
+    uint64_t bases = offs[n_reads];
+    if (bases > ws->max_bases) return fail(SALT_E_CAPACITY, "more bases than the workspace holds");
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n_reads; ++i) {
+        if (offs[i + 1] < offs[i]) return fail(SALT_E_INVAL, "offs must be non-decreasing");
+        uint32_t l = offs[i + 1] - offs[i];
+        if (l == 0) return fail(SALT_E_INVAL, "empty read");
+        max_len = l > max_len ? l : max_len;
+    }
+    HIPCHK(hipSetDevice(ws->ix->device));
+    HIPCHK(hipMemcpyAsync(ws->d_seqs, seqs, bases, hipMemcpyHostToDevice, ws->stream));
+    HIPCHK(hipMemcpyAsync(ws->d_offs, offs, ((uint64_t)n_reads + 1) * 4, hipMemcpyHostToDevice, ws->stream));
+    int rc = salt_gpu_align_se_resident(ws, o, n_reads, max_len, ws->d_seqs, ws->d_offs, ws->d_results, ws->stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(results, ws->d_results, (uint64_t)n_reads * sizeof(salt_result_t), hipMemcpyDeviceToHost, ws->stream));
+    HIPCHK(hipStreamSynchronize(ws->stream));
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_ws_counters(salt_gpu_ws_t *ws, uint64_t out[SALT_CTR_N])
+{
+    if (!ws || !out) return fail(SALT_E_INVAL, "null argument");
+    HIPCHK(hipSetDevice(ws->ix->device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long tmp[SALT_CTR_N];
+    HIPCHK(hipMemcpy(tmp, ws->d_ctr, sizeof tmp, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(ws->d_ctr, 0, sizeof tmp));
+    for (int i = 0; i < SALT_CTR_N; ++i) out[i] = tmp[i];
+    return SALT_OK;
+}

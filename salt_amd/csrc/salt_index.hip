@@ -1,0 +1,79 @@
+// salt_amd/csrc/salt_index.hip -- attach-time expansion kernels (run once per index, gfx950).
+//
+// They replay the reference's own locate walks for EVERY suffix-array row so that the per-read
+// kernels replace a data-dependent walk by one load:
+//   k_build_c_sa   bwt_sa / bwt_invPsi                 (Align_src/bwt.c:89-102, bwt.h:67-71)
+//   k_build_r_pos  Rbwt_back_bwt_sa                    (Align_src/rbwt.c:316-333)
+//   k_build_r_lkt  first lkt_len steps of Rbwt_exact_match_backward from (0, textLength)
+//                                                      (Align_src/rbwt.c:619-648, alnse.c:273-275)
+#include "salt_device.h"
+#include "salt_kernels.h"
+
+namespace salt {
+
+__global__ void __launch_bounds__(256)
+k_build_c_sa(IndexView ix, const uint32_t *__restrict__ sa_sampled, uint32_t intv, uint32_t *__restrict__ out)
+{
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > ix.c_seq_len) return;
+    uint32_t k = (uint32_t)j, steps = 0;
+    while (k % intv != 0) {
+        ++steps;
+        if (k == ix.c_primary) k = 0;
+        else {
+            uint32_t c = c_sym(ix, k < ix.c_primary ? k : k - 1);
+            k = ix.c_L2[c] + c_occ(ix, k, c);
+        }
+    }
+    out[j] = steps + sa_sampled[k / intv];          // sa_sampled[0] = 0xFFFFFFFF: wraps exactly as in C
+}
+
+__global__ void __launch_bounds__(256)
+k_build_r_pos(IndexView ix, const uint32_t *__restrict__ r_sa, uint32_t *__restrict__ out)
+{
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > ix.r_text_len) return;
+    uint32_t sa_index = (uint32_t)j, step = 0;
+    const uint32_t n_acgt = ix.r_cum[4];
+    // every walk ends at a '#' (the text starts with one); the bound only guards a corrupt index
+    while (sa_index <= n_acgt && step < (1u << 20)) {
+        uint32_t c = r_bwt2nt(ix, sa_index);
+        sa_index = ix.r_cum[c] + r_occ(ix, sa_index, c) + 1;
+        ++step;
+    }
+    out[j] = sa_index > n_acgt ? r_sa[sa_index - n_acgt - 1] + step - 1 : 0xFFFFFFFFu;
+}
+
+__global__ void __launch_bounds__(256)
+k_build_r_lkt(IndexView ix, uint32_t len, uint2 *__restrict__ out)
+{
+    uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (1ull << (2 * len))) return;
+    uint32_t k0 = 0, l0 = ix.r_text_len;
+    for (uint32_t step = 0; step < len && k0 <= l0; ++step) {
+        uint32_t c = (uint32_t)(x >> (2 * step)) & 3u;     // last base of the 12-mer first
+        k0 = ix.r_cum[c] + r_occ(ix, k0, c) + 1;
+        l0 = ix.r_cum[c] + r_occ(ix, l0 + 1, c);
+    }
+    out[x] = k0 <= l0 ? make_uint2(k0, l0) : make_uint2(1u, 0u);
+}
+
+void launch_build_c_sa(const IndexView &ix, const uint32_t *sa_sampled, uint32_t sa_intv, uint32_t *out, hipStream_t st)
+{
+    uint64_t n = (uint64_t)ix.c_seq_len + 1;
+    hipLaunchKernelGGL(k_build_c_sa, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, ix, sa_sampled, sa_intv, out);
+}
+
+void launch_build_r_pos(const IndexView &ix, const uint32_t *r_sa, uint32_t *out, hipStream_t st)
+{
+    uint64_t n = (uint64_t)ix.r_text_len + 1;
+    hipLaunchKernelGGL(k_build_r_pos, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, ix, r_sa, out);
+}
+
+void launch_build_r_lkt(const IndexView &ix, uint32_t len, uint2 *out, hipStream_t st)
+{
+    uint64_t n = 1ull << (2 * len);
+    hipLaunchKernelGGL(k_build_r_lkt, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, ix, len, out);
+}
+
+} // namespace salt

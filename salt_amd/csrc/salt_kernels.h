@@ -1,0 +1,33 @@
+// salt_amd/csrc/salt_kernels.h -- host-visible declarations of the kernel launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/salt_gpu.h"
+#include "salt_device.h"
+
+namespace salt {
+
+struct SeedParams {
+    uint32_t n_reads, spr;          // spr: seed slots per (read, strand) = ceil((Lmax-k+1)/overlap)
+    int32_t  l_seed, l_overlap;
+    uint32_t max_seed;
+    int32_t  seed_only_ref;
+};
+
+struct AlignParams {
+    uint32_t n_reads, spr;
+    int32_t  l_seed;
+    uint32_t max_locate;
+    int32_t  max_hits;
+};
+
+void launch_seed(const IndexView &ix, const SeedParams &sp, const uint8_t *seqs, const uint32_t *offs, uint4 *sai_c,
+                 uint4 *sai_r, unsigned long long *ctr, hipStream_t st);
+void launch_align(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
+                  const uint4 *sai_r, salt_result_t *results, unsigned long long *ctr, hipStream_t st);
+
+// attach-time expansion kernels (salt_index.hip)
+void launch_build_c_sa(const IndexView &ix, const uint32_t *sa_sampled, uint32_t sa_intv, uint32_t *out, hipStream_t st);
+void launch_build_r_pos(const IndexView &ix, const uint32_t *r_sa, uint32_t *out, hipStream_t st);
+void launch_build_r_lkt(const IndexView &ix, uint32_t len, uint2 *out, hipStream_t st);
+
+} // namespace salt
