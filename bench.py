@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of salt's single-end alignment hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload chr21|mini|tiny]
+
+A "step" is one pass of the hot path (k_seed + k_align behind salt_gpu_align_se_resident) over one
+batch of synthetic reads that is already resident in HBM.  Per-GPU work is fixed (weak scaling): every
+rank aligns its own read shard against its own replica of the device index; rank 0 packs the index and
+the other ranks receive the packed image by one RCCL broadcast (no collective on the data path).
+
+Prints ONE JSON line (rank 0) with the metric of BASELINE.json plus
+  "roofline":     dominant kernel, algorithmic bytes per launch / its HIP-event time vs 8 TB/s
+  "cpu_baseline": the CPU oracle (bit-exact restatement of the reference) on a bounded sample of the
+                  same reads on this box's host cores, also used to check the GPU results.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes(ctr, L):
+    """bytes per read of the reference algorithm's logical accesses, split by kernel.
+    ctr: oracle counters over a sample.  R-Occ scan bytes are taken as syms/2 (no word rounding)."""
+    n = float(ctr["n_reads"])
+    seed = (2 * L * n + 8 * ctr["n_lkt"] + 48 * ctr["n_occC_seed"] + 8 * ctr["n_occR_seed"]
+            + ctr["n_occR_syms_seed"] / 2.0)
+    occC_loc = ctr["n_occC"] - ctr["n_occC_seed"]
+    occR_loc = ctr["n_occR"] - ctr["n_occR_seed"]
+    syms_loc = ctr["n_occR_syms"] - ctr["n_occR_syms_seed"]
+    align = (48 * occC_loc + 8 * occR_loc + syms_loc / 2.0 + 4 * (ctr["n_saC"] + ctr["n_saR"] + ctr["n_bwt2nt"])
+             + 4 * ctr["n_verify_words"] + (L + 4) / 2.0 * ctr["n_lv"] + 24 * n + 8 * ctr["n_hits_out"])
+    return seed / n, align / n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=os.environ.get("SALT_BENCH_WORKLOAD", "chr21"))
+    ap.add_argument("--cpu-sample", type=int, default=200000, help="reads given to the CPU baseline")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import salt_amd
+    from salt_amd import workload
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = workload.CONFIGS[args.workload]
+    L, n_reads = cfg["read_len"], cfg["n_reads"]
+    cache = os.environ.get("SALT_BENCH_CACHE", "/tmp/salt_bench_cache")
+
+    # ---- index files (rank 0 builds them with the product's own salt-idx equivalent) ----
+    t0 = time.time()
+    w = None
+    if rank == 0:
+        w = workload.prepare(args.workload, cache)
+        log("workload %s ready in %.1f s (%s)" % (args.workload, time.time() - t0, w["dir"]))
+    if world > 1:
+        dist.barrier()
+    # every rank regenerates the genome/SNPs from the seeds to draw its own read shard
+    genome = w["genome"] if w else workload.make_genome(cfg["genome_len"])
+    if w:
+        pos, mask = w["snp_pos"], w["snp_mask"]
+    else:
+        pos, mask = workload.make_snps(genome, cfg["n_snps"])
+    seqs, offs, _, _ = workload.make_reads(genome, pos, mask, n_reads, L, seed=1 + rank)
+
+    # ---- device index: rank 0 packs, the others get the image by one broadcast over RCCL ----
+    t0 = time.time()
+    idx = None
+    if rank == 0:
+        idx = salt_amd.Index.reload(w["prefix"], rebuild_lkt=False)
+        aln = salt_amd.GpuAligner(idx, device=local_rank, max_reads=n_reads, max_bases=n_reads * L)
+        ptr, nbytes = aln.image()
+    img = None
+    if world > 1:
+        sz = torch.tensor([nbytes if rank == 0 else 0], dtype=torch.int64, device=dev)
+        dist.broadcast(sz, 0)
+        nbytes = int(sz.item())
+        img = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            aln.image_copy(img.data_ptr(), nbytes)
+        dist.broadcast(img, 0)
+        if rank != 0:
+            aln = salt_amd.GpuAligner(None, device=local_rank, max_reads=n_reads, max_bases=n_reads * L,
+                                      image=(img.data_ptr(), nbytes))
+    torch.cuda.synchronize()
+    if rank == 0:
+        log("device index: %.2f GiB, attach+broadcast %.1f s" % (nbytes / 2**30, time.time() - t0))
+
+    opt = salt_amd.AlnOpt(l_seed=cfg["k"])
+    d_seqs = torch.from_numpy(seqs).to(dev)
+    d_offs = torch.from_numpy(offs.view(np.int32)).to(dev)
+    d_res = torch.zeros(n_reads * salt_amd.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        aln.align_resident(opt, n_reads, L, d_seqs.data_ptr(), d_offs.data_ptr(), d_res.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    aln.timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_seed, ms_align, n_calls = aln.kernel_ms()
+
+    out = None
+    if rank == 0:
+        total_reads = n_reads * world * args.steps
+        value = total_reads / dt / 1e6
+        out = {
+            "metric": "Mreads/s aligned (100 bp SE, GRCh38+snp144) at 1/2/4/8 MI355X vs CPU ref",
+            "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "%s-scale synthetic (SURVEY 8d config 2): %d bp genome, %d SNPs, k=%d, %d x %d bp SE reads per GPU, "
+                                   "inputs and results resident in HBM" % (args.workload, cfg["genome_len"], cfg["n_snps"], cfg["k"], n_reads, L),
+                       "reads_per_gpu_per_step": n_reads, "read_len": L, "options": "default (-s 50 -m 1000, overlap = k)",
+                       "parallelism": "reads sharded over %d GPU(s), index replicated (one RCCL broadcast)" % world},
+            "kernel_ms": {"k_seed": round(ms_seed / max(n_calls, 1), 3), "k_align": round(ms_align / max(n_calls, 1), 3)},
+        }
+        # ---- CPU baseline + parity check on a bounded sample (oracle = checker, never the product) ----
+        if not args.no_cpu and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py
+            ns = min(args.cpu_sample, n_reads)
+            ora = oracle_py.Oracle(os.path.join(w["dir"], "idx"))
+            oo = ora.opt()
+            cores = min(os.cpu_count() or 1, 64)
+            t1 = time.perf_counter()
+            ores = ora.align(oo, seqs[:ns * L], offs[:ns + 1], n_threads=cores)
+            cpu_dt = time.perf_counter() - t1
+            _, ctr = ora.align(oo, seqs[:20000 * L], offs[:20001], n_threads=1, counters=True)
+            gres = d_res.cpu().numpy().view(salt_amd.RESULT_DTYPE)[:ns]
+            bad = oracle_py.compare(gres, ores)
+            out["cpu_baseline"] = {"value": round(ns / cpu_dt / 1e6, 5), "unit": "Mreads/s", "cores": cores, "kind": "port",
+                                   "sample": "first %d reads of the same batch, oracle/libsalt_oracle.so (bit-exact CPU restatement "
+                                             "of the reference), %d threads, align time only" % (ns, cores),
+                                   "speedup_1gpu": round(value / (ns / cpu_dt / 1e6), 1)}
+            out["parity"] = {"checked_reads": int(ns), "mismatching_reads": int(len(bad))}
+            b_seed, b_align = algorithmic_bytes(ctr, L)
+            k_ms = {"k_seed": ms_seed / max(n_calls, 1), "k_align": ms_align / max(n_calls, 1)}
+            dom = "k_seed" if k_ms["k_seed"] >= k_ms["k_align"] else "k_align"
+            b = b_seed if dom == "k_seed" else b_align
+            ach = b * n_reads / (k_ms[dom] / 1e3) / 1e9
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get(args.workload, {}).get(dom)
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                               "algorithmic_bytes_per_read": {"k_seed": round(b_seed, 1), "k_align": round(b_align, 1)},
+                               "bytes_per_launch": round(b * n_reads, 0), "avg_launch_ms": round(k_ms[dom], 3)}
+            ora.close()
+        print(json.dumps(out), flush=True)
+    aln.close()
+    if idx is not None:
+        idx.destroy()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

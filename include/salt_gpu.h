@@ -111,6 +111,8 @@ void salt_gpu_index_detach(salt_gpu_index_t *ix);
  * driver can broadcast it (RCCL) instead of re-packing on every rank. */
 int  salt_gpu_index_image(const salt_gpu_index_t *ix, void **dev_ptr, uint64_t *bytes);
 int  salt_gpu_index_attach_image(void *dev_ptr, uint64_t bytes, int device, salt_gpu_index_t **out);
+/* device-to-device copy of the image into a caller-owned buffer of >= bytes (e.g. a broadcast buffer) */
+int  salt_gpu_index_image_copy(const salt_gpu_index_t *ix, void *dst_dev_ptr, uint64_t dst_bytes);
 
 /* ---- per-batch work ----------------------------------------------------------------------- */
 int  salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint64_t max_bases, salt_gpu_ws_t **out);
@@ -125,6 +127,13 @@ int  salt_gpu_align_se(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, uint32_t n_
 int  salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, uint32_t n_reads,
                                 uint32_t max_read_len, const void *d_seqs, const void *d_offs,
                                 void *d_results, void *hip_stream);
+
+/* Per-kernel device time.  After salt_gpu_ws_timing(ws, 1) every resident/host align call brackets its
+ * kernels with HIP events on the stream it launches on; salt_gpu_ws_kernel_ms synchronises, adds the
+ * elapsed times of all calls since the last read into ms[0] (k_seed) and ms[1] (k_align), returns the
+ * number of calls in *n_calls and resets.  At most 256 calls are kept between two reads. */
+int  salt_gpu_ws_timing(salt_gpu_ws_t *ws, int enable);
+int  salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[2], uint32_t *n_calls);
 
 /* counters of the last batch(es) since the previous call; resets them */
 int  salt_gpu_ws_counters(salt_gpu_ws_t *ws, uint64_t out[SALT_CTR_N]);

@@ -46,6 +46,13 @@ int salt_sam_header(const salt_index_t *ix, const salt_sam_opt_t *opt, char *buf
 int salt_sam_se(const salt_index_t *ix, const salt_sam_opt_t *opt, const char *name, const uint8_t *seq,
                 int32_t l_seq, const char *qual, const salt_result_t *res, char *buf, size_t cap);
 
+/* Index builder (row N1): writes <prefix>.{R.seedLen,C.pac,C.ann,C.amb,C.lkt,C.bwt,C.sa,lp,
+ * R.backward.bwt,R.backward.occ,R.backward.sa,ref} in salt-idx's formats from a FASTA (plain or .gz)
+ * and salt's 4-column SNP file (chr, 1-based pos, alleles "A/G", ref; no header; grouped by
+ * chromosome in FASTA order).  Mirrors index_main (Index_src/index1.c:46-185).  0 on success. */
+int salt_idx_build(const char *fn_fa, const char *fn_snp, const char *prefix, int l_seed);
+const char *salt_idx_last_error(void);
+
 /* "<len><op>..." text of a binary CIGAR (ops as in salt_result_t); returns bytes written or -1 */
 int salt_cigar_text(const uint16_t *ops, int n_ops, char *buf, size_t cap);
 

@@ -906,10 +906,17 @@ static void align_se1(const so_index_t *ix, const so_opt_t *o, const uint8_t *se
         aux_reserve(aux[i], n_sai > 1 ? n_sai : 1, o->max_locate + 1);
         aux[i]->n_c = aux[i]->n_r = 0; aux[i]->n_loci = 0; aux[i]->n_hits = 0;
     }
-    seed_overlap(ix, o, seq, l_seq, aux[0], ctr);
-    locate_alt(ix, o, (uint32_t)l_seq, aux[0], ctr);
-    seed_overlap(ix, o, rseq, l_seq, aux[1], ctr);
-    locate_alt(ix, o, (uint32_t)l_seq, aux[1], ctr);
+    for (i = 0; i < 2; ++i) {
+        so_counters_t before;
+        if (ctr) before = *ctr;
+        seed_overlap(ix, o, i == 0 ? seq : rseq, l_seq, aux[i], ctr);
+        if (ctr) {
+            ctr->n_occC_seed += ctr->n_occC - before.n_occC;
+            ctr->n_occR_seed += ctr->n_occR - before.n_occR;
+            ctr->n_occR_syms_seed += ctr->n_occR_syms - before.n_occR_syms;
+        }
+        locate_alt(ix, o, (uint32_t)l_seq, aux[i], ctr);
+    }
     max_diff = 3;                                              /* alnse.c:1079 */
     n0 = check_nogap(ix, q, seq, (uint32_t)l_seq, max_diff, 0, aux[0], ctr);
     if (n0 != NO_MATCH && n0 < max_diff) max_diff = n0;
@@ -923,6 +930,7 @@ static void align_se1(const so_index_t *ix, const so_opt_t *o, const uint8_t *se
     }
     set_hits(q, o->max_hits, aux);
     gen_cigar(ix, q, seq, rseq, l_seq);
+    if (ctr) { ctr->n_bases += (uint64_t)l_seq; ctr->n_hits_out += (uint64_t)(q->n_hits[0] + q->n_hits[1]); }
 }
 
 void so_align_se1(const so_index_t *ix, const so_opt_t *o, const uint8_t *seq, int l_seq, so_result_t *res,

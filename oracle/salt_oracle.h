@@ -58,7 +58,9 @@ typedef struct {
 /* per-read logical access counters */
 typedef struct {
     uint64_t n_lkt, n_occC, n_occR, n_occR_syms, n_saC, n_saR, n_bwt2nt, n_verify,
-             n_verify_words, n_lv, n_reads;
+             n_verify_words, n_lv, n_reads,
+             n_occC_seed, n_occR_seed, n_occR_syms_seed,   /* the part of the three Occ counters spent in seeding */
+             n_bases, n_hits_out;
 } so_counters_t;
 
 so_index_t *so_index_load(const char *prefix);      /* NULL on failure (message on stderr) */

@@ -114,6 +114,9 @@ def gpu_lib():
         lib.salt_gpu_align_se_resident.argtypes = [ctypes.c_void_p, ctypes.POINTER(_AlnOpt), ctypes.c_uint32, ctypes.c_uint32,
                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.salt_gpu_ws_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        lib.salt_gpu_index_image_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        lib.salt_gpu_ws_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.salt_gpu_ws_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32)]
         assert lib.salt_gpu_result_size() == RESULT_DTYPE.itemsize
         _gpu = lib
     return _gpu
@@ -222,10 +225,15 @@ class Index:
 class GpuAligner:
     """Device copy of the index + one batch workspace on one GPU."""
 
-    def __init__(self, index, device=0, max_reads=100000, max_bases=None):
+    def __init__(self, index=None, device=0, max_reads=100000, max_bases=None, image=None):
+        """index: a host Index to re-pack and upload, or image=(device_ptr, bytes): an already packed
+        device image (e.g. received by an RCCL broadcast) that stays owned by the caller."""
         lib = gpu_lib()
         self._ix = ctypes.c_void_p()
-        _gpu_check(lib.salt_gpu_index_attach(index.view, device, ctypes.byref(self._ix)))
+        if image is not None:
+            _gpu_check(lib.salt_gpu_index_attach_image(image[0], image[1], device, ctypes.byref(self._ix)))
+        else:
+            _gpu_check(lib.salt_gpu_index_attach(index.view, device, ctypes.byref(self._ix)))
         self._ws = ctypes.c_void_p()
         self.max_reads = max_reads
         self.max_bases = max_bases if max_bases is not None else max_reads * 160
@@ -240,6 +248,19 @@ class GpuAligner:
         p, n = ctypes.c_void_p(), ctypes.c_uint64()
         _gpu_check(gpu_lib().salt_gpu_index_image(self._ix, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
+
+    def image_copy(self, dst_ptr, dst_bytes):
+        _gpu_check(gpu_lib().salt_gpu_index_image_copy(self._ix, dst_ptr, dst_bytes))
+
+    def timing(self, enable=True):
+        _gpu_check(gpu_lib().salt_gpu_ws_timing(self._ws, 1 if enable else 0))
+
+    def kernel_ms(self):
+        """(ms in k_seed, ms in k_align, calls) summed since the last read."""
+        ms = (ctypes.c_double * 2)()
+        n = ctypes.c_uint32()
+        _gpu_check(gpu_lib().salt_gpu_ws_kernel_ms(self._ws, ms, ctypes.byref(n)))
+        return ms[0], ms[1], n.value
 
     def alnse_core1(self, opt, seqs, offs):
         """seqs: uint8 codes 0..4 concatenated; offs: uint32 n+1 offsets.  Returns RESULT_DTYPE[n]."""

@@ -33,7 +33,11 @@ struct salt_gpu_ws {
     uint4 *d_sai_c = nullptr, *d_sai_r = nullptr; uint64_t sai_cap = 0;
     unsigned long long *d_ctr = nullptr;
     hipStream_t stream = nullptr;
+    bool timing = false;
+    std::vector<hipEvent_t> ev;        // 3 per call: before k_seed, between, after k_align
+    uint32_t n_timed = 0;
 };
+static const uint32_t MAX_TIMED = 256;
 
 static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
@@ -213,6 +217,7 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
     hipSetDevice(ws->ix->device);
     hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_ctr);
     if (ws->stream) hipStreamDestroy(ws->stream);
+    for (auto &e : ws->ev) if (e) hipEventDestroy(e);
     delete ws;
 }
 
@@ -252,9 +257,14 @@ extern "C" int salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_
     sp.max_seed = o->max_seed; sp.seed_only_ref = o->seed_only_ref;
     AlignParams ap; ap.n_reads = n_reads; ap.spr = spr; ap.l_seed = o->l_seed; ap.max_locate = o->max_locate; ap.max_hits = o->max_hits;
     unsigned long long *ctr = o->collect_counters ? ws->d_ctr : nullptr;
+    const bool timed = ws->timing && ws->n_timed < MAX_TIMED;
+    hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * 3] : nullptr;
+    if (timed) HIPCHK(hipEventRecord(ev[0], st));
     launch_seed(ws->ix->view, sp, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r, ctr, st);
+    if (timed) HIPCHK(hipEventRecord(ev[1], st));
     launch_align(ws->ix->view, ap, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
                  static_cast<salt_result_t *>(d_results), ctr, st);
+    if (timed) { HIPCHK(hipEventRecord(ev[2], st)); ++ws->n_timed; }
     HIPCHK(hipGetLastError());
     return SALT_OK;
 }
@@ -282,6 +292,43 @@ extern "C" int salt_gpu_align_se(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uin
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(results, ws->d_results, (uint64_t)n_reads * sizeof(salt_result_t), hipMemcpyDeviceToHost, ws->stream));
     HIPCHK(hipStreamSynchronize(ws->stream));
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_index_image_copy(const salt_gpu_index_t *ix, void *dst, uint64_t dst_bytes)
+{
+    if (!ix || !dst || dst_bytes < ix->bytes) return fail(SALT_E_INVAL, "destination too small for the index image");
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipMemcpy(dst, ix->image, ix->bytes, hipMemcpyDeviceToDevice));
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_ws_timing(salt_gpu_ws_t *ws, int enable)
+{
+    if (!ws) return fail(SALT_E_INVAL, "null argument");
+    HIPCHK(hipSetDevice(ws->ix->device));
+    if (enable && ws->ev.empty()) {
+        ws->ev.resize((size_t)MAX_TIMED * 3);
+        for (auto &e : ws->ev) HIPCHK(hipEventCreate(&e));
+    }
+    ws->timing = enable != 0; ws->n_timed = 0;
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[2], uint32_t *n_calls)
+{
+    if (!ws || !ms || !n_calls) return fail(SALT_E_INVAL, "null argument");
+    HIPCHK(hipSetDevice(ws->ix->device));
+    ms[0] = ms[1] = 0; *n_calls = ws->n_timed;
+    for (uint32_t i = 0; i < ws->n_timed; ++i) {
+        hipEvent_t *ev = &ws->ev[(size_t)i * 3];
+        HIPCHK(hipEventSynchronize(ev[2]));
+        float a = 0, b = 0;
+        HIPCHK(hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIPCHK(hipEventElapsedTime(&b, ev[1], ev[2]));
+        ms[0] += a; ms[1] += b;
+    }
+    ws->n_timed = 0;
     return SALT_OK;
 }
 
