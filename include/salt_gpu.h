@@ -130,13 +130,26 @@ int  salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, ui
 
 /* Per-kernel device time.  After salt_gpu_ws_timing(ws, 1) every resident/host align call brackets its
  * kernels with HIP events on the stream it launches on; salt_gpu_ws_kernel_ms synchronises, adds the
- * elapsed times of all calls since the last read into ms[0] (k_seed) and ms[1] (k_align), returns the
- * number of calls in *n_calls and resets.  At most 256 calls are kept between two reads. */
+ * elapsed times of all calls since the last read into ms[0] (k_seed), ms[1] (k_light) and ms[2]
+ * (k_heavy), returns the number of calls in *n_calls and resets.  At most 256 calls are kept. */
 int  salt_gpu_ws_timing(salt_gpu_ws_t *ws, int enable);
-int  salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[2], uint32_t *n_calls);
+int  salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[3], uint32_t *n_calls);
+
+/* The reads of the LAST batch that k_light handed to k_heavy (diagnostics / per-kernel accounting):
+ * *n = how many; ids[0..min(*n,cap)) = their indices in the batch, in queue order. */
+int  salt_gpu_ws_heavy_reads(salt_gpu_ws_t *ws, uint32_t *ids, uint32_t cap, uint32_t *n);
 
 /* counters of the last batch(es) since the previous call; resets them */
 int  salt_gpu_ws_counters(salt_gpu_ws_t *ws, uint64_t out[SALT_CTR_N]);
+
+/* Unit access (tests): for each case c -- a read seqs[offs[c]..offs[c+1]) against the 4-bit mixRef
+ * `ref_words` at pos[c] -- out4[4c+0] = masked Hamming distance capped at 3 (255 = more; -2 = window
+ * past the end), out4[4c+1] = LV distance with bound kdiff[c] from the diagonal-per-lane kernel, out4[4c+2]
+ * = the same from the candidate-per-lane kernel (-2 when kdiff/L are outside its range), out4[4c+3] =
+ * number of CIGAR ops written to cigars[64c..] (-2 when there is no alignment).  Mirrors ed_mismatch,
+ * ed_diff, ed_diff_withcigar (editdistance.c:88,174,234). */
+int  salt_gpu_diag_lv(const uint32_t *ref_words, uint32_t ref_len, uint32_t n_cases, const uint32_t *pos,
+                      const uint32_t *kdiff, const uint8_t *seqs, const uint32_t *offs, int32_t *out4, uint16_t *cigars);
 
 const char *salt_gpu_last_error(void);
 uint32_t    salt_gpu_result_size(void);         /* sizeof(salt_result_t), for bindings */

@@ -116,6 +116,7 @@ def gpu_lib():
         lib.salt_gpu_ws_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
         lib.salt_gpu_index_image_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
         lib.salt_gpu_ws_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.salt_gpu_ws_heavy_reads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
         lib.salt_gpu_ws_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32)]
         assert lib.salt_gpu_result_size() == RESULT_DTYPE.itemsize
         _gpu = lib
@@ -256,11 +257,18 @@ class GpuAligner:
         _gpu_check(gpu_lib().salt_gpu_ws_timing(self._ws, 1 if enable else 0))
 
     def kernel_ms(self):
-        """(ms in k_seed, ms in k_align, calls) summed since the last read."""
-        ms = (ctypes.c_double * 2)()
+        """({kernel: ms summed since the last read}, calls)."""
+        ms = (ctypes.c_double * 3)()
         n = ctypes.c_uint32()
         _gpu_check(gpu_lib().salt_gpu_ws_kernel_ms(self._ws, ms, ctypes.byref(n)))
-        return ms[0], ms[1], n.value
+        return {"k_seed": ms[0], "k_light": ms[1], "k_heavy": ms[2]}, n.value
+
+    def heavy_reads(self):
+        """Indices (in the last batch) of the reads k_light queued for k_heavy."""
+        n = ctypes.c_uint32()
+        ids = np.zeros(self.max_reads, dtype=np.uint32)
+        _gpu_check(gpu_lib().salt_gpu_ws_heavy_reads(self._ws, ids.ctypes.data, len(ids), ctypes.byref(n)))
+        return ids[:n.value]
 
     def alnse_core1(self, opt, seqs, offs):
         """seqs: uint8 codes 0..4 concatenated; offs: uint32 n+1 offsets.  Returns RESULT_DTYPE[n]."""

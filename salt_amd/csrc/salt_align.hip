@@ -129,10 +129,16 @@ k_seed(IndexView ix, SeedParams sp, const uint8_t *__restrict__ seqs, const uint
 // ---------------------------------------------------------------------------------------------
 struct SaiLists { uint32_t sp[2][SLOTS], ep[2][SLOTS], off[2][SLOTS]; };     // [0]=C, [1]=R
 struct LvTables { short L[LVK][64]; char A[LVK][64]; };
+// lane-parallel LV (one candidate per lane): nibble-packed text window per lane + two DP rows per lane
+static constexpr int LLV_K = 12;                 // handles k <= 12 (reads up to 129 bp at k = L/10)
+static constexpr int LLV_TW = 18;                // words per lane: up to 133 text nibbles (+1 pad word)
+static constexpr int LLV_W = 2 * LLV_K + 3;      // diagonals -k-1 .. k+1
+struct LaneLv { uint32_t T[64 * LLV_TW]; uint8_t rows[2][LLV_W][64]; };
 struct WaveLds {
     uint8_t  seq[2][MAXL];
     uint32_t pm[2][MAXL / 8];
-    union { SaiLists sai; LvTables lv; } u;
+    union { SaiLists sai; LvTables lv; LaneLv llv; } u;
+    uint8_t  cand_e[MAXLOC];
     uint32_t loci[MAXLOC];
     uint8_t  lvT[MAXL + 4 + 64];
     uint8_t  lvP[MAXL + 64];
@@ -169,7 +175,7 @@ __device__ void sai_combsort(SaiLists &s, int w, int base, int n)
     if (gap != 1) sai_insertsort(s, w, base, base + n);
 }
 
-__device__ void sai_introsort(SaiLists &s, int w, int n)
+__device__ __attribute__((noinline)) void sai_introsort(SaiLists &s, int w, int n)
 {
     if (n < 1) return;
     if (n == 2) { if (sai_lt(s, w, 1, 0)) sai_swap(s, w, 0, 1); return; }
@@ -230,7 +236,7 @@ __device__ void sort_loci(uint32_t *a, uint32_t n)
 // ---- candidates of one strand: gather seeds, order them, locate, sort, dedup ----------------------
 // Leaves the candidate positions in w.loci[0..return).  gap_mode selects the range filter of
 // alnse_check_withgap (alnse.c:894) instead of alnse_check_nogap's (alnse.c:762).
-__device__ uint32_t build_candidates(const IndexView &ix, const AlignParams &ap, WaveLds &w, uint32_t r, int strand,
+__device__ __attribute__((noinline)) uint32_t build_candidates(const IndexView &ix, const AlignParams &ap, WaveLds &w, uint32_t r, int strand,
                                      uint32_t L, const uint4 *sai_c, const uint4 *sai_r, bool gap_mode,
                                      uint32_t &n_sa_c, uint32_t &n_sa_r, uint32_t &n_loci_out)
 {
@@ -349,7 +355,7 @@ __device__ __forceinline__ uint32_t mismatch_capped(const IndexView &ix, const u
 // Returns e (<= k), or -1.  When tab != nullptr also fills the L / action tables and returns the
 // finishing diagonal in d_fin (order 0,-1,1,... LandauVishkin.c:248); otherwise the order is
 // irrelevant for the distance (LandauVishkin.c:67).
-__device__ int lv_wave(const uint8_t *T, int tlen, const uint8_t *P, int plen, int k, LvTables *tab, int &d_fin)
+__device__ __attribute__((noinline)) int lv_wave(const uint8_t *T, int tlen, const uint8_t *P, int plen, int k, LvTables *tab, int &d_fin)
 {
     const int lane = (int)lane_id();
     const int d = lane - 31;
@@ -396,6 +402,50 @@ __device__ int lv_wave(const uint8_t *T, int tlen, const uint8_t *P, int plen, i
     return -1;
 }
 
+// ---- Landau-Vishkin distance, one candidate per lane (computeEditDistance, LandauVishkin.c:19-122) ----
+// Text: the lane's (L+4)-base window of the mixRef, nibble-packed in LDS (zero beyond tlen, like the
+// reference's zero-padded byte buffer); pattern: the read's one-hot nibbles (N = 15), shared.
+// Returns e in 0..k, or 255 for "more than k" / inactive lanes.  The distance does not depend on the
+// diagonal order, so all lanes walk the (e, d) cells in the same order.
+__device__ __attribute__((noinline)) uint32_t lv_lanes(LaneLv &s, const uint32_t *pm, int plen, int tlen, int k, bool active)
+{
+    const int lane = (int)lane_id();
+    const uint32_t *T = s.T + lane * LLV_TW;
+    auto nT = [&](int i) -> uint32_t { return (i >= 0 && i < tlen) ? (T[i >> 3] >> (4 * (i & 7))) & 15u : 0u; };
+    auto nP = [&](int i) -> uint32_t { return i < plen ? (pm[i >> 3] >> (4 * (i & 7))) & 15u : 0u; };
+    auto RD = [&](int row, int d) -> int { return (int)s.rows[row][d + LLV_K + 1][lane] - 2; };
+    auto WR = [&](int row, int d, int v) { s.rows[row][d + LLV_K + 1][lane] = (uint8_t)(v + 2); };
+    for (int row = 0; row < 2; ++row) for (int d = 0; d < LLV_W; ++d) s.rows[row][d][lane] = 0;      // -2 everywhere
+    const int end0 = plen < tlen ? plen : tlen;
+    uint32_t result = 255;
+    bool done = !active;
+    if (active) {
+        int i = 0;
+        while (i < end0 && (nP(i) & nT(i)) != 0) ++i;
+        WR(0, 0, i);
+        if (i == end0) { result = (uint32_t)(plen > end0 ? plen - end0 : 0); done = true; }
+    }
+    for (int e = 1; e <= k; ++e) {
+        if (__ballot(!done) == 0) break;
+        const int cur = e & 1, prev = cur ^ 1;
+        for (int d = -e; d <= e; ++d) {
+            if (done) continue;
+            int best = RD(prev, d) + 1;
+            const int left = RD(prev, d - 1), right = RD(prev, d + 1) + 1;
+            if (left > best) best = left;
+            if (right > best) best = right;
+            if (nP(best) == nT(d + best)) {                               // equality gate (LandauVishkin.c:79)
+                const int end = plen < tlen - d ? plen : tlen - d;
+                if (best >= end) best = end;
+                else { int i = best; while (i < end && (nP(i) & nT(d + i)) != 0) ++i; best = i; }
+            }
+            if (best == plen) { result = (uint32_t)e; done = true; }
+            else WR(cur, d, best);
+        }
+    }
+    return result;
+}
+
 // unpack text masks / one-hot pattern for LV (editdistance.c:183-227)
 __device__ void lv_unpack(const IndexView &ix, WaveLds &w, int strand, uint32_t L, uint32_t pos)
 {
@@ -412,7 +462,7 @@ __device__ void lv_unpack(const IndexView &ix, WaveLds &w, int strand, uint32_t 
 }
 
 // CIGAR of a gapped hit into w.cig / w.n_cig (computeEditDistanceWithCigar, useM=1) ------------------
-__device__ void lv_cigar(const IndexView &ix, WaveLds &w, int strand, uint32_t L, uint32_t pos, int k)
+__device__ __attribute__((noinline)) void lv_cigar(const IndexView &ix, WaveLds &w, int strand, uint32_t L, uint32_t pos, int k)
 {
     lv_unpack(ix, w, strand, L, pos);
     int d_fin = 0;
@@ -458,15 +508,13 @@ __device__ void lv_cigar(const IndexView &ix, WaveLds &w, int strand, uint32_t L
 // ---------------------------------------------------------------------------------------------
 // k_align
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-k_align(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
-        const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
-        unsigned long long *__restrict__ ctr)
+__device__ void align_general(const IndexView &ix, const AlignParams &ap, WaveLds &w, const uint32_t r,
+                              const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+                              const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r,
+                              salt_result_t *__restrict__ results, unsigned long long *__restrict__ ctr)
 {
-    __shared__ WaveLds w;
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull;
-    const uint32_t r = blockIdx.x;
     const uint32_t off = offs[r], L = offs[r + 1] - off;
     salt_result_t *out = results + r;
     uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_lv = 0, c_loci = 0;
@@ -557,10 +605,44 @@ k_align(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
         for (int strand = 0; strand < 2; ++strand) {
             uint32_t n_cand = build_candidates(ix, ap, w, r, strand, L, sai_c, sai_r, true, c_sa_c, c_sa_r, c_loci);
             bool any = false;
+            // all candidates' distances at the call's initial bound, 64 at a time (one per lane); the
+            // sequential rule below then only compares numbers
+            const bool lanes_ok = (int)(L / 10) <= LLV_K && L + 4 <= 8u * (LLV_TW - 1);
+            if (lanes_ok) {
+                const int k0 = (int)(L / 10);
+                for (uint32_t b = 0; b < n_cand; b += 64) {
+                    WSYNC();
+                    const uint32_t i = b + lane;
+                    bool act = false;
+                    if (i < n_cand) {
+                        const uint32_t pos = w.loci[i];
+                        act = !(pos > ix.ref_len || pos + L + 4 > ix.ref_len);           // ed_diff guard (editdistance.c:178)
+                        if (act) {
+                            const uint32_t tl = L + 4, w0 = pos >> 3, sh = (pos & 7u) * 4u, nwt = (tl + 7) >> 3;
+                            uint32_t lo = ix.ref[w0];
+                            for (uint32_t j = 0; j < LLV_TW; ++j) {
+                                uint32_t word = 0;
+                                if (j < nwt) {
+                                    const uint32_t hi = ix.ref[w0 + j + 1];
+                                    word = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+                                    const uint32_t rem = tl - j * 8;
+                                    if (rem < 8) word &= (1u << (4 * rem)) - 1u;
+                                    lo = hi;
+                                }
+                                w.u.llv.T[lane * LLV_TW + j] = word;
+                            }
+                        }
+                    }
+                    const uint32_t e = lv_lanes(w.u.llv, w.pm[strand], (int)L, (int)L + 4, k0, act);
+                    if (i < n_cand) w.cand_e[i] = (uint8_t)e;
+                }
+                WSYNC();
+            }
             for (uint32_t i = 0; i < n_cand; ++i) {
                 uint32_t pos = w.loci[i];
                 int e = -1;
-                if (!(pos > ix.ref_len || pos + L + 4 > ix.ref_len)) {        // ed_diff guard (editdistance.c:178)
+                if (lanes_ok) { const uint32_t ev = w.cand_e[i]; e = (ev != 255 && (int)ev <= maxd) ? (int)ev : -1; }
+                else if (!(pos > ix.ref_len || pos + L + 4 > ix.ref_len)) {   // ed_diff guard (editdistance.c:178)
                     lv_unpack(ix, w, strand, L, pos);
                     int dd;
                     e = lv_wave(w.lvT, (int)L + 4, w.lvP, (int)L, maxd, nullptr, dd);
@@ -650,6 +732,280 @@ k_align(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_heavy: persistent waves pull the reads k_light could not finish from a queue
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_heavy(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+        const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
+        const uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl, unsigned long long *__restrict__ ctr)
+{
+    __shared__ WaveLds w;
+    __shared__ uint32_t s_item;
+    const uint32_t n_items = ap.all_heavy ? ap.n_reads : qctl[0];       // qctl[0]: reads queued by k_light
+    for (;;) {                                                           // every wave leaves once the head passes n_items
+        if (threadIdx.x == 0) s_item = atomicAdd(&qctl[1], 1u);
+        WSYNC();
+        const uint32_t it = s_item;
+        WSYNC();
+        if (it >= n_items) break;
+        align_general(ix, ap, w, ap.all_heavy ? it : queue[it], seqs, offs, sai_c, sai_r, results, ctr);
+        WSYNC();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_light: one wave per read, the common case in three memory round trips.
+//
+// A read stays here when (a) it is short enough for the small LDS image (L <= 160, <= 16 seed slots),
+// (b) each of its four seed lists (C/R x strand) enumerates at most 64 suffix-array rows, so that the
+// max_locate cap (>= 128) can never bite and locate order is irrelevant once the loci are sorted, and
+// (c) a gap-free hit exists.  Everything else is queued for k_heavy, which replays the reference's
+// general control flow.  Same results either way; the split only changes who computes them.
+// ---------------------------------------------------------------------------------------------
+static constexpr int LT_SLOTS = 16;      // seed slots per list handled here
+static constexpr int LT_LOCI = 128;      // loci per strand handled here
+static constexpr int LT_MAXL = 160;
+
+struct LightLds {
+    uint32_t pm[2][LT_MAXL / 8];
+    uint32_t sp[4][LT_SLOTS], ep[4][LT_SLOTS], off[4][LT_SLOTS];
+    uint32_t pre[4][LT_SLOTS + 1];       // rows enumerated before interval i of list l
+    uint32_t n_list[4];
+    uint32_t loci[2][LT_LOCI];
+    uint32_t tmp[2][LT_LOCI];
+    uint32_t hit_pos[2][NHIT];
+    uint8_t  hit_nd[2][NHIT];
+};
+
+// insertion/introsort replica on one small list (same comparisons and swaps as sai_introsort above)
+__device__ void light_sort(LightLds &w, int l, int n)
+{
+    auto key = [&](int i) { return w.ep[l][i] - w.sp[l][i]; };
+    auto swp = [&](int i, int j) {
+        uint32_t a = w.sp[l][i], b = w.ep[l][i], c = w.off[l][i];
+        w.sp[l][i] = w.sp[l][j]; w.ep[l][i] = w.ep[l][j]; w.off[l][i] = w.off[l][j];
+        w.sp[l][j] = a; w.ep[l][j] = b; w.off[l][j] = c;
+    };
+    if (n < 2) return;
+    if (n == 2) { if (key(1) < key(0)) swp(0, 1); return; }
+    // n <= 16: ks_introsort makes exactly one partition pass over [0, n-1] (both halves are <= 16 long,
+    // so nothing is pushed and the loop ends), then insertion sort finishes (ksort.h:176-228)
+    {
+        int i = 0, j = n - 1, k = ((j - i) >> 1) + 1;
+        if (key(k) < key(i)) { if (key(k) < key(j)) k = j; }
+        else k = key(j) < key(i) ? i : j;
+        uint32_t rp = key(k);
+        if (k != n - 1) swp(k, n - 1);
+        for (;;) {
+            do ++i; while (key(i) < rp);
+            do --j; while (i <= j && rp < key(j));
+            if (j <= i) break;
+            swp(i, j);
+        }
+        swp(i, n - 1);
+    }
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && key(j) < key(j - 1); --j) swp(j, j - 1);
+}
+
+__global__ void __launch_bounds__(64)
+k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+        const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
+        uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl, unsigned long long *__restrict__ ctr)
+{
+    __shared__ LightLds w;
+    const uint32_t lane = lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t r = blockIdx.x;
+    const uint32_t off = offs[r], L = offs[r + 1] - off;
+    bool heavy = L > LT_MAXL || L < (uint32_t)ap.l_seed || ap.spr > LT_SLOTS || ap.max_locate < 2 * 64;
+    uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_loci = 0;
+
+    if (!heavy) {
+        // ---- round trip 1: the read (as one-hot nibble words, both strands) and its seeds ----
+        const uint32_t nw = (L + 7) >> 3;
+        if (lane < 2 * nw) {
+            const uint32_t s = lane >= nw, j = s ? lane - nw : lane;
+            uint32_t word = 0;
+            for (uint32_t q = 0; q < 8; ++q) {
+                uint32_t i = j * 8 + q, msk = 0;
+                if (i < L) {
+                    uint32_t c = s ? seqs[off + (L - 1 - i)] : seqs[off + i];
+                    if (s && c < 4) c = 3 - c;
+                    msk = c < 4 ? (1u << c) : 15u;                         // nt2bit (editdistance.c:40)
+                }
+                word |= msk << (4 * q);
+            }
+            w.pm[s][j] = word;
+        }
+        {
+            const uint32_t l = lane >> 4, slot = lane & 15u;               // l: 0 C/fwd 1 R/fwd 2 C/rev 3 R/rev
+            uint4 v = make_uint4(1, 0, 0, 0);
+            if (slot < ap.spr) v = ((l & 1) ? sai_r : sai_c)[((uint64_t)r * 2u + (l >> 1)) * ap.spr + slot];
+            const uint64_t m = __ballot(v.w != 0);
+            const uint64_t grp = 0xFFFFull << (l * 16);
+            if (v.w) { uint32_t at = (uint32_t)__popcll(m & grp & lt); w.sp[l][at] = v.x; w.ep[l][at] = v.y; w.off[l][at] = v.z; }
+            if (slot == 0) w.n_list[l] = (uint32_t)__popcll(m & grp);
+        }
+        WSYNC();
+        if (lane < 4) {                                                     // alnse.c:307-308 + row prefix sums
+            const int n = (int)w.n_list[lane];
+            light_sort(w, (int)lane, n);
+            uint32_t acc = 0;
+            for (int i = 0; i < n; ++i) { w.pre[lane][i] = acc; uint32_t sz = w.ep[lane][i] - w.sp[lane][i] + 1; acc = sz > 64 || acc + sz > 64 ? 65u : acc + sz; }
+            w.pre[lane][n] = acc;
+        }
+        WSYNC();
+        uint32_t tot[4];
+        for (int l = 0; l < 4; ++l) { tot[l] = w.pre[l][w.n_list[l]]; heavy |= tot[l] > 64; }
+        if (!heavy) {
+            // ---- round trip 2: every suffix-array row of the four lists at once ----
+            uint32_t pos4[4]; bool keep4[4];
+            for (int l = 0; l < 4; ++l) {
+                keep4[l] = false; pos4[l] = 0;
+                if (lane < tot[l]) {
+                    uint32_t i = 0;
+                    while (w.pre[l][i + 1] <= lane) ++i;
+                    const uint32_t j = w.sp[l][i] + (lane - w.pre[l][i]);
+                    const uint32_t p = ((l & 1) ? ix.r_pos[j] : ix.c_sa[j]) - w.off[l][i];
+                    pos4[l] = p;
+                    keep4[l] = (l & 1) ? !(p > ix.ref_len || p + L > ix.ref_len) : !(p + L > ix.ref_len);   // alnse.c:672-673,715-717
+                }
+            }
+            uint32_t n_s[2];
+            for (int s = 0; s < 2; ++s) {
+                const uint64_t mc = __ballot(keep4[2 * s]), mr = __ballot(keep4[2 * s + 1]);
+                const uint32_t nc = (uint32_t)__popcll(mc);
+                if (keep4[2 * s]) w.tmp[s][(uint32_t)__popcll(mc & lt)] = pos4[2 * s];
+                if (keep4[2 * s + 1]) w.tmp[s][nc + (uint32_t)__popcll(mr & lt)] = pos4[2 * s + 1];
+                n_s[s] = nc + (uint32_t)__popcll(mr);
+                c_sa_c += tot[2 * s]; c_sa_r += tot[2 * s + 1]; c_loci += n_s[s];
+            }
+            WSYNC();
+            // ---- sort (rank sort), dedup, range filter (alnse.c:726-729, 758-762) ----
+            uint32_t n_c[2];
+            for (int s = 0; s < 2; ++s) {
+                const uint32_t n = n_s[s];
+                uint32_t x0 = 0, x1 = 0, r0 = 0, r1 = 0;
+                const uint32_t i0 = lane, i1 = lane + 64;
+                if (i0 < n) x0 = w.tmp[s][i0];
+                if (i1 < n) x1 = w.tmp[s][i1];
+                for (uint32_t j = 0; j < n; ++j) {
+                    const uint32_t y = w.tmp[s][j];
+                    r0 += (y < x0) || (y == x0 && j < i0);
+                    r1 += (y < x1) || (y == x1 && j < i1);
+                }
+                if (i0 < n) w.loci[s][r0] = x0;
+                if (i1 < n) w.loci[s][r1] = x1;
+                WSYNC();
+                bool k0 = false, k1 = false;
+                if (i0 < n) k0 = !(i0 > 0 && w.loci[s][i0 - 1] == w.loci[s][i0]) && w.loci[s][i0] < ix.ref_len;
+                if (i1 < n) k1 = !(w.loci[s][i1 - 1] == w.loci[s][i1]) && w.loci[s][i1] < ix.ref_len;
+                const uint32_t v0 = i0 < n ? w.loci[s][i0] : 0, v1 = i1 < n ? w.loci[s][i1] : 0;
+                const uint64_t m0 = __ballot(k0), m1 = __ballot(k1);
+                WSYNC();
+                const uint32_t c0 = (uint32_t)__popcll(m0);
+                if (k0) w.loci[s][(uint32_t)__popcll(m0 & lt)] = v0;
+                if (k1) w.loci[s][c0 + (uint32_t)__popcll(m1 & lt)] = v1;
+                n_c[s] = c0 + (uint32_t)__popcll(m1);
+            }
+            WSYNC();
+            // ---- round trip 3: masked Hamming distance of every candidate of both strands ----
+            uint32_t v[2][2], p[2][2];
+            for (int s = 0; s < 2; ++s)
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t i = lane + 64 * h;
+                    v[s][h] = INF; p[s][h] = 0;
+                    if (i < n_c[s]) { p[s][h] = w.loci[s][i]; v[s][h] = mismatch_capped(ix, w.pm[s], L, p[s][h]); c_vwords += ((p[s][h] & 7u) + L + 7) >> 3; }
+                }
+            c_verify += n_c[0] + n_c[1];
+            // ---- the sequential best/first-hit rule, replayed by ballots (alnse.c:348-369, 1079-1083) ----
+            uint32_t bound = 3, q_pos = 0xFFFFFFFFu, q_strand = 3, q_ndiff = 255;
+            uint32_t n_hits_s[2] = { 0, 0 }, a0[2] = { 0, 0 };
+            bool found[2] = { false, false };
+            for (int s = 0; s < 2; ++s) {
+                uint32_t call_best_n = INF, call_best_pos = 0;
+                for (int h = 0; h < 2; ++h) {
+                    if (64u * h >= n_c[s]) break;
+                    const uint32_t vv = v[s][h], pp = p[s][h];
+                    const uint64_t m0 = __ballot(vv <= 0), m1 = __ballot(vv <= 1), m2 = __ballot(vv <= 2);
+                    const uint64_t smaller = vv == 0 ? 0ull : (vv == 1 ? m0 : (vv == 2 ? m1 : m2));
+                    const bool pass = vv <= bound && (smaller & lt) == 0;
+                    const uint64_t pm = __ballot(pass);
+                    if (!pm) continue;
+                    const uint32_t vmin = m0 & pm ? 0u : (m1 & pm ? 1u : (m2 & pm ? 2u : 3u));
+                    const uint32_t rank = n_hits_s[s] + (uint32_t)__popcll(pm & lt);
+                    if (pass && rank < NHIT) { w.hit_pos[s][rank] = pp; w.hit_nd[s][rank] = (uint8_t)vv; }
+                    if (n_hits_s[s] == 0) a0[s] = (uint32_t)__shfl((int)vv, __ffsll((long long)pm) - 1);
+                    const uint32_t add = (uint32_t)__popcll(pm);
+                    n_hits_s[s] = n_hits_s[s] + add > NHIT ? NHIT : n_hits_s[s] + add;
+                    if (vmin < call_best_n) {
+                        const uint64_t at = __ballot(pass && vv == vmin);
+                        call_best_n = vmin;
+                        call_best_pos = (uint32_t)__shfl((int)pp, __ffsll((long long)at) - 1);
+                    }
+                    found[s] = true;
+                    bound = vmin < bound ? vmin : bound;
+                }
+                if (found[s]) { q_pos = call_best_pos; q_ndiff = call_best_n; q_strand = (uint32_t)s; }
+            }
+            if (!found[0] && !found[1]) heavy = true;                       // needs the gapped pass
+            else {
+                WSYNC();
+                // ---- query_set_hits / gen_mapq (query.c:270-333) ----
+                int b0 = (int)q_ndiff, b1 = 100000, tot_h = 0;
+                uint32_t nh[2] = { 0, 0 };
+                uint32_t sel_idx[2][SALT_MAX_HITS];
+                for (int s = 0; s < 2 && tot_h < ap.max_hits; ++s)
+                    for (uint32_t j = 0; j < n_hits_s[s]; ++j) {
+                        const uint32_t hp = w.hit_pos[s][j];
+                        if (hp == 0xFFFFFFFFu || hp == q_pos) continue;
+                        if (a0[s] <= q_ndiff) {
+                            if ((int)a0[s] <= b1) b1 = (int)a0[s];
+                            if (nh[s] < SALT_MAX_HITS) sel_idx[s][nh[s]] = j;
+                            ++nh[s]; ++tot_h;
+                        }
+                        if (tot_h == ap.max_hits) break;
+                    }
+                uint32_t mapq = 0;
+                if (b0 != 0) {
+                    const uint32_t x = (uint32_t)(b0 > b1 ? b0 - b1 : b1 - b0);
+                    const uint64_t q = (uint64_t)255 * x / (uint32_t)b0;
+                    mapq = q < 254 ? (uint32_t)q : 254u;
+                }
+                if (lane == 0) {
+                    salt_result_t *out = results + r;
+                    out->pos = q_pos; out->strand = (uint8_t)q_strand; out->n_diff = (uint8_t)q_ndiff; out->is_gap = 0;
+                    out->mapq = (uint8_t)mapq; out->b0 = b0; out->b1 = b1; out->seq_start = 0; out->seq_end = (uint16_t)(L - 1);
+                    out->n_hits[0] = (uint8_t)nh[0]; out->n_hits[1] = (uint8_t)nh[1]; out->skipped = 0;
+                    out->cigar[0] = (uint16_t)((L << 4) | 0u); out->n_cigar = 1;
+                    uint32_t hidx = 0;
+                    for (int s = 0; s < 2; ++s)
+                        for (uint32_t j = 0; j < nh[s]; ++j, ++hidx) {
+                            const uint32_t h = sel_idx[s][j];
+                            out->hits[s][j].pos = w.hit_pos[s][h]; out->hits[s][j].n_diff = w.hit_nd[s][h];
+                            out->hits[s][j].is_gap = 0; out->hits[s][j].strand = (uint16_t)s;
+                            out->hit_n_cigar[hidx] = 0;
+                        }
+                }
+            }
+        }
+    }
+    if (heavy) {
+        if (lane == 0) queue[atomicAdd(&qctl[0], 1u)] = r;
+        return;                                                             // k_heavy does (and counts) all of it
+    }
+    if (ctr) {
+        for (int o = 32; o > 0; o >>= 1) c_vwords += __shfl_down(c_vwords, o);
+        if (lane == 0) {
+            atomicAdd(ctr + SALT_CTR_SA_C, c_sa_c); atomicAdd(ctr + SALT_CTR_SA_R, c_sa_r);
+            atomicAdd(ctr + SALT_CTR_VERIFY, c_verify); atomicAdd(ctr + SALT_CTR_VERIFY_WORDS, c_vwords);
+            atomicAdd(ctr + SALT_CTR_READS, 1ull); atomicAdd(ctr + SALT_CTR_BASES, L); atomicAdd(ctr + SALT_CTR_LOCI, c_loci);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launch wrappers (called from salt_gpu.hip)
 // ---------------------------------------------------------------------------------------------
 void launch_seed(const IndexView &ix, const SeedParams &sp, const uint8_t *seqs, const uint32_t *offs, uint4 *sai_c,
@@ -661,11 +1017,97 @@ void launch_seed(const IndexView &ix, const SeedParams &sp, const uint8_t *seqs,
     hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(256), 0, st, ix, sp, seqs, offs, sai_c, sai_r, ctr);
 }
 
-void launch_align(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
-                  const uint4 *sai_r, salt_result_t *results, unsigned long long *ctr, hipStream_t st)
+void launch_light(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
+                  const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, unsigned long long *ctr, hipStream_t st)
 {
     if (!ap.n_reads) return;
-    hipLaunchKernelGGL(k_align, dim3(ap.n_reads), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, ctr);
+    hipLaunchKernelGGL(k_light, dim3(ap.n_reads), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_diag_lv: unit access to the verify / LV device functions for the golden vectors (tests only)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_diag_lv(IndexView ix, uint32_t n_cases, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ kdiff,
+          const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs, int32_t *__restrict__ out /* [n][4] */,
+          uint16_t *__restrict__ cig_out /* [n][64] */)
+{
+    __shared__ WaveLds w;
+    const uint32_t c = blockIdx.x, lane = lane_id();
+    if (c >= n_cases) return;
+    const uint32_t off = offs[c], L = offs[c + 1] - off, p = pos[c];
+    for (uint32_t i = lane; i < L; i += 64) w.seq[0][i] = seqs[off + i];
+    WSYNC();
+    const uint32_t nw = (L + 7) >> 3;
+    for (uint32_t j = lane; j < nw; j += 64) {
+        uint32_t word = 0;
+        for (uint32_t q = 0; q < 8; ++q) {
+            uint32_t i = j * 8 + q, cc = i < L ? w.seq[0][i] : 5u;
+            word |= (cc < 4 ? (1u << cc) : (cc == 4 ? 15u : 0u)) << (4 * q);
+        }
+        w.pm[0][j] = word;
+    }
+    WSYNC();
+    int32_t v = -2, e_wave = -2, e_lane = -2, n_cig = -2;
+    if (p + L <= ix.ref_len) v = (int32_t)mismatch_capped(ix, w.pm[0], L, p);
+    const bool in_range = !(p > ix.ref_len || p + L + 4 > ix.ref_len);
+    const int k = (int)kdiff[c];
+    if (in_range) {
+        lv_unpack(ix, w, 0, L, p);
+        int dd;
+        e_wave = lv_wave(w.lvT, (int)L + 4, w.lvP, (int)L, k, nullptr, dd);
+        WSYNC();
+        if (k <= LLV_K && L + 4 <= 8u * (LLV_TW - 1)) {
+            const uint32_t tl = L + 4, w0 = p >> 3, sh = (p & 7u) * 4u, nwt = (tl + 7) >> 3;
+            uint32_t lo = ix.ref[w0];
+            for (uint32_t j = 0; j < LLV_TW; ++j) {                    // every lane stages the same window
+                uint32_t word = 0;
+                if (j < nwt) {
+                    const uint32_t hi = ix.ref[w0 + j + 1];
+                    word = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+                    const uint32_t rem = tl - j * 8;
+                    if (rem < 8) word &= (1u << (4 * rem)) - 1u;
+                    lo = hi;
+                }
+                w.u.llv.T[lane * LLV_TW + j] = word;
+            }
+            uint32_t el = lv_lanes(w.u.llv, w.pm[0], (int)L, (int)L + 4, k, true);
+            e_lane = el == 255 ? -1 : (int32_t)el;
+            WSYNC();
+        }
+        if (e_wave >= 0 && e_wave < LVK) {
+            lv_cigar(ix, w, 0, L, p, e_wave);
+            n_cig = w.n_cig;
+            if (lane < (uint32_t)w.n_cig) cig_out[(size_t)c * SALT_MAX_CIGAR_OPS + lane] = w.cig[lane];
+        }
+    } else { e_wave = -1; e_lane = -1; }
+    if (lane == 0) { out[c * 4 + 0] = v; out[c * 4 + 1] = e_wave; out[c * 4 + 2] = e_lane; out[c * 4 + 3] = n_cig; }
+}
+
+void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const uint32_t *kdiff, const uint8_t *seqs,
+                    const uint32_t *offs, int32_t *out, uint16_t *cig, hipStream_t st)
+{
+    if (n) hipLaunchKernelGGL(k_diag_lv, dim3(n), dim3(64), 0, st, ix, n, pos, kdiff, seqs, offs, out, cig);
+}
+
+uint32_t heavy_blocks_per_cu()
+{
+    static int cached = 0;
+    if (!cached) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_heavy, 64, 0) != hipSuccess || n < 1) n = 8;
+        cached = n;
+    }
+    return (uint32_t)cached;
+}
+
+void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
+                  const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, uint32_t *qctl, unsigned long long *ctr,
+                  uint32_t n_blocks, hipStream_t st)
+{
+    if (!ap.n_reads) return;
+    uint32_t blocks = n_blocks < ap.n_reads ? n_blocks : ap.n_reads;
+    hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr);
 }
 
 } // namespace salt

@@ -32,9 +32,12 @@ struct salt_gpu_ws {
     uint8_t *d_seqs = nullptr; uint32_t *d_offs = nullptr; salt_result_t *d_results = nullptr;
     uint4 *d_sai_c = nullptr, *d_sai_r = nullptr; uint64_t sai_cap = 0;
     unsigned long long *d_ctr = nullptr;
+    uint32_t *d_queue = nullptr, *d_qctl = nullptr;   // reads k_light hands to k_heavy; {count, head}
+    uint32_t heavy_blocks = 2048;
+    int all_heavy = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
-    std::vector<hipEvent_t> ev;        // 3 per call: before k_seed, between, after k_align
+    std::vector<hipEvent_t> ev;        // 4 per call: before k_seed, before k_light, before k_heavy, after
     uint32_t n_timed = 0;
 };
 static const uint32_t MAX_TIMED = 256;
@@ -203,6 +206,15 @@ extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint
     CHKW(hipMalloc((void **)&ws->d_offs, ((uint64_t)max_reads + 1) * 4));
     CHKW(hipMalloc((void **)&ws->d_results, (uint64_t)max_reads * sizeof(salt_result_t)));
     CHKW(hipMemset(ws->d_results, 0, (uint64_t)max_reads * sizeof(salt_result_t)));
+    CHKW(hipMalloc((void **)&ws->d_queue, (uint64_t)max_reads * 4));
+    CHKW(hipMalloc((void **)&ws->d_qctl, 2 * 4));
+    {
+        hipDeviceProp_t prop;
+        CHKW(hipGetDeviceProperties(&prop, ix->device));
+        ws->heavy_blocks = (uint32_t)prop.multiProcessorCount * heavy_blocks_per_cu();   // persistent waves (LDS-bound)
+        const char *e = getenv("SALT_GPU_ALL_HEAVY");
+        ws->all_heavy = e && atoi(e) != 0;
+    }
     CHKW(hipMalloc((void **)&ws->d_ctr, SALT_CTR_N * sizeof(unsigned long long)));
     CHKW(hipMemset(ws->d_ctr, 0, SALT_CTR_N * sizeof(unsigned long long)));
     CHKW(hipStreamCreate(&ws->stream));
@@ -215,7 +227,7 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
 {
     if (!ws) return;
     hipSetDevice(ws->ix->device);
-    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_ctr);
+    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl);
     if (ws->stream) hipStreamDestroy(ws->stream);
     for (auto &e : ws->ev) if (e) hipEventDestroy(e);
     delete ws;
@@ -255,16 +267,23 @@ extern "C" int salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_
     }
     SeedParams sp; sp.n_reads = n_reads; sp.spr = spr; sp.l_seed = o->l_seed; sp.l_overlap = o->l_overlap;
     sp.max_seed = o->max_seed; sp.seed_only_ref = o->seed_only_ref;
+    if (n_reads > ws->max_reads) return fail(SALT_E_CAPACITY, "more reads than the workspace holds");
     AlignParams ap; ap.n_reads = n_reads; ap.spr = spr; ap.l_seed = o->l_seed; ap.max_locate = o->max_locate; ap.max_hits = o->max_hits;
+    ap.all_heavy = ws->all_heavy;
     unsigned long long *ctr = o->collect_counters ? ws->d_ctr : nullptr;
     const bool timed = ws->timing && ws->n_timed < MAX_TIMED;
-    hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * 3] : nullptr;
+    hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * 4] : nullptr;
+    HIPCHK(hipMemsetAsync(ws->d_qctl, 0, 8, st));
     if (timed) HIPCHK(hipEventRecord(ev[0], st));
     launch_seed(ws->ix->view, sp, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r, ctr, st);
     if (timed) HIPCHK(hipEventRecord(ev[1], st));
-    launch_align(ws->ix->view, ap, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
-                 static_cast<salt_result_t *>(d_results), ctr, st);
-    if (timed) { HIPCHK(hipEventRecord(ev[2], st)); ++ws->n_timed; }
+    if (!ap.all_heavy)
+        launch_light(ws->ix->view, ap, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
+                     static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, st);
+    if (timed) HIPCHK(hipEventRecord(ev[2], st));
+    launch_heavy(ws->ix->view, ap, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
+                 static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, ws->heavy_blocks, st);
+    if (timed) { HIPCHK(hipEventRecord(ev[3], st)); ++ws->n_timed; }
     HIPCHK(hipGetLastError());
     return SALT_OK;
 }
@@ -308,27 +327,72 @@ extern "C" int salt_gpu_ws_timing(salt_gpu_ws_t *ws, int enable)
     if (!ws) return fail(SALT_E_INVAL, "null argument");
     HIPCHK(hipSetDevice(ws->ix->device));
     if (enable && ws->ev.empty()) {
-        ws->ev.resize((size_t)MAX_TIMED * 3);
+        ws->ev.resize((size_t)MAX_TIMED * 4);
         for (auto &e : ws->ev) HIPCHK(hipEventCreate(&e));
     }
     ws->timing = enable != 0; ws->n_timed = 0;
     return SALT_OK;
 }
 
-extern "C" int salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[2], uint32_t *n_calls)
+extern "C" int salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[3], uint32_t *n_calls)
 {
     if (!ws || !ms || !n_calls) return fail(SALT_E_INVAL, "null argument");
     HIPCHK(hipSetDevice(ws->ix->device));
-    ms[0] = ms[1] = 0; *n_calls = ws->n_timed;
+    ms[0] = ms[1] = ms[2] = 0; *n_calls = ws->n_timed;
     for (uint32_t i = 0; i < ws->n_timed; ++i) {
-        hipEvent_t *ev = &ws->ev[(size_t)i * 3];
-        HIPCHK(hipEventSynchronize(ev[2]));
-        float a = 0, b = 0;
+        hipEvent_t *ev = &ws->ev[(size_t)i * 4];
+        HIPCHK(hipEventSynchronize(ev[3]));
+        float a = 0, b = 0, c = 0;
         HIPCHK(hipEventElapsedTime(&a, ev[0], ev[1]));
         HIPCHK(hipEventElapsedTime(&b, ev[1], ev[2]));
-        ms[0] += a; ms[1] += b;
+        HIPCHK(hipEventElapsedTime(&c, ev[2], ev[3]));
+        ms[0] += a; ms[1] += b; ms[2] += c;
     }
     ws->n_timed = 0;
+    return SALT_OK;
+}
+
+// Unit access for tests: verify / LV device functions on a caller-supplied mixRef (no index needed).
+extern "C" int salt_gpu_diag_lv(const uint32_t *ref_words, uint32_t ref_len, uint32_t n_cases, const uint32_t *pos,
+                                const uint32_t *kdiff, const uint8_t *seqs, const uint32_t *offs, int32_t *out4,
+                                uint16_t *cigars)
+{
+    if (!ref_words || !pos || !kdiff || !seqs || !offs || !out4 || !cigars) return fail(SALT_E_INVAL, "null argument");
+    int n_dev = 0;
+    HIPCHK(hipGetDeviceCount(&n_dev));
+    if (n_dev <= 0) return fail(SALT_E_HIP, "no HIP device visible");
+    const uint64_t nw = ((uint64_t)ref_len + 7) / 8 + 4;
+    uint32_t *d_ref = nullptr, *d_pos = nullptr, *d_k = nullptr, *d_offs = nullptr; uint8_t *d_seqs = nullptr;
+    int32_t *d_out = nullptr; uint16_t *d_cig = nullptr;
+    const uint64_t bases = offs[n_cases];
+    HIPCHK(hipMalloc((void **)&d_ref, nw * 4)); HIPCHK(hipMemset(d_ref, 0, nw * 4));
+    HIPCHK(hipMemcpy(d_ref, ref_words, (nw - 4) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_pos, (uint64_t)n_cases * 4)); HIPCHK(hipMemcpy(d_pos, pos, (uint64_t)n_cases * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_k, (uint64_t)n_cases * 4)); HIPCHK(hipMemcpy(d_k, kdiff, (uint64_t)n_cases * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_offs, ((uint64_t)n_cases + 1) * 4)); HIPCHK(hipMemcpy(d_offs, offs, ((uint64_t)n_cases + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_seqs, bases + 64)); HIPCHK(hipMemcpy(d_seqs, seqs, bases, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_out, (uint64_t)n_cases * 16));
+    HIPCHK(hipMalloc((void **)&d_cig, (uint64_t)n_cases * SALT_MAX_CIGAR_OPS * 2)); HIPCHK(hipMemset(d_cig, 0, (uint64_t)n_cases * SALT_MAX_CIGAR_OPS * 2));
+    IndexView v; memset(&v, 0, sizeof v);
+    v.ref = d_ref; v.ref_len = ref_len;
+    launch_diag_lv(v, n_cases, d_pos, d_k, d_seqs, d_offs, d_out, d_cig, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out4, d_out, (uint64_t)n_cases * 16, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cigars, d_cig, (uint64_t)n_cases * SALT_MAX_CIGAR_OPS * 2, hipMemcpyDeviceToHost));
+    hipFree(d_ref); hipFree(d_pos); hipFree(d_k); hipFree(d_offs); hipFree(d_seqs); hipFree(d_out); hipFree(d_cig);
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_ws_heavy_reads(salt_gpu_ws_t *ws, uint32_t *ids, uint32_t cap, uint32_t *n)
+{
+    if (!ws || !n) return fail(SALT_E_INVAL, "null argument");
+    HIPCHK(hipSetDevice(ws->ix->device));
+    HIPCHK(hipDeviceSynchronize());
+    uint32_t ctl[2];
+    HIPCHK(hipMemcpy(ctl, ws->d_qctl, 8, hipMemcpyDeviceToHost));
+    *n = ctl[0];
+    if (ids && cap) HIPCHK(hipMemcpy(ids, ws->d_queue, (uint64_t)(ctl[0] < cap ? ctl[0] : cap) * 4, hipMemcpyDeviceToHost));
     return SALT_OK;
 }
 

@@ -18,12 +18,20 @@ struct AlignParams {
     int32_t  l_seed;
     uint32_t max_locate;
     int32_t  max_hits;
+    int32_t  all_heavy;             // debug/A-B: skip k_light, k_heavy walks reads 0..n_reads-1
 };
 
 void launch_seed(const IndexView &ix, const SeedParams &sp, const uint8_t *seqs, const uint32_t *offs, uint4 *sai_c,
                  uint4 *sai_r, unsigned long long *ctr, hipStream_t st);
-void launch_align(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
-                  const uint4 *sai_r, salt_result_t *results, unsigned long long *ctr, hipStream_t st);
+void launch_light(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
+                  const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, unsigned long long *ctr, hipStream_t st);
+void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
+                  const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, uint32_t *qctl, unsigned long long *ctr,
+                  uint32_t n_blocks, hipStream_t st);
+
+uint32_t heavy_blocks_per_cu();
+void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const uint32_t *kdiff, const uint8_t *seqs,
+                    const uint32_t *offs, int32_t *out, uint16_t *cig, hipStream_t st);
 
 // attach-time expansion kernels (salt_index.hip)
 void launch_build_c_sa(const IndexView &ix, const uint32_t *sa_sampled, uint32_t sa_intv, uint32_t *out, hipStream_t st);

