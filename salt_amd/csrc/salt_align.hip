@@ -350,6 +350,40 @@ __device__ __forceinline__ uint32_t mismatch_capped(const IndexView &ix, const u
     return mism > 3 ? INF : mism;
 }
 
+// U candidates per lane with every reference word loaded before the first compare, so that the
+// U x (NW+1) independent loads overlap instead of paying one memory latency per candidate.
+// Requires (L+7)/8 <= NW.  pm[u] selects the strand's read masks; inactive slots return INF.
+template <int NW, int U>
+__device__ __forceinline__ void mismatch_batch(const IndexView &ix, const uint32_t *const (&pm)[U], uint32_t L,
+                                               const uint32_t (&pos)[U], const bool (&act)[U], uint32_t (&out)[U])
+{
+    const uint32_t nw = (L + 7) >> 3;
+    uint32_t rw[U][NW + 1];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t *ref = ix.ref + (pos[u] >> 3);
+#pragma unroll
+        for (int j = 0; j <= NW; ++j) rw[u][j] = (act[u] && (uint32_t)j <= nw) ? ref[j] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t sh = (pos[u] & 7u) * 4u;
+        uint32_t mism = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            if ((uint32_t)j < nw) {
+                const uint32_t w = sh ? ((rw[u][j] >> sh) | (rw[u][j + 1] << (32 - sh))) : rw[u][j];
+                const uint32_t x = w & pm[u][j];
+                const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
+                const uint32_t rem = L - (uint32_t)j * 8;
+                const uint32_t vm = rem >= 8 ? 0x11111111u : (0x11111111u >> (4 * (8 - rem)));
+                mism += (uint32_t)__popc(vm) - (uint32_t)__popc(nz & vm);
+            }
+        }
+        out[u] = act[u] ? (mism > 3 ? INF : mism) : INF;
+    }
+}
+
 // ---- Landau-Vishkin on byte masks, one diagonal per lane ---------------------------------------
 // T: text masks (tlen bytes, zero padded), P: one-hot pattern (plen bytes, zero padded).
 // Returns e (<= k), or -1.  When tab != nullptr also fills the L / action tables and returns the
@@ -566,9 +600,23 @@ __device__ void align_general(const IndexView &ix, const AlignParams &ap, WaveLd
     for (int strand = 0; strand < 2; ++strand) {
         uint32_t n_cand = build_candidates(ix, ap, w, r, strand, L, sai_c, sai_r, false, c_sa_c, c_sa_r, c_loci);
         uint32_t call_best_n = INF, call_best_pos = 0;
+        // phase A: every candidate's distance, 4 per lane with all loads in flight
+        if (L <= 8 * 13) {
+            for (uint32_t b = 0; b < n_cand; b += 256) {
+                uint32_t pp[4], vv[4]; bool aa[4];
+                const uint32_t *const pms[4] = { w.pm[strand], w.pm[strand], w.pm[strand], w.pm[strand] };
+                for (int u = 0; u < 4; ++u) { const uint32_t i = b + 64u * u + lane; aa[u] = i < n_cand; pp[u] = aa[u] ? w.loci[i] : 0u; }
+                mismatch_batch<13, 4>(ix, pms, L, pp, aa, vv);
+                for (int u = 0; u < 4; ++u) { const uint32_t i = b + 64u * u + lane; if (i < n_cand) w.cand_e[i] = (uint8_t)vv[u]; }
+            }
+        } else {
+            for (uint32_t i = lane; i < n_cand; i += 64) w.cand_e[i] = (uint8_t)mismatch_capped(ix, w.pm[strand], L, w.loci[i]);
+        }
+        WSYNC();
+        // phase B: the sequential rule, replayed by ballots over 64 candidates at a time
         for (uint32_t b = 0; b < n_cand; b += 64) {
             uint32_t i = b + lane, v = INF, pos = 0;
-            if (i < n_cand) { pos = w.loci[i]; v = mismatch_capped(ix, w.pm[strand], L, pos); }
+            if (i < n_cand) { pos = w.loci[i]; v = w.cand_e[i]; }
             // ballots by value: m[t] = lanes with v <= t
             uint64_t m0 = __ballot(v <= 0), m1 = __ballot(v <= 1), m2 = __ballot(v <= 2), m3 = __ballot(v <= 3);
             // a candidate passes iff v <= bound and no earlier candidate of this chunk is smaller
@@ -768,45 +816,13 @@ static constexpr int LT_MAXL = 160;
 
 struct LightLds {
     uint32_t pm[2][LT_MAXL / 8];
-    uint32_t sp[4][LT_SLOTS], ep[4][LT_SLOTS], off[4][LT_SLOTS];
-    uint32_t pre[4][LT_SLOTS + 1];       // rows enumerated before interval i of list l
-    uint32_t n_list[4];
+    uint32_t sp[4][LT_SLOTS], off[4][LT_SLOTS];
+    uint32_t pre[4][LT_SLOTS + 1];       // rows enumerated before slot i of list l
     uint32_t loci[2][LT_LOCI];
     uint32_t tmp[2][LT_LOCI];
     uint32_t hit_pos[2][NHIT];
     uint8_t  hit_nd[2][NHIT];
 };
-
-// insertion/introsort replica on one small list (same comparisons and swaps as sai_introsort above)
-__device__ void light_sort(LightLds &w, int l, int n)
-{
-    auto key = [&](int i) { return w.ep[l][i] - w.sp[l][i]; };
-    auto swp = [&](int i, int j) {
-        uint32_t a = w.sp[l][i], b = w.ep[l][i], c = w.off[l][i];
-        w.sp[l][i] = w.sp[l][j]; w.ep[l][i] = w.ep[l][j]; w.off[l][i] = w.off[l][j];
-        w.sp[l][j] = a; w.ep[l][j] = b; w.off[l][j] = c;
-    };
-    if (n < 2) return;
-    if (n == 2) { if (key(1) < key(0)) swp(0, 1); return; }
-    // n <= 16: ks_introsort makes exactly one partition pass over [0, n-1] (both halves are <= 16 long,
-    // so nothing is pushed and the loop ends), then insertion sort finishes (ksort.h:176-228)
-    {
-        int i = 0, j = n - 1, k = ((j - i) >> 1) + 1;
-        if (key(k) < key(i)) { if (key(k) < key(j)) k = j; }
-        else k = key(j) < key(i) ? i : j;
-        uint32_t rp = key(k);
-        if (k != n - 1) swp(k, n - 1);
-        for (;;) {
-            do ++i; while (key(i) < rp);
-            do --j; while (i <= j && rp < key(j));
-            if (j <= i) break;
-            swp(i, j);
-        }
-        swp(i, n - 1);
-    }
-    for (int i = 1; i < n; ++i)
-        for (int j = i; j > 0 && key(j) < key(j - 1); --j) swp(j, j - 1);
-}
 
 __global__ void __launch_bounds__(64)
 k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
@@ -839,25 +855,23 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
             w.pm[s][j] = word;
         }
         {
-            const uint32_t l = lane >> 4, slot = lane & 15u;               // l: 0 C/fwd 1 R/fwd 2 C/rev 3 R/rev
+            // lane = (list, slot); list: 0 C/fwd 1 R/fwd 2 C/rev 3 R/rev.  The reference orders each list by
+            // interval size (alnse.c:307-308), which only decides what is located first when the max_locate
+            // cap bites; here it cannot (<= 64 rows per list), and the loci are sorted afterwards anyway.
+            const uint32_t l = lane >> 4, slot = lane & 15u;
             uint4 v = make_uint4(1, 0, 0, 0);
             if (slot < ap.spr) v = ((l & 1) ? sai_r : sai_c)[((uint64_t)r * 2u + (l >> 1)) * ap.spr + slot];
-            const uint64_t m = __ballot(v.w != 0);
-            const uint64_t grp = 0xFFFFull << (l * 16);
-            if (v.w) { uint32_t at = (uint32_t)__popcll(m & grp & lt); w.sp[l][at] = v.x; w.ep[l][at] = v.y; w.off[l][at] = v.z; }
-            if (slot == 0) w.n_list[l] = (uint32_t)__popcll(m & grp);
-        }
-        WSYNC();
-        if (lane < 4) {                                                     // alnse.c:307-308 + row prefix sums
-            const int n = (int)w.n_list[lane];
-            light_sort(w, (int)lane, n);
-            uint32_t acc = 0;
-            for (int i = 0; i < n; ++i) { w.pre[lane][i] = acc; uint32_t sz = w.ep[lane][i] - w.sp[lane][i] + 1; acc = sz > 64 || acc + sz > 64 ? 65u : acc + sz; }
-            w.pre[lane][n] = acc;
+            uint32_t sz = v.w ? v.y - v.x + 1u : 0u;
+            if (sz > 65u) sz = 65u;                                         // keeps the sums below from wrapping
+            uint32_t inc = sz;                                              // inclusive prefix sum within the 16-lane row
+            for (int o = 1; o < 16; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 16); if (slot >= (uint32_t)o) inc += t; }
+            w.sp[l][slot] = v.x; w.off[l][slot] = v.z;
+            w.pre[l][slot + 1] = inc;
+            if (slot == 0) w.pre[l][0] = 0;
         }
         WSYNC();
         uint32_t tot[4];
-        for (int l = 0; l < 4; ++l) { tot[l] = w.pre[l][w.n_list[l]]; heavy |= tot[l] > 64; }
+        for (int l = 0; l < 4; ++l) { tot[l] = w.pre[l][16]; heavy |= tot[l] > 64; }
         if (!heavy) {
             // ---- round trip 2: every suffix-array row of the four lists at once ----
             uint32_t pos4[4]; bool keep4[4];
@@ -865,7 +879,7 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
                 keep4[l] = false; pos4[l] = 0;
                 if (lane < tot[l]) {
                     uint32_t i = 0;
-                    while (w.pre[l][i + 1] <= lane) ++i;
+                    while (w.pre[l][i + 1] <= lane) ++i;                   // skips empty slots (equal prefix sums)
                     const uint32_t j = w.sp[l][i] + (lane - w.pre[l][i]);
                     const uint32_t p = ((l & 1) ? ix.r_pos[j] : ix.c_sa[j]) - w.off[l][i];
                     pos4[l] = p;
@@ -911,45 +925,45 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
             }
             WSYNC();
             // ---- round trip 3: masked Hamming distance of every candidate of both strands ----
-            uint32_t v[2][2], p[2][2];
-            for (int s = 0; s < 2; ++s)
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t i = lane + 64 * h;
-                    v[s][h] = INF; p[s][h] = 0;
-                    if (i < n_c[s]) { p[s][h] = w.loci[s][i]; v[s][h] = mismatch_capped(ix, w.pm[s], L, p[s][h]); c_vwords += ((p[s][h] & 7u) + L + 7) >> 3; }
-                }
-            c_verify += n_c[0] + n_c[1];
-            // ---- the sequential best/first-hit rule, replayed by ballots (alnse.c:348-369, 1079-1083) ----
+            if (n_c[0] > 64 || n_c[1] > 64) heavy = true;                   // rare: leave multi-chunk scans to k_heavy
             uint32_t bound = 3, q_pos = 0xFFFFFFFFu, q_strand = 3, q_ndiff = 255;
             uint32_t n_hits_s[2] = { 0, 0 }, a0[2] = { 0, 0 };
             bool found[2] = { false, false };
-            for (int s = 0; s < 2; ++s) {
-                uint32_t call_best_n = INF, call_best_pos = 0;
-                for (int h = 0; h < 2; ++h) {
-                    if (64u * h >= n_c[s]) break;
-                    const uint32_t vv = v[s][h], pp = p[s][h];
+            if (!heavy) {
+                uint32_t v2[2];
+                const uint32_t *const pm2[2] = { w.pm[0], w.pm[1] };
+                const bool a2[2] = { lane < n_c[0], lane < n_c[1] };
+                const uint32_t p2[2] = { a2[0] ? w.loci[0][lane] : 0u, a2[1] ? w.loci[1][lane] : 0u };
+                if (L <= 8 * 13) mismatch_batch<13, 2>(ix, pm2, L, p2, a2, v2);
+                else mismatch_batch<20, 2>(ix, pm2, L, p2, a2, v2);
+                c_verify += n_c[0] + n_c[1];
+                if (a2[0]) c_vwords += ((p2[0] & 7u) + L + 7) >> 3;
+                if (a2[1]) c_vwords += ((p2[1] & 7u) + L + 7) >> 3;
+                // ---- the sequential best/first-hit rule, replayed by ballots (alnse.c:348-369, 1079-1083) ----
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const uint32_t vv = v2[s], pp = p2[s];
                     const uint64_t m0 = __ballot(vv <= 0), m1 = __ballot(vv <= 1), m2 = __ballot(vv <= 2);
                     const uint64_t smaller = vv == 0 ? 0ull : (vv == 1 ? m0 : (vv == 2 ? m1 : m2));
                     const bool pass = vv <= bound && (smaller & lt) == 0;
                     const uint64_t pm = __ballot(pass);
-                    if (!pm) continue;
-                    const uint32_t vmin = m0 & pm ? 0u : (m1 & pm ? 1u : (m2 & pm ? 2u : 3u));
-                    const uint32_t rank = n_hits_s[s] + (uint32_t)__popcll(pm & lt);
-                    if (pass && rank < NHIT) { w.hit_pos[s][rank] = pp; w.hit_nd[s][rank] = (uint8_t)vv; }
-                    if (n_hits_s[s] == 0) a0[s] = (uint32_t)__shfl((int)vv, __ffsll((long long)pm) - 1);
-                    const uint32_t add = (uint32_t)__popcll(pm);
-                    n_hits_s[s] = n_hits_s[s] + add > NHIT ? NHIT : n_hits_s[s] + add;
-                    if (vmin < call_best_n) {
+                    if (pm) {
+                        const uint32_t vmin = m0 & pm ? 0u : (m1 & pm ? 1u : (m2 & pm ? 2u : 3u));
+                        const uint32_t rank = (uint32_t)__popcll(pm & lt);
+                        if (pass && rank < NHIT) { w.hit_pos[s][rank] = pp; w.hit_nd[s][rank] = (uint8_t)vv; }
+                        a0[s] = (uint32_t)__shfl((int)vv, __ffsll((long long)pm) - 1);
+                        const uint32_t add = (uint32_t)__popcll(pm);
+                        n_hits_s[s] = add > NHIT ? NHIT : add;
                         const uint64_t at = __ballot(pass && vv == vmin);
-                        call_best_n = vmin;
-                        call_best_pos = (uint32_t)__shfl((int)pp, __ffsll((long long)at) - 1);
+                        q_pos = (uint32_t)__shfl((int)pp, __ffsll((long long)at) - 1);
+                        q_ndiff = vmin; q_strand = (uint32_t)s;
+                        found[s] = true;
+                        bound = vmin < bound ? vmin : bound;
                     }
-                    found[s] = true;
-                    bound = vmin < bound ? vmin : bound;
                 }
-                if (found[s]) { q_pos = call_best_pos; q_ndiff = call_best_n; q_strand = (uint32_t)s; }
             }
-            if (!found[0] && !found[1]) heavy = true;                       // needs the gapped pass
+            if (!heavy && !found[0] && !found[1]) heavy = true;             // needs the gapped pass
+            if (heavy) { }
             else {
                 WSYNC();
                 // ---- query_set_hits / gen_mapq (query.c:270-333) ----
