@@ -58,6 +58,8 @@ typedef struct {
     /* <P>.ref : mixRef_t (metaref.h) */
     uint32_t ref_len;
     const uint32_t *ref;
+    /* <P>.R.seedLen (aln.c:215-224); 0 = unknown.  Bounds the width of the device-side k-mer tables. */
+    int32_t  l_seed;
 } salt_host_index_t;
 
 /* The fields of aln_opt_t (aln.h:63-89) the single-end path reads. */
@@ -98,7 +100,10 @@ typedef struct {
 
 /* logical accesses of the reference algorithm, summed over a batch */
 enum { SALT_CTR_LKT, SALT_CTR_OCC_C, SALT_CTR_OCC_R, SALT_CTR_SA_C, SALT_CTR_SA_R, SALT_CTR_VERIFY,
-       SALT_CTR_VERIFY_WORDS, SALT_CTR_LV, SALT_CTR_READS, SALT_CTR_BASES, SALT_CTR_LOCI, SALT_CTR_N };
+       SALT_CTR_VERIFY_WORDS, SALT_CTR_LV, SALT_CTR_READS, SALT_CTR_BASES, SALT_CTR_LOCI,
+       /* diagnostics: shader-clock cycles k_heavy waves spent per phase (only with collect_counters) */
+       SALT_CTR_T_LOAD, SALT_CTR_T_GATHER, SALT_CTR_T_LOCATE, SALT_CTR_T_SORT, SALT_CTR_T_DEDUP, SALT_CTR_T_VERIFY,
+       SALT_CTR_T_SCAN, SALT_CTR_T_GAP, SALT_CTR_T_TAIL, SALT_CTR_HEAVY_READS, SALT_CTR_X0, SALT_CTR_X1, SALT_CTR_X2, SALT_CTR_X3, SALT_CTR_N };
 
 typedef struct salt_gpu_index salt_gpu_index_t;
 typedef struct salt_gpu_ws    salt_gpu_ws_t;
@@ -111,6 +116,10 @@ void salt_gpu_index_detach(salt_gpu_index_t *ix);
  * driver can broadcast it (RCCL) instead of re-packing on every rank. */
 int  salt_gpu_index_image(const salt_gpu_index_t *ix, void **dev_ptr, uint64_t *bytes);
 int  salt_gpu_index_attach_image(void *dev_ptr, uint64_t bytes, int device, salt_gpu_index_t **out);
+/* Replicates the packed image of `src` (attached on devices[0]) onto devices[1..n): one RCCL broadcast
+ * over xGMI inside this process (ncclCommInitAll + grouped ncclBroadcast), then attaches each copy.
+ * out[0] = src; out[i] owns its copy and is released with salt_gpu_index_detach. */
+int  salt_gpu_index_replicate(salt_gpu_index_t *src, const int *devices, int n, salt_gpu_index_t **out);
 /* device-to-device copy of the image into a caller-owned buffer of >= bytes (e.g. a broadcast buffer) */
 int  salt_gpu_index_image_copy(const salt_gpu_index_t *ix, void *dst_dev_ptr, uint64_t dst_bytes);
 

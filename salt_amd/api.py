@@ -20,7 +20,8 @@ LIB_DIR = os.path.join(_HERE, "lib")
 
 MAX_HITS = 5
 MAX_CIGAR_OPS = 64
-CTR_NAMES = ["lkt", "occ_c", "occ_r", "sa_c", "sa_r", "verify", "verify_words", "lv", "reads", "bases", "loci"]
+CTR_NAMES = ["lkt", "occ_c", "occ_r", "sa_c", "sa_r", "verify", "verify_words", "lv", "reads", "bases", "loci",
+             "t_load", "t_gather", "t_locate", "t_sort", "t_dedup", "t_verify", "t_scan", "t_gap", "t_tail", "heavy_reads", "x0", "x1", "x2", "x3"]
 
 
 class SaltError(RuntimeError):
@@ -52,6 +53,7 @@ class _HostIndex(ctypes.Structure):
         ("r_major_words", ctypes.c_uint32), ("r_major", ctypes.c_void_p),
         ("r_n_sa", ctypes.c_uint32), ("r_sa", ctypes.c_void_p),
         ("ref_len", ctypes.c_uint32), ("ref", ctypes.c_void_p),
+        ("l_seed", ctypes.c_int32),
     ]
 
 

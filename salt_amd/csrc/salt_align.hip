@@ -16,7 +16,11 @@
 
 namespace salt {
 
-#define WSYNC() __syncthreads()     /* blocks are exactly one wave: orders LDS traffic between lanes */
+// Every block is exactly one wave, and the LDS unit executes one wave's DS instructions in issue order, so
+// lanes only need the COMPILER not to move LDS accesses across the hand-off point: a wavefront-scope
+// fence + wave_barrier costs no instruction, where __syncthreads() costs s_waitcnt vmcnt(0) + s_barrier.
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); } while (0)
 
 static constexpr int MAXL = SALT_MAX_READ_LEN;
 static constexpr int SLOTS = SALT_MAX_SEED_SLOTS;
@@ -26,6 +30,28 @@ static constexpr int NHIT = 6;                  // first hits kept per strand (5
 static constexpr uint32_t INF = 255;
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Pointers that reach a non-inlined device function lose their address space (flat_load + coupled
+// vmcnt/lgkmcnt waits); these casts state that they point to global memory.
+typedef const uint32_t __attribute__((address_space(1))) *gp_u32;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef const u32x4_t __attribute__((address_space(1))) *gp_u32x4;
+__device__ __forceinline__ gp_u32 as_global(const uint32_t *p) { return (gp_u32)p; }
+__device__ __forceinline__ gp_u32x4 as_global(const uint4 *p) { return (gp_u32x4)(const void *)p; }
+
+// diagnostic phase clock: adds the cycles since the previous stamp to ctr[slot] (lane 0, only when counting)
+struct PhaseClock {                    // acc: a per-wave LDS array (flushed once per wave), or nullptr
+    unsigned long long *acc; uint64_t t;
+    __device__ PhaseClock(unsigned long long *a) : acc(a), t(a ? __builtin_amdgcn_s_memtime() : 0) {}
+    __device__ __forceinline__ void stamp(int slot)
+    {
+        if (!acc) return;
+        uint64_t n = __builtin_amdgcn_s_memtime();
+        if (lane_id() == 0) acc[slot] += (unsigned long long)(n - t);
+        t = n;
+    }
+    __device__ __forceinline__ void add(int slot, unsigned long long v) { if (acc && lane_id() == 0) acc[slot] += v; }
+};
 
 __device__ __forceinline__ uint32_t read_base(const uint8_t *seq, uint32_t L, int strand, uint32_t i)
 {
@@ -53,29 +79,24 @@ k_seed(IndexView ix, SeedParams sp, const uint8_t *__restrict__ seqs, const uint
         const uint32_t k = (uint32_t)sp.l_seed, s = slot * (uint32_t)sp.l_overlap;
         uint4 oc = make_uint4(1, 0, 0, 0), orr = make_uint4(1, 0, 0, 0);
         if (L >= k && s + k <= L) {
-            const uint32_t e = s + k - 1, lk = ix.lkt_len;
-            // 12-mer at the seed tail (LKT_seq2LktItem, lookup.c:163-177)
+            const uint32_t e = s + k - 1, W = ix.r_lkt_len;
+            // W-mer at the seed tail: both searches start from their tabulated interval
+            // (LKT_seq2LktItem / LKT_lookup_sa lookup.c:163-177 + the first steps of bwt.c:281-309, rbwt.c:619-648)
             uint32_t x = 0; bool has_n = false;
-            for (uint32_t t = 0; t < lk; ++t) {
-                uint32_t c = read_base(seq, L, strand, e - lk + 1 + t);
+            for (uint32_t t = 0; t < W; ++t) {
+                uint32_t c = read_base(seq, L, strand, e - W + 1 + t);
                 has_n |= c > 3; x = (x << 2) | (c & 3u);
             }
             uint32_t kc = 1, lc = 0, kr = 1, lr = 0;
             bool alive_c = !has_n, alive_r = !has_n && !sp.seed_only_ref;
-            if (alive_c) { kc = ix.lkt[x]; lc = ix.lkt[x + 1] - 1; alive_c = kc <= lc; ++n_lkt; }
-            int i_r_start;                                   // first head index the R search still has to consume
-            if (ix.r_lkt_len == lk) {
-                if (alive_r) { uint2 v = ix.r_lkt[x]; kr = v.x; lr = v.y; alive_r = kr <= lr; n_occ_r += 2 * lk; }
-                i_r_start = (int)(k - lk) - 1;
-            } else {                                          // no R table: start from the full range
-                kr = 0; lr = ix.r_text_len; i_r_start = (int)k - 1;
-                alive_r = !sp.seed_only_ref;
-            }
+            if (alive_c) { uint2 v = ix.c_wlkt[x]; kc = v.x; lc = v.y; alive_c = kc <= lc; ++n_lkt; n_occ_c += 2 * (W - ix.lkt_len); }
+            if (alive_r) { uint2 v = ix.r_lkt[x]; kr = v.x; lr = v.y; alive_r = kr <= lr; n_occ_r += 2 * W; }
+            const int i_r_start = (int)(k - W) - 1;         // first head index still to consume
             // joint backward search over the seed head, newest base last (bwt.c:281-309, rbwt.c:619-648)
             for (int i = i_r_start; i >= 0 && (alive_c || alive_r); --i) {
                 uint32_t c = read_base(seq, L, strand, s + (uint32_t)i);
                 if (c > 3) { alive_c = false; alive_r = false; break; }
-                if (alive_c && i < (int)(k - lk)) {
+                if (alive_c) {
                     uint32_t ok = c_occ(ix, kc - 1, c), ol = c_occ(ix, lc, c);
                     kc = ix.c_L2[c] + ok + 1; lc = ix.c_L2[c] + ol; alive_c = kc <= lc; n_occ_c += 2;
                 }
@@ -236,22 +257,31 @@ __device__ void sort_loci(uint32_t *a, uint32_t n)
 // ---- candidates of one strand: gather seeds, order them, locate, sort, dedup ----------------------
 // Leaves the candidate positions in w.loci[0..return).  gap_mode selects the range filter of
 // alnse_check_withgap (alnse.c:894) instead of alnse_check_nogap's (alnse.c:762).
-__device__ __attribute__((noinline)) uint32_t build_candidates(const IndexView &ix, const AlignParams &ap, WaveLds &w, uint32_t r, int strand,
-                                     uint32_t L, const uint4 *sai_c, const uint4 *sai_r, bool gap_mode,
-                                     uint32_t &n_sa_c, uint32_t &n_sa_r, uint32_t &n_loci_out)
+struct CandStats { uint32_t n_cand, n_sa_c, n_sa_r, n_loci; };
+struct CandArgs {                      // everything by value: a by-reference IndexView would live in scratch memory
+    const uint32_t *c_sa, *r_pos; const uint4 *sai_c, *sai_r;
+    uint32_t ref_len, spr, max_locate, r, L; int strand; bool gap_mode; unsigned long long *phase;
+};
+__device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, WaveLds &w)
 {
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t L = a.L, r = a.r; const int strand = a.strand; const bool gap_mode = a.gap_mode;
+    const gp_u32x4 sai_c = as_global(a.sai_c), sai_r = as_global(a.sai_r);
+    struct { gp_u32 c_sa, r_pos; uint32_t ref_len; } ix = { as_global(a.c_sa), as_global(a.r_pos), a.ref_len };
+    struct { uint32_t spr, max_locate; } ap = { a.spr, a.max_locate };
+    uint32_t n_sa_c = 0, n_sa_r = 0, n_loci_out = 0;
+    PhaseClock pc(a.phase);
     const uint64_t base_item = ((uint64_t)r * 2u + (uint32_t)strand) * ap.spr;
     uint32_t n_list[2] = { 0, 0 };
     // gather valid seeds in seed order (n_C / n_back_R grow in seed_start order, alnse.c:265-300)
     for (int which = 0; which < 2; ++which) {
-        const uint4 *src = which == 0 ? sai_c : sai_r;
+        const gp_u32x4 src = which == 0 ? sai_c : sai_r;
         uint32_t n = 0;
         for (uint32_t b = 0; b < ap.spr; b += 64) {
             uint32_t slot = b + lane;
             uint4 v = make_uint4(1, 0, 0, 0);
-            if (slot < ap.spr) v = src[base_item + slot];
+            if (slot < ap.spr) { const u32x4_t t = src[base_item + slot]; v = make_uint4(t.x, t.y, t.z, t.w); }
             uint64_t m = __ballot(v.w != 0);
             if (v.w) { uint32_t at = n + (uint32_t)__popcll(m & lt); w.u.sai.sp[which][at] = v.x; w.u.sai.ep[which][at] = v.y; w.u.sai.off[which][at] = v.z; }
             n += (uint32_t)__popcll(m);
@@ -261,12 +291,14 @@ __device__ __attribute__((noinline)) uint32_t build_candidates(const IndexView &
     WSYNC();
     if (lane < 2) sai_introsort(w.u.sai, (int)lane, (int)n_list[lane]);      // alnse.c:307-308
     WSYNC();
+    pc.stamp(SALT_CTR_T_GATHER);
     // locate under the global cap (alnse_locate_alt, alnse.c:633-731)
     uint32_t n = 0;
     bool full = false;
     for (uint32_t i = 0; i < n_list[0] && !full; ++i) {
         const uint32_t sp = w.u.sai.sp[0][i], ep = w.u.sai.ep[0][i], off = w.u.sai.off[0][i];
         for (uint64_t j0 = sp; j0 <= ep && !full; j0 += 64) {
+            pc.add(SALT_CTR_X0, 1);
             uint64_t j = j0 + lane;
             bool in = j <= ep, keep = false;
             uint32_t pos = 0;
@@ -286,11 +318,13 @@ __device__ __attribute__((noinline)) uint32_t build_candidates(const IndexView &
             } else { n += tot; n_sa_c += (uint32_t)__popcll(__ballot(in)); }
         }
     }
+    pc.stamp(SALT_CTR_X2);
     for (uint32_t i = 0; i < n_list[1] && !full; ++i) {
         const uint32_t sp = w.u.sai.sp[1][i], ep = w.u.sai.ep[1][i], off = w.u.sai.off[1][i];
         uint32_t skip = (ep + 1 - sp) / 0x40000u;                                       // alnse.c:707-708
         if ((int)skip <= 0) skip = 1;
         for (uint64_t j0 = sp; j0 <= ep && !full; j0 += 64ull * skip) {
+            pc.add(SALT_CTR_X1, 1);
             uint64_t j = j0 + (uint64_t)lane * skip;
             bool in = j <= ep, keep = false;
             uint32_t pos = 0;
@@ -309,8 +343,10 @@ __device__ __attribute__((noinline)) uint32_t build_candidates(const IndexView &
     }
     n_loci_out += n;
     WSYNC();
+    pc.stamp(SALT_CTR_T_LOCATE);
     sort_loci(w.loci, n);
     WSYNC();
+    pc.stamp(SALT_CTR_T_SORT);
     // drop duplicates and out-of-range loci, keeping order (alnse.c:758-762 / 890-894)
     uint32_t n_out = 0;
     for (uint32_t b = 0; b < n; b += 64) {
@@ -328,7 +364,8 @@ __device__ __attribute__((noinline)) uint32_t build_candidates(const IndexView &
         n_out += (uint32_t)__popcll(m);
         WSYNC();
     }
-    return n_out;
+    pc.stamp(SALT_CTR_T_DEDUP);
+    return CandStats{ n_out, n_sa_c, n_sa_r, n_loci_out };
 }
 
 // ---- masked Hamming distance, capped: returns 0..3 or INF (ed_mismatch, editdistance.c:88-163) ----
@@ -381,6 +418,55 @@ __device__ __forceinline__ void mismatch_batch(const IndexView &ix, const uint32
             }
         }
         out[u] = act[u] ? (mism > 3 ? INF : mism) : INF;
+    }
+}
+
+// ---- masked Hamming distance, four lanes per candidate -------------------------------------------
+// Each lane of a quad loads 16 contiguous bytes of the candidate's window (one dwordx4), so a wave-wide
+// load touches 16 candidates x 64 B instead of 64 lanes x 14 scattered dwords: ~8x fewer cache-line
+// lookups per candidate in the texture-address path, which is what bounds this stage.
+// Needs (L+7)/8 + 1 <= 16 words, i.e. L <= 120.  Writes min(count, INF) for candidates [0, n) to out[].
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, const uint32_t *pm, uint32_t L,
+                                             const uint32_t *cand, uint32_t n, uint8_t *out)
+{
+    const uint32_t lane = lane_id(), sub = lane & 3u, q = lane >> 2;
+    const uint32_t nw = (L + 7) >> 3;
+    uint32_t pmw[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) pmw[t] = (4 * sub + t) < nw ? pm[4 * sub + t] : 0u;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {                           // 4 groups of 16 candidates per trip
+        uint32_t pos[4]; u32x4_a4 x[4]; bool act[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t c = c0 + 16u * g + q;
+            act[g] = c < n;
+            pos[g] = act[g] ? cand[c] : 0u;
+            x[g] = *reinterpret_cast<const u32x4_a4 *>(ref + (pos[g] >> 3) + 4 * sub);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t sh = (pos[g] & 7u) * 4u;
+            const uint32_t nxt = (uint32_t)__shfl_down((int)x[g].x, 1);       // first word of the next lane of the quad
+            const uint32_t xs[5] = { x[g].x, x[g].y, x[g].z, x[g].w, nxt };
+            uint32_t mism = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t j = 4 * sub + t;
+                if (j < nw) {
+                    const uint32_t w = sh ? ((xs[t] >> sh) | (xs[t + 1] << (32 - sh))) : xs[t];
+                    const uint32_t y = w & pmw[t];
+                    const uint32_t nz = (y | (y >> 1) | (y >> 2) | (y >> 3)) & 0x11111111u;
+                    const uint32_t rem = L - j * 8;
+                    const uint32_t vm = rem >= 8 ? 0x11111111u : (0x11111111u >> (4 * (8 - rem)));
+                    mism += (uint32_t)__popc(vm) - (uint32_t)__popc(nz & vm);
+                }
+            }
+            mism += (uint32_t)__shfl_xor((int)mism, 1);
+            mism += (uint32_t)__shfl_xor((int)mism, 2);
+            if (act[g] && sub == 0) out[c0 + 16u * g + q] = (uint8_t)(mism > 3 ? INF : mism);
+        }
     }
 }
 
@@ -481,12 +567,13 @@ __device__ __attribute__((noinline)) uint32_t lv_lanes(LaneLv &s, const uint32_t
 }
 
 // unpack text masks / one-hot pattern for LV (editdistance.c:183-227)
-__device__ void lv_unpack(const IndexView &ix, WaveLds &w, int strand, uint32_t L, uint32_t pos)
+__device__ void lv_unpack(const uint32_t *ref_generic, WaveLds &w, int strand, uint32_t L, uint32_t pos)
 {
+    const gp_u32 ref = as_global(ref_generic);
     const uint32_t tlen = L + 4;
     for (uint32_t i = lane_id(); i < tlen + 48; i += 64) {
         uint32_t p = pos + i;
-        w.lvT[i] = i < tlen ? (uint8_t)((ix.ref[p >> 3] >> (4 * (p & 7u))) & 15u) : (uint8_t)0;
+        w.lvT[i] = i < tlen ? (uint8_t)((ref[p >> 3] >> (4 * (p & 7u))) & 15u) : (uint8_t)0;
     }
     for (uint32_t i = lane_id(); i < L + 48; i += 64) {
         uint8_t c = i < L ? w.seq[strand][i] : (uint8_t)5;
@@ -496,9 +583,9 @@ __device__ void lv_unpack(const IndexView &ix, WaveLds &w, int strand, uint32_t 
 }
 
 // CIGAR of a gapped hit into w.cig / w.n_cig (computeEditDistanceWithCigar, useM=1) ------------------
-__device__ __attribute__((noinline)) void lv_cigar(const IndexView &ix, WaveLds &w, int strand, uint32_t L, uint32_t pos, int k)
+__device__ __attribute__((noinline)) void lv_cigar(const uint32_t *ref, WaveLds &w, int strand, uint32_t L, uint32_t pos, int k)
 {
-    lv_unpack(ix, w, strand, L, pos);
+    lv_unpack(ref, w, strand, L, pos);
     int d_fin = 0;
     WSYNC();
     int e = lv_wave(w.lvT, (int)L + 4, w.lvP, (int)L, k, &w.u.lv, d_fin);
@@ -542,16 +629,19 @@ __device__ __attribute__((noinline)) void lv_cigar(const IndexView &ix, WaveLds 
 // ---------------------------------------------------------------------------------------------
 // k_align
 // ---------------------------------------------------------------------------------------------
-__device__ void align_general(const IndexView &ix, const AlignParams &ap, WaveLds &w, const uint32_t r,
+__device__ __forceinline__ void align_general(const IndexView ix, const AlignParams ap, WaveLds &w, const uint32_t r,
                               const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
                               const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r,
-                              salt_result_t *__restrict__ results, unsigned long long *__restrict__ ctr)
+                              salt_result_t *__restrict__ results, unsigned long long *__restrict__ ctr,
+                              unsigned long long *phase)
 {
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t off = offs[r], L = offs[r + 1] - off;
     salt_result_t *out = results + r;
     uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_lv = 0, c_loci = 0;
+    PhaseClock pc(phase);
+    const uint64_t rt0 = phase ? __builtin_amdgcn_s_memrealtime() : 0;
 
     // ---- load the read, both strands (query.c:177-183, 46-71) ----
     uint32_t n_amb = 0;
@@ -591,6 +681,7 @@ __device__ void align_general(const IndexView &ix, const AlignParams &ap, WaveLd
     }
     WSYNC();
 
+    pc.stamp(SALT_CTR_T_LOAD);
     // ---- gap-free pass over both strands (alnse.c:1077-1084) ----
     uint32_t bound = 3;
     bool found[2] = { false, false };
@@ -598,10 +689,14 @@ __device__ void align_general(const IndexView &ix, const AlignParams &ap, WaveLd
     uint32_t a0[2] = { 0, 0 };                  // n_diff of the first hit of each list
     if (!too_short)
     for (int strand = 0; strand < 2; ++strand) {
-        uint32_t n_cand = build_candidates(ix, ap, w, r, strand, L, sai_c, sai_r, false, c_sa_c, c_sa_r, c_loci);
+        pc.stamp(SALT_CTR_T_SCAN);
+        const CandStats cs = build_candidates(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase }, w);
+        pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
+        const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
         uint32_t call_best_n = INF, call_best_pos = 0;
         // phase A: every candidate's distance, 4 per lane with all loads in flight
-        if (L <= 8 * 13) {
+        if (L <= 120) verify_quads(ix.ref, w.pm[strand], L, w.loci, n_cand, w.cand_e);
+        else if (L <= 8 * 13) {
             for (uint32_t b = 0; b < n_cand; b += 256) {
                 uint32_t pp[4], vv[4]; bool aa[4];
                 const uint32_t *const pms[4] = { w.pm[strand], w.pm[strand], w.pm[strand], w.pm[strand] };
@@ -613,6 +708,7 @@ __device__ void align_general(const IndexView &ix, const AlignParams &ap, WaveLd
             for (uint32_t i = lane; i < n_cand; i += 64) w.cand_e[i] = (uint8_t)mismatch_capped(ix, w.pm[strand], L, w.loci[i]);
         }
         WSYNC();
+        pc.stamp(SALT_CTR_T_VERIFY);
         // phase B: the sequential rule, replayed by ballots over 64 candidates at a time
         for (uint32_t b = 0; b < n_cand; b += 64) {
             uint32_t i = b + lane, v = INF, pos = 0;
@@ -645,13 +741,17 @@ __device__ void align_general(const IndexView &ix, const AlignParams &ap, WaveLd
         for (uint32_t b = lane; b < n_cand; b += 64) c_vwords += ((w.loci[b] & 7u) + L + 7) >> 3;
         if (found[strand]) { q_pos = call_best_pos; q_ndiff = call_best_n; q_gap = 0; q_strand = (uint32_t)strand; }
         WSYNC();
+        pc.stamp(SALT_CTR_T_SCAN);
     }
 
     // ---- gapped pass (alnse.c:1089-1096): sequential per candidate, LV across lanes ----
     if (!too_short && !found[0] && !found[1]) {
         int maxd = (int)(L / 10);
         for (int strand = 0; strand < 2; ++strand) {
-            uint32_t n_cand = build_candidates(ix, ap, w, r, strand, L, sai_c, sai_r, true, c_sa_c, c_sa_r, c_loci);
+            pc.stamp(SALT_CTR_T_GAP);
+            const CandStats cs = build_candidates(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase }, w);
+            pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
+            const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
             bool any = false;
             // all candidates' distances at the call's initial bound, 64 at a time (one per lane); the
             // sequential rule below then only compares numbers
@@ -691,7 +791,7 @@ __device__ void align_general(const IndexView &ix, const AlignParams &ap, WaveLd
                 int e = -1;
                 if (lanes_ok) { const uint32_t ev = w.cand_e[i]; e = (ev != 255 && (int)ev <= maxd) ? (int)ev : -1; }
                 else if (!(pos > ix.ref_len || pos + L + 4 > ix.ref_len)) {   // ed_diff guard (editdistance.c:178)
-                    lv_unpack(ix, w, strand, L, pos);
+                    lv_unpack(ix.ref, w, strand, L, pos);
                     int dd;
                     e = lv_wave(w.lvT, (int)L + 4, w.lvP, (int)L, maxd, nullptr, dd);
                     WSYNC();
@@ -713,6 +813,7 @@ __device__ void align_general(const IndexView &ix, const AlignParams &ap, WaveLd
         }
     }
     WSYNC();
+    pc.stamp(SALT_CTR_T_GAP);
 
     // ---- hits, MAPQ (query_set_hits / gen_mapq, query.c:270-333) ----
     // every lane computes the same small loop; lane 0 writes
@@ -751,7 +852,7 @@ __device__ void align_general(const IndexView &ix, const AlignParams &ap, WaveLd
     // ---- CIGARs (query_gen_cigar query.c:282-296; XA cigars sam.c:216-225) ----
     if (q_pos != 0xFFFFFFFFu) {
         if (q_gap) {
-            lv_cigar(ix, w, (int)q_strand, L, q_pos, (int)q_ndiff);
+            lv_cigar(ix.ref, w, (int)q_strand, L, q_pos, (int)q_ndiff);
             if (lane < (uint32_t)w.n_cig) out->cigar[lane] = w.cig[lane];
             if (lane == 0) out->n_cigar = (uint8_t)w.n_cig;
         } else if (lane == 0) { out->cigar[0] = (uint16_t)((L << 4) | 0u); out->n_cigar = 1; }
@@ -762,12 +863,14 @@ __device__ void align_general(const IndexView &ix, const AlignParams &ap, WaveLd
             uint32_t h = sel_idx[s][j];
             if (w.hit_gap[s][h]) {
                 WSYNC();
-                lv_cigar(ix, w, s, L, w.hit_pos[s][h], (int)w.hit_nd[s][h]);
+                lv_cigar(ix.ref, w, s, L, w.hit_pos[s][h], (int)w.hit_nd[s][h]);
                 if (lane < (uint32_t)w.n_cig) out->hit_cigar[hidx][lane] = w.cig[lane];
                 if (lane == 0) out->hit_n_cigar[hidx] = (uint8_t)w.n_cig;
             } else if (lane == 0) out->hit_n_cigar[hidx] = 0;
         }
 
+    pc.stamp(SALT_CTR_T_TAIL);
+    if (phase) pc.add(SALT_CTR_X3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - rt0));
     if (ctr) {
         for (int o = 32; o > 0; o >>= 1) c_vwords += __shfl_down(c_vwords, o);
         if (lane == 0) {
@@ -789,6 +892,10 @@ k_heavy(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
 {
     __shared__ WaveLds w;
     __shared__ uint32_t s_item;
+    __shared__ unsigned long long s_phase[SALT_CTR_N];
+    unsigned long long *phase = ctr ? s_phase : nullptr;
+    if (ctr) { for (int i = threadIdx.x; i < SALT_CTR_N; i += 64) s_phase[i] = 0; }
+    WSYNC();
     const uint32_t n_items = ap.all_heavy ? ap.n_reads : qctl[0];       // qctl[0]: reads queued by k_light
     for (;;) {                                                           // every wave leaves once the head passes n_items
         if (threadIdx.x == 0) s_item = atomicAdd(&qctl[1], 1u);
@@ -796,8 +903,13 @@ k_heavy(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
         const uint32_t it = s_item;
         WSYNC();
         if (it >= n_items) break;
-        align_general(ix, ap, w, ap.all_heavy ? it : queue[it], seqs, offs, sai_c, sai_r, results, ctr);
+        align_general(ix, ap, w, ap.all_heavy ? it : queue[it], seqs, offs, sai_c, sai_r, results, ctr, phase);
+        if (phase && threadIdx.x == 0) s_phase[SALT_CTR_HEAVY_READS] += 1;
         WSYNC();
+    }
+    if (phase) {                                                         // one flush per wave
+        WSYNC();
+        for (int i = SALT_CTR_T_LOAD + (int)threadIdx.x; i < SALT_CTR_N; i += 64) if (s_phase[i]) atomicAdd(ctr + i, s_phase[i]);
     }
 }
 
@@ -822,6 +934,7 @@ struct LightLds {
     uint32_t tmp[2][LT_LOCI];
     uint32_t hit_pos[2][NHIT];
     uint8_t  hit_nd[2][NHIT];
+    uint8_t  val[2][64];
 };
 
 __global__ void __launch_bounds__(64)
@@ -934,8 +1047,12 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
                 const uint32_t *const pm2[2] = { w.pm[0], w.pm[1] };
                 const bool a2[2] = { lane < n_c[0], lane < n_c[1] };
                 const uint32_t p2[2] = { a2[0] ? w.loci[0][lane] : 0u, a2[1] ? w.loci[1][lane] : 0u };
-                if (L <= 8 * 13) mismatch_batch<13, 2>(ix, pm2, L, p2, a2, v2);
-                else mismatch_batch<20, 2>(ix, pm2, L, p2, a2, v2);
+                if (L <= 120) {
+                    verify_quads(ix.ref, w.pm[0], L, w.loci[0], n_c[0], w.val[0]);
+                    verify_quads(ix.ref, w.pm[1], L, w.loci[1], n_c[1], w.val[1]);
+                    WSYNC();
+                    v2[0] = a2[0] ? w.val[0][lane] : INF; v2[1] = a2[1] ? w.val[1][lane] : INF;
+                } else mismatch_batch<20, 2>(ix, pm2, L, p2, a2, v2);
                 c_verify += n_c[0] + n_c[1];
                 if (a2[0]) c_vwords += ((p2[0] & 7u) + L + 7) >> 3;
                 if (a2[1]) c_vwords += ((p2[1] & 7u) + L + 7) >> 3;
@@ -1067,7 +1184,7 @@ k_diag_lv(IndexView ix, uint32_t n_cases, const uint32_t *__restrict__ pos, cons
     const bool in_range = !(p > ix.ref_len || p + L + 4 > ix.ref_len);
     const int k = (int)kdiff[c];
     if (in_range) {
-        lv_unpack(ix, w, 0, L, p);
+        lv_unpack(ix.ref, w, 0, L, p);
         int dd;
         e_wave = lv_wave(w.lvT, (int)L + 4, w.lvP, (int)L, k, nullptr, dd);
         WSYNC();
@@ -1090,7 +1207,7 @@ k_diag_lv(IndexView ix, uint32_t n_cases, const uint32_t *__restrict__ pos, cons
             WSYNC();
         }
         if (e_wave >= 0 && e_wave < LVK) {
-            lv_cigar(ix, w, 0, L, p, e_wave);
+            lv_cigar(ix.ref, w, 0, L, p, e_wave);
             n_cig = w.n_cig;
             if (lane < (uint32_t)w.n_cig) cig_out[(size_t)c * SALT_MAX_CIGAR_OPS + lane] = w.cig[lane];
         }

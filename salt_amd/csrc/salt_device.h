@@ -13,8 +13,11 @@
 //          1-in-8 samples by the reference's own LF walk (bwt.c:89-102) -- locate is then one load.
 //   r_pos  for every R suffix-array row the value Rbwt_back_bwt_sa() (rbwt.c:316-333) returns,
 //          again expanded once at attach time.
-//   r_lkt  (k,l) of the R index after backward-searching each 12-mer from the full range, i.e. the
-//          first 12 iterations of Rbwt_exact_match_backward (rbwt.c:619-648), tabulated once.
+//   c_wlkt / r_lkt  W-mer tables (W = 12..16, default 14, never above the seed length): for every W-mer
+//          the SA interval both searches hold after consuming it -- C: LKT_lookup_sa on its last 12 bases
+//          (lookup.h:39-53, with that table's A-padded tail quirk) followed by W-12 steps of
+//          bwt_match_exact_alt (bwt.c:281-309); R: the first W iterations of Rbwt_exact_match_backward
+//          from (0, textLength) (rbwt.c:619-648).  Tabulated once at attach time; (1,0) = dead.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,16 +37,16 @@ struct ImageHeader {
     uint32_t lkt_len, lkt_n;
     uint32_t r_text_len, r_inv_sa0, r_cum[6];
     uint32_t ref_len, r_lkt_len;
-    uint64_t off_c_occ, off_c_sa, off_lkt, off_r_occ, off_r_pos, off_r_lkt, off_ref;
+    uint64_t off_c_occ, off_c_sa, off_lkt, off_r_occ, off_r_pos, off_r_lkt, off_ref, off_c_wlkt;
     uint64_t n_c_blocks, n_r_blocks;
-    uint64_t reserved[8];
+    uint64_t reserved[7];
 };
 static const uint64_t IMAGE_MAGIC = 0x53414c5447465839ull;          // "SALTGFX9"
 
 // What kernels receive (by value): resolved pointers + scalars.
 struct IndexView {
     const COcc *c_occ; const uint32_t *c_sa; const uint32_t *lkt;
-    const ROcc *r_occ; const uint32_t *r_pos; const uint2 *r_lkt; const uint32_t *ref;
+    const ROcc *r_occ; const uint32_t *r_pos; const uint2 *r_lkt; const uint32_t *ref; const uint2 *c_wlkt;
     uint32_t c_primary, c_L2[5], c_seq_len;
     uint32_t r_text_len, r_inv_sa0, r_cum[6];
     uint32_t ref_len, lkt_len, r_lkt_len;

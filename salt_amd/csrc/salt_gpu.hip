@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include "salt_kernels.h"
+#include <rccl/rccl.h>
 
 using namespace salt;
 
@@ -56,6 +57,7 @@ static void make_view(salt_gpu_index *ix)
     v.r_pos = reinterpret_cast<const uint32_t *>(b + h.off_r_pos);
     v.r_lkt = reinterpret_cast<const uint2 *>(b + h.off_r_lkt);
     v.ref = reinterpret_cast<const uint32_t *>(b + h.off_ref);
+    v.c_wlkt = reinterpret_cast<const uint2 *>(b + h.off_c_wlkt);
     v.c_primary = h.c_primary; memcpy(v.c_L2, h.c_L2, sizeof v.c_L2); v.c_seq_len = h.c_seq_len;
     v.r_text_len = h.r_text_len; v.r_inv_sa0 = h.r_inv_sa0; memcpy(v.r_cum, h.r_cum, sizeof v.r_cum);
     v.ref_len = h.ref_len; v.lkt_len = h.lkt_len; v.r_lkt_len = h.r_lkt_len;
@@ -85,7 +87,16 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     hd.c_primary = h->c_primary; memcpy(hd.c_L2, h->c_L2, sizeof hd.c_L2); hd.c_seq_len = h->c_seq_len; hd.c_sa_intv = h->c_sa_intv;
     hd.lkt_len = h->lkt_len; hd.lkt_n = h->lkt_n;
     hd.r_text_len = h->r_text_len; hd.r_inv_sa0 = h->r_inv_sa0; memcpy(hd.r_cum, h->r_cum, sizeof hd.r_cum);
-    hd.ref_len = h->ref_len; hd.r_lkt_len = h->lkt_len;
+    hd.ref_len = h->ref_len;
+    {   // width of the device k-mer tables: 8 B x 4^W per table (W=14: 2 GiB each, W=16: 32 GiB each)
+        uint32_t w = 14;
+        if (const char *e = getenv("SALT_GPU_LKT_LEN")) w = (uint32_t)atoi(e);
+        if (h->l_seed > 0 && w > (uint32_t)h->l_seed) w = (uint32_t)h->l_seed;
+        if (h->l_seed <= 0) w = h->lkt_len;
+        if (w < h->lkt_len) w = h->lkt_len;
+        if (w > 16) w = 16;
+        hd.r_lkt_len = w;
+    }
     hd.n_c_blocks = (uint64_t)h->c_seq_len / 64 + 1;
     hd.n_r_blocks = (uint64_t)h->r_text_len / 128 + 1;
     const uint64_t ref_words = ((uint64_t)h->ref_len + 7) / 8;
@@ -95,7 +106,8 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     hd.off_lkt = off;   off = align_up(off + (uint64_t)h->lkt_n * 4, 256);
     hd.off_r_occ = off; off = align_up(off + hd.n_r_blocks * sizeof(ROcc), 256);
     hd.off_r_pos = off; off = align_up(off + ((uint64_t)h->r_text_len + 1) * 4, 256);
-    hd.off_r_lkt = off; off = align_up(off + (1ull << (2 * h->lkt_len)) * 8, 256);
+    hd.off_r_lkt = off; off = align_up(off + (1ull << (2 * hd.r_lkt_len)) * 8, 256);
+    hd.off_c_wlkt = off; off = align_up(off + (1ull << (2 * hd.r_lkt_len)) * 8, 256);
     hd.off_ref = off;   off = align_up(off + (ref_words + 4) * 4, 256);
     hd.bytes = off;
     ix->bytes = off;
@@ -142,7 +154,7 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     uint32_t *d_sa_s = nullptr, *d_r_sa = nullptr;
 #define CHK2(x) do { hipError_t e2 = (x); if (e2 != hipSuccess) { hipFree(ix->image); hipFree(d_sa_s); hipFree(d_r_sa); delete ix; \
     return fail(SALT_E_HIP, std::string(#x) + ": " + hipGetErrorString(e2)); } } while (0)
-    CHK2(hipMemset(ix->image, 0, ix->bytes));
+    CHK2(hipMemset(ix->image, 0, hd.off_r_lkt));     // the two W-mer tables are fully written by their kernels
     CHK2(hipMemcpy(ix->image, &hd, sizeof hd, hipMemcpyHostToDevice));
     CHK2(hipMemcpy(ix->image + hd.off_c_occ, cocc.data(), cocc.size() * sizeof(COcc), hipMemcpyHostToDevice));
     CHK2(hipMemcpy(ix->image + hd.off_lkt, h->lkt, (uint64_t)h->lkt_n * 4, hipMemcpyHostToDevice));
@@ -156,7 +168,8 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     CHK2(hipMemcpy(d_r_sa, h->r_sa, (uint64_t)h->r_n_sa * 4, hipMemcpyHostToDevice));
     launch_build_c_sa(ix->view, d_sa_s, h->c_sa_intv, reinterpret_cast<uint32_t *>(ix->image + hd.off_c_sa), nullptr);
     launch_build_r_pos(ix->view, d_r_sa, reinterpret_cast<uint32_t *>(ix->image + hd.off_r_pos), nullptr);
-    launch_build_r_lkt(ix->view, h->lkt_len, reinterpret_cast<uint2 *>(ix->image + hd.off_r_lkt), nullptr);
+    launch_build_r_lkt(ix->view, hd.r_lkt_len, reinterpret_cast<uint2 *>(ix->image + hd.off_r_lkt), nullptr);
+    launch_build_c_wlkt(ix->view, hd.r_lkt_len, reinterpret_cast<uint2 *>(ix->image + hd.off_c_wlkt), nullptr);
     CHK2(hipGetLastError());
     CHK2(hipDeviceSynchronize());
     hipFree(d_sa_s); hipFree(d_r_sa);
@@ -235,7 +248,7 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
 
 static int check_opt(const salt_gpu_index *ix, const salt_aln_opt_t *o, uint32_t max_len, uint32_t *spr_out)
 {
-    if (o->l_seed < (int32_t)ix->hdr.lkt_len) return fail(SALT_E_INVAL, "l_seed shorter than the lookup-table k-mer");
+    if (o->l_seed < (int32_t)ix->hdr.r_lkt_len) return fail(SALT_E_INVAL, "l_seed shorter than the device k-mer table (set SALT_GPU_LKT_LEN or pass l_seed at attach)");
     if (o->l_overlap <= 0) return fail(SALT_E_INVAL, "l_overlap must be positive (aln.c:223 sets it to l_seed when -r is absent)");
     if (o->max_locate == 0 || o->max_locate > SALT_MAX_LOCATE) return fail(SALT_E_INVAL, "max_locate (-m) must be in 1..1024");
     if (o->max_hits != SALT_MAX_HITS) return fail(SALT_E_INVAL, "max_hits is fixed at 5 (aln.h:133)");
@@ -311,6 +324,35 @@ extern "C" int salt_gpu_align_se(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uin
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(results, ws->d_results, (uint64_t)n_reads * sizeof(salt_result_t), hipMemcpyDeviceToHost, ws->stream));
     HIPCHK(hipStreamSynchronize(ws->stream));
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_index_replicate(salt_gpu_index_t *src, const int *devices, int n, salt_gpu_index_t **out)
+{
+    if (!src || !devices || !out || n < 1 || devices[0] != src->device) return fail(SALT_E_INVAL, "bad replicate arguments");
+    out[0] = src;
+    if (n == 1) return SALT_OK;
+    std::vector<void *> buf((size_t)n, nullptr);
+    std::vector<ncclComm_t> comm((size_t)n);
+    std::vector<hipStream_t> st((size_t)n, nullptr);
+    buf[0] = src->image;
+    for (int i = 1; i < n; ++i) { HIPCHK(hipSetDevice(devices[i])); HIPCHK(hipMalloc(&buf[i], src->bytes)); }
+    ncclResult_t rc = ncclCommInitAll(comm.data(), n, devices);
+    if (rc != ncclSuccess) return fail(SALT_E_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(rc));
+    for (int i = 0; i < n; ++i) { HIPCHK(hipSetDevice(devices[i])); HIPCHK(hipStreamCreate(&st[i])); }
+    ncclGroupStart();
+    for (int i = 0; i < n; ++i) {
+        rc = ncclBroadcast(buf[i], buf[i], src->bytes, ncclUint8, 0, comm[i], st[i]);
+        if (rc != ncclSuccess) { ncclGroupEnd(); return fail(SALT_E_HIP, std::string("ncclBroadcast: ") + ncclGetErrorString(rc)); }
+    }
+    rc = ncclGroupEnd();
+    if (rc != ncclSuccess) return fail(SALT_E_HIP, std::string("ncclGroupEnd: ") + ncclGetErrorString(rc));
+    for (int i = 0; i < n; ++i) { HIPCHK(hipSetDevice(devices[i])); HIPCHK(hipStreamSynchronize(st[i])); HIPCHK(hipStreamDestroy(st[i])); ncclCommDestroy(comm[i]); }
+    for (int i = 1; i < n; ++i) {
+        int r2 = salt_gpu_index_attach_image(buf[i], src->bytes, devices[i], &out[i]);
+        if (r2) return r2;
+        out[i]->owns = true;
+    }
     return SALT_OK;
 }
 

@@ -37,5 +37,6 @@ void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const 
 void launch_build_c_sa(const IndexView &ix, const uint32_t *sa_sampled, uint32_t sa_intv, uint32_t *out, hipStream_t st);
 void launch_build_r_pos(const IndexView &ix, const uint32_t *r_sa, uint32_t *out, hipStream_t st);
 void launch_build_r_lkt(const IndexView &ix, uint32_t len, uint2 *out, hipStream_t st);
+void launch_build_c_wlkt(const IndexView &ix, uint32_t len, uint2 *out, hipStream_t st);
 
 } // namespace salt

@@ -175,6 +175,7 @@ extern "C" salt_index_t *salt_index_load(const char *prefix_c, int rebuild_lkt)
     v.c_bwt = ix->c_bwt.data(); v.c_sa = ix->c_sa.data(); v.lkt = ix->lkt.data();
     v.r_bwt = ix->r_bwt.data(); v.r_occ = ix->r_occ.data(); v.r_major = ix->r_major.data(); v.r_sa = ix->r_sa.data();
     v.ref = ix->ref.data();
+    v.l_seed = ix->seed_len;
     return ix;
 }
 

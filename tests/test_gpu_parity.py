@@ -117,3 +117,22 @@ def test_gpu_verify_and_lv_units_match_reference_vectors():
             got = "".join("%d%s" % (int(x) >> 4, "MID"[int(x) & 3]) for x in cig[i, :int(out[i, 3])])
             assert got == ctext, ("cigar", i, got, ctext)
     assert n_lane > 1000
+
+
+def test_cli_salt_matches_reference_golden(tmp_path):
+    """The C++ drop-in CLI (salt_amd/bin/salt) on an index written by salt_amd/bin/salt-idx: SAM stream
+    identical to the reference's for the same command line (the dated @PG line excluded)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt, salt_idx = os.path.join(root, "salt_amd", "bin", "salt"), os.path.join(root, "salt_amd", "bin", "salt-idx")
+    if not (os.path.exists(salt) and os.path.exists(salt_idx)):
+        subprocess.run(["make", "-C", os.path.join(root, "salt_amd", "host")], check=True, stdout=subprocess.DEVNULL)
+    prefix = str(tmp_path / "idx")
+    subprocess.run([salt_idx, "-k", "19", os.path.join(LAMBDA, "genome.fa"), os.path.join(LAMBDA, "snps.txt"), prefix],
+                   check=True, stderr=subprocess.DEVNULL)
+    for case, extra in (("se_default", []), ("se_r1_m500", ["--gpus", "1", "-t", "4"])):
+        args = read_cases()[case]
+        out = subprocess.run([salt] + args + extra + [prefix, os.path.join(LAMBDA, "reads_se.fq")], check=True,
+                             capture_output=True).stdout
+        got = b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+        want = open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
+        assert got == want, case
