@@ -154,15 +154,15 @@ struct LvTables { short L[LVK][64]; char A[LVK][64]; };
 static constexpr int LLV_K = 12;                 // handles k <= 12 (reads up to 129 bp at k = L/10)
 static constexpr int LLV_TW = 18;                // words per lane: up to 133 text nibbles (+1 pad word)
 static constexpr int LLV_W = 2 * LLV_K + 3;      // diagonals -k-1 .. k+1
-struct LaneLv { uint32_t T[64 * LLV_TW]; uint8_t rows[2][LLV_W][64]; };
-struct WaveLds {
+static constexpr int LLV_N = 32;                 // candidates per round (lanes 0..31)
+struct LaneLv { uint32_t T[LLV_N * LLV_TW]; uint8_t rows[2][LLV_W][LLV_N]; };
+struct LvBytes { uint8_t T[MAXL + 4 + 64]; uint8_t P[MAXL + 64]; };
+struct WaveLds {                                 // ~10.7 KB: 14-15 one-wave blocks per CU
     uint8_t  seq[2][MAXL];
     uint32_t pm[2][MAXL / 8];
-    union { SaiLists sai; LvTables lv; LaneLv llv; } u;
+    union { SaiLists sai; LaneLv llv; LvBytes lvb; } u;     // seeds | lane-LV scratch | wave-LV byte strings
     uint8_t  cand_e[MAXLOC];
     uint32_t loci[MAXLOC];
-    uint8_t  lvT[MAXL + 4 + 64];
-    uint8_t  lvP[MAXL + 64];
     uint32_t hit_pos[2][NHIT];
     uint8_t  hit_nd[2][NHIT], hit_gap[2][NHIT];
     uint16_t cig[SALT_MAX_CIGAR_OPS];
@@ -529,7 +529,7 @@ __device__ __attribute__((noinline)) int lv_wave(const uint8_t *T, int tlen, con
 // diagonal order, so all lanes walk the (e, d) cells in the same order.
 __device__ __attribute__((noinline)) uint32_t lv_lanes(LaneLv &s, const uint32_t *pm, int plen, int tlen, int k, bool active)
 {
-    const int lane = (int)lane_id();
+    const int lane = (int)lane_id() & (LLV_N - 1);      // callers pass active = false for lanes >= LLV_N
     const uint32_t *T = s.T + lane * LLV_TW;
     auto nT = [&](int i) -> uint32_t { return (i >= 0 && i < tlen) ? (T[i >> 3] >> (4 * (i & 7))) & 15u : 0u; };
     auto nP = [&](int i) -> uint32_t { return i < plen ? (pm[i >> 3] >> (4 * (i & 7))) & 15u : 0u; };
@@ -573,22 +573,24 @@ __device__ void lv_unpack(const uint32_t *ref_generic, WaveLds &w, int strand, u
     const uint32_t tlen = L + 4;
     for (uint32_t i = lane_id(); i < tlen + 48; i += 64) {
         uint32_t p = pos + i;
-        w.lvT[i] = i < tlen ? (uint8_t)((ref[p >> 3] >> (4 * (p & 7u))) & 15u) : (uint8_t)0;
+        w.u.lvb.T[i] = i < tlen ? (uint8_t)((ref[p >> 3] >> (4 * (p & 7u))) & 15u) : (uint8_t)0;
     }
     for (uint32_t i = lane_id(); i < L + 48; i += 64) {
         uint8_t c = i < L ? w.seq[strand][i] : (uint8_t)5;
-        w.lvP[i] = c > 4 ? (uint8_t)0 : (c > 3 ? (uint8_t)15 : (uint8_t)(1u << c));
+        w.u.lvb.P[i] = c > 4 ? (uint8_t)0 : (c > 3 ? (uint8_t)15 : (uint8_t)(1u << c));
     }
     WSYNC();
 }
 
 // CIGAR of a gapped hit into w.cig / w.n_cig (computeEditDistanceWithCigar, useM=1) ------------------
-__device__ __attribute__((noinline)) void lv_cigar(const uint32_t *ref, WaveLds &w, int strand, uint32_t L, uint32_t pos, int k)
+__device__ __attribute__((noinline)) void lv_cigar(const uint32_t *ref, WaveLds &w, LvTables *tabp, int strand, uint32_t L, uint32_t pos, int k)
 {
+    LvTables &tab = *tabp;                  // per-block table in global memory (L2-resident, rare path)
     lv_unpack(ref, w, strand, L, pos);
     int d_fin = 0;
     WSYNC();
-    int e = lv_wave(w.lvT, (int)L + 4, w.lvP, (int)L, k, &w.u.lv, d_fin);
+    int e = lv_wave(w.u.lvb.T, (int)L + 4, w.u.lvb.P, (int)L, k, &tab, d_fin);
+    __threadfence_block();
     WSYNC();
     if (lane_id() == 0) {
         int n = 0;
@@ -598,14 +600,14 @@ __device__ __attribute__((noinline)) void lv_cigar(const uint32_t *ref, WaveLds 
             char act[LVK + 1]; int matched[LVK + 1];
             int cd = d_fin;
             for (int ce = e; ce >= 1; --ce) {
-                char a = w.u.lv.A[ce][cd + 31];
+                char a = tab.A[ce][cd + 31];
                 act[ce] = a;
-                int cur = w.u.lv.L[ce][cd + 31];
-                if (a == 'I') { matched[ce] = cur - w.u.lv.L[ce - 1][cd + 1 + 31] - 1; cd += 1; }
-                else if (a == 'D') { matched[ce] = cur - w.u.lv.L[ce - 1][cd - 1 + 31]; cd -= 1; }
-                else { matched[ce] = cur - w.u.lv.L[ce - 1][cd + 31] - 1; }
+                int cur = tab.L[ce][cd + 31];
+                if (a == 'I') { matched[ce] = cur - tab.L[ce - 1][cd + 1 + 31] - 1; cd += 1; }
+                else if (a == 'D') { matched[ce] = cur - tab.L[ce - 1][cd - 1 + 31]; cd -= 1; }
+                else { matched[ce] = cur - tab.L[ce - 1][cd + 31] - 1; }
             }
-            int acc = w.u.lv.L[0][31];
+            int acc = tab.L[0][31];
             int ce = 1;
             while (ce <= e) {
                 char a = act[ce]; int cnt = 1;
@@ -629,11 +631,24 @@ __device__ __attribute__((noinline)) void lv_cigar(const uint32_t *ref, WaveLds 
 // ---------------------------------------------------------------------------------------------
 // k_align
 // ---------------------------------------------------------------------------------------------
+// Reads whose gapped pass would run Landau-Vishkin over hundreds of candidates are the kernel's tail: one
+// wave would spend milliseconds on them.  k_heavy (MODE 0) therefore only queues such a read; k_gap
+// (MODE 1) computes the candidates' distances with one wave per (read, strand, 32 candidates), and
+// k_gapfin (MODE 2) replays the sequential rule over the stored distances and writes the result.
+struct GapCtx {
+    uint32_t *gq;        // queued read indices
+    uint32_t *gctl;      // [2] = number queued
+    uint8_t  *ge;        // [slot][strand][MAXLOC] distances (255 = more than L/10)
+    uint32_t cap, slot, strand, chunk;
+};
+static constexpr uint32_t GAP_DEFER_MIN = 128;    // candidates (both strands) from which the gapped pass is deferred
+
+template <int MODE>
 __device__ __forceinline__ void align_general(const IndexView ix, const AlignParams ap, WaveLds &w, const uint32_t r,
                               const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
                               const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r,
                               salt_result_t *__restrict__ results, unsigned long long *__restrict__ ctr,
-                              unsigned long long *phase)
+                              unsigned long long *phase, LvTables *lvtab, const GapCtx g)
 {
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -687,7 +702,8 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     bool found[2] = { false, false };
     uint32_t n_hits_s[2] = { 0, 0 };            // hits recorded (<= NHIT) per strand
     uint32_t a0[2] = { 0, 0 };                  // n_diff of the first hit of each list
-    if (!too_short)
+    uint32_t n_cand_nogap = 0;
+    if (MODE == 0 && !too_short)
     for (int strand = 0; strand < 2; ++strand) {
         pc.stamp(SALT_CTR_T_SCAN);
         const CandStats cs = build_candidates(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase }, w);
@@ -737,7 +753,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             }
             (void)m3;
         }
-        c_verify += n_cand;
+        c_verify += n_cand; n_cand_nogap += n_cand;
         for (uint32_t b = lane; b < n_cand; b += 64) c_vwords += ((w.loci[b] & 7u) + L + 7) >> 3;
         if (found[strand]) { q_pos = call_best_pos; q_ndiff = call_best_n; q_gap = 0; q_strand = (uint32_t)strand; }
         WSYNC();
@@ -747,7 +763,15 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     // ---- gapped pass (alnse.c:1089-1096): sequential per candidate, LV across lanes ----
     if (!too_short && !found[0] && !found[1]) {
         int maxd = (int)(L / 10);
+        const bool lanes_fit = (int)(L / 10) <= LLV_K && L + 4 <= 8u * (LLV_TW - 1);
+        if (MODE == 0 && lanes_fit && g.cap && n_cand_nogap >= GAP_DEFER_MIN) {
+            uint32_t slot = 0;
+            if (lane == 0) slot = atomicAdd(&g.gctl[2], 1u);
+            slot = (uint32_t)__shfl((int)slot, 0);
+            if (slot < g.cap) { if (lane == 0) g.gq[slot] = r; return; }      // k_gap / k_gapfin take it from here
+        }
         for (int strand = 0; strand < 2; ++strand) {
+            if (MODE == 1 && strand != (int)g.strand) continue;
             pc.stamp(SALT_CTR_T_GAP);
             const CandStats cs = build_candidates(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase }, w);
             pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
@@ -755,14 +779,18 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             bool any = false;
             // all candidates' distances at the call's initial bound, 64 at a time (one per lane); the
             // sequential rule below then only compares numbers
-            const bool lanes_ok = (int)(L / 10) <= LLV_K && L + 4 <= 8u * (LLV_TW - 1);
-            if (lanes_ok) {
+            const bool lanes_ok = lanes_fit;
+            uint8_t *ge = (MODE != 0) ? g.ge + ((size_t)g.slot * 2 + (uint32_t)strand) * MAXLOC : nullptr;
+            if (MODE == 2) {                                          // distances were computed by k_gap
+                for (uint32_t i = lane; i < n_cand; i += 64) w.cand_e[i] = ge[i];
+                WSYNC();
+            } else if (lanes_ok) {
                 const int k0 = (int)(L / 10);
-                for (uint32_t b = 0; b < n_cand; b += 64) {
+                for (uint32_t b = (MODE == 1 ? g.chunk * LLV_N : 0u); b < (MODE == 1 ? (g.chunk + 1) * LLV_N : n_cand) && b < n_cand; b += LLV_N) {
                     WSYNC();
                     const uint32_t i = b + lane;
                     bool act = false;
-                    if (i < n_cand) {
+                    if (lane < LLV_N && i < n_cand) {
                         const uint32_t pos = w.loci[i];
                         act = !(pos > ix.ref_len || pos + L + 4 > ix.ref_len);           // ed_diff guard (editdistance.c:178)
                         if (act) {
@@ -782,10 +810,11 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                         }
                     }
                     const uint32_t e = lv_lanes(w.u.llv, w.pm[strand], (int)L, (int)L + 4, k0, act);
-                    if (i < n_cand) w.cand_e[i] = (uint8_t)e;
+                    if (lane < LLV_N && i < n_cand) { if (MODE == 1) ge[i] = (uint8_t)e; else w.cand_e[i] = (uint8_t)e; }
                 }
                 WSYNC();
             }
+            if (MODE == 1) return;                                    // this item's 32 distances are stored
             for (uint32_t i = 0; i < n_cand; ++i) {
                 uint32_t pos = w.loci[i];
                 int e = -1;
@@ -793,7 +822,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                 else if (!(pos > ix.ref_len || pos + L + 4 > ix.ref_len)) {   // ed_diff guard (editdistance.c:178)
                     lv_unpack(ix.ref, w, strand, L, pos);
                     int dd;
-                    e = lv_wave(w.lvT, (int)L + 4, w.lvP, (int)L, maxd, nullptr, dd);
+                    e = lv_wave(w.u.lvb.T, (int)L + 4, w.u.lvb.P, (int)L, maxd, nullptr, dd);
                     WSYNC();
                 }
                 ++c_lv;
@@ -852,7 +881,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     // ---- CIGARs (query_gen_cigar query.c:282-296; XA cigars sam.c:216-225) ----
     if (q_pos != 0xFFFFFFFFu) {
         if (q_gap) {
-            lv_cigar(ix.ref, w, (int)q_strand, L, q_pos, (int)q_ndiff);
+            lv_cigar(ix.ref, w, lvtab, (int)q_strand, L, q_pos, (int)q_ndiff);
             if (lane < (uint32_t)w.n_cig) out->cigar[lane] = w.cig[lane];
             if (lane == 0) out->n_cigar = (uint8_t)w.n_cig;
         } else if (lane == 0) { out->cigar[0] = (uint16_t)((L << 4) | 0u); out->n_cigar = 1; }
@@ -863,7 +892,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             uint32_t h = sel_idx[s][j];
             if (w.hit_gap[s][h]) {
                 WSYNC();
-                lv_cigar(ix.ref, w, s, L, w.hit_pos[s][h], (int)w.hit_nd[s][h]);
+                lv_cigar(ix.ref, w, lvtab, s, L, w.hit_pos[s][h], (int)w.hit_nd[s][h]);
                 if (lane < (uint32_t)w.n_cig) out->hit_cigar[hidx][lane] = w.cig[lane];
                 if (lane == 0) out->hit_n_cigar[hidx] = (uint8_t)w.n_cig;
             } else if (lane == 0) out->hit_n_cigar[hidx] = 0;
@@ -883,12 +912,17 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_heavy: persistent waves pull the reads k_light could not finish from a queue
+// k_heavy / k_gap / k_gapfin: persistent waves pull work items from counters in qctl[]
+//   qctl[0] reads queued by k_light      qctl[1] k_heavy head
+//   qctl[2] reads queued for k_gap       qctl[3] k_gap head      qctl[4] k_gapfin head
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-k_heavy(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
-        const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
-        const uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl, unsigned long long *__restrict__ ctr)
+template <int MODE>
+__device__ __forceinline__ void persistent_body(const IndexView &ix, const AlignParams &ap, const uint8_t *__restrict__ seqs,
+                                                const uint32_t *__restrict__ offs, const uint4 *__restrict__ sai_c,
+                                                const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
+                                                const uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl,
+                                                unsigned long long *__restrict__ ctr, LvTables *__restrict__ lvtab,
+                                                uint32_t *__restrict__ gq, uint8_t *__restrict__ ge, uint32_t gcap)
 {
     __shared__ WaveLds w;
     __shared__ uint32_t s_item;
@@ -896,15 +930,23 @@ k_heavy(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
     unsigned long long *phase = ctr ? s_phase : nullptr;
     if (ctr) { for (int i = threadIdx.x; i < SALT_CTR_N; i += 64) s_phase[i] = 0; }
     WSYNC();
-    const uint32_t n_items = ap.all_heavy ? ap.n_reads : qctl[0];       // qctl[0]: reads queued by k_light
+    uint32_t n_items;
+    if (MODE == 0) n_items = ap.all_heavy ? ap.n_reads : qctl[0];
+    else { uint32_t ng = qctl[2] < gcap ? qctl[2] : gcap; n_items = MODE == 1 ? ng * 2u * (MAXLOC / LLV_N) : ng; }
+    uint32_t *head = qctl + (MODE == 0 ? 1 : MODE == 1 ? 3 : 4);
     for (;;) {                                                           // every wave leaves once the head passes n_items
-        if (threadIdx.x == 0) s_item = atomicAdd(&qctl[1], 1u);
+        if (threadIdx.x == 0) s_item = atomicAdd(head, 1u);
         WSYNC();
         const uint32_t it = s_item;
         WSYNC();
         if (it >= n_items) break;
-        align_general(ix, ap, w, ap.all_heavy ? it : queue[it], seqs, offs, sai_c, sai_r, results, ctr, phase);
-        if (phase && threadIdx.x == 0) s_phase[SALT_CTR_HEAVY_READS] += 1;
+        GapCtx g{ gq, qctl, ge, gcap, 0, 0, 0 };
+        uint32_t r;
+        if (MODE == 0) r = ap.all_heavy ? it : queue[it];
+        else if (MODE == 1) { const uint32_t per = 2u * (MAXLOC / LLV_N); g.slot = it / per; g.strand = (it % per) / (MAXLOC / LLV_N); g.chunk = it % (MAXLOC / LLV_N); r = gq[g.slot]; }
+        else { g.slot = it; r = gq[it]; }
+        align_general<MODE>(ix, ap, w, r, seqs, offs, sai_c, sai_r, results, MODE == 1 ? nullptr : ctr, MODE == 1 ? nullptr : phase, lvtab + blockIdx.x, g);
+        if (MODE == 0 && phase && threadIdx.x == 0) s_phase[SALT_CTR_HEAVY_READS] += 1;
         WSYNC();
     }
     if (phase) {                                                         // one flush per wave
@@ -912,6 +954,17 @@ k_heavy(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
         for (int i = SALT_CTR_T_LOAD + (int)threadIdx.x; i < SALT_CTR_N; i += 64) if (s_phase[i]) atomicAdd(ctr + i, s_phase[i]);
     }
 }
+
+#define PERSISTENT_KERNEL(NAME, MODE)                                                                                   \
+__global__ void __launch_bounds__(64)                                                                                   \
+NAME(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,                  \
+     const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,             \
+     const uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl, unsigned long long *__restrict__ ctr,             \
+     LvTables *__restrict__ lvtab, uint32_t *__restrict__ gq, uint8_t *__restrict__ ge, uint32_t gcap)                   \
+{ persistent_body<MODE>(ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, lvtab, gq, ge, gcap); }
+PERSISTENT_KERNEL(k_heavy, 0)
+PERSISTENT_KERNEL(k_gap, 1)
+PERSISTENT_KERNEL(k_gapfin, 2)
 
 // ---------------------------------------------------------------------------------------------
 // k_light: one wave per read, the common case in three memory round trips.
@@ -1161,7 +1214,7 @@ void launch_light(const IndexView &ix, const AlignParams &ap, const uint8_t *seq
 __global__ void __launch_bounds__(64)
 k_diag_lv(IndexView ix, uint32_t n_cases, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ kdiff,
           const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs, int32_t *__restrict__ out /* [n][4] */,
-          uint16_t *__restrict__ cig_out /* [n][64] */)
+          uint16_t *__restrict__ cig_out /* [n][64] */, LvTables *__restrict__ lvtab)
 {
     __shared__ WaveLds w;
     const uint32_t c = blockIdx.x, lane = lane_id();
@@ -1186,12 +1239,12 @@ k_diag_lv(IndexView ix, uint32_t n_cases, const uint32_t *__restrict__ pos, cons
     if (in_range) {
         lv_unpack(ix.ref, w, 0, L, p);
         int dd;
-        e_wave = lv_wave(w.lvT, (int)L + 4, w.lvP, (int)L, k, nullptr, dd);
+        e_wave = lv_wave(w.u.lvb.T, (int)L + 4, w.u.lvb.P, (int)L, k, nullptr, dd);
         WSYNC();
         if (k <= LLV_K && L + 4 <= 8u * (LLV_TW - 1)) {
             const uint32_t tl = L + 4, w0 = p >> 3, sh = (p & 7u) * 4u, nwt = (tl + 7) >> 3;
             uint32_t lo = ix.ref[w0];
-            for (uint32_t j = 0; j < LLV_TW; ++j) {                    // every lane stages the same window
+            for (uint32_t j = 0; j < LLV_TW && lane < LLV_N; ++j) {    // every lane stages the same window
                 uint32_t word = 0;
                 if (j < nwt) {
                     const uint32_t hi = ix.ref[w0 + j + 1];
@@ -1202,12 +1255,13 @@ k_diag_lv(IndexView ix, uint32_t n_cases, const uint32_t *__restrict__ pos, cons
                 }
                 w.u.llv.T[lane * LLV_TW + j] = word;
             }
-            uint32_t el = lv_lanes(w.u.llv, w.pm[0], (int)L, (int)L + 4, k, true);
+            uint32_t el = lv_lanes(w.u.llv, w.pm[0], (int)L, (int)L + 4, k, lane < LLV_N);
+            el = (uint32_t)__shfl((int)el, 0);
             e_lane = el == 255 ? -1 : (int32_t)el;
             WSYNC();
         }
         if (e_wave >= 0 && e_wave < LVK) {
-            lv_cigar(ix.ref, w, 0, L, p, e_wave);
+            lv_cigar(ix.ref, w, lvtab + blockIdx.x, 0, L, p, e_wave);
             n_cig = w.n_cig;
             if (lane < (uint32_t)w.n_cig) cig_out[(size_t)c * SALT_MAX_CIGAR_OPS + lane] = w.cig[lane];
         }
@@ -1215,10 +1269,12 @@ k_diag_lv(IndexView ix, uint32_t n_cases, const uint32_t *__restrict__ pos, cons
     if (lane == 0) { out[c * 4 + 0] = v; out[c * 4 + 1] = e_wave; out[c * 4 + 2] = e_lane; out[c * 4 + 3] = n_cig; }
 }
 
+size_t lv_table_bytes() { return sizeof(LvTables); }
+
 void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const uint32_t *kdiff, const uint8_t *seqs,
-                    const uint32_t *offs, int32_t *out, uint16_t *cig, hipStream_t st)
+                    const uint32_t *offs, int32_t *out, uint16_t *cig, void *lvtab, hipStream_t st)
 {
-    if (n) hipLaunchKernelGGL(k_diag_lv, dim3(n), dim3(64), 0, st, ix, n, pos, kdiff, seqs, offs, out, cig);
+    if (n) hipLaunchKernelGGL(k_diag_lv, dim3(n), dim3(64), 0, st, ix, n, pos, kdiff, seqs, offs, out, cig, static_cast<LvTables *>(lvtab));
 }
 
 uint32_t heavy_blocks_per_cu()
@@ -1234,11 +1290,18 @@ uint32_t heavy_blocks_per_cu()
 
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, uint32_t *qctl, unsigned long long *ctr,
-                  uint32_t n_blocks, hipStream_t st)
+                  uint32_t n_blocks, void *lvtab, uint32_t *gq, uint8_t *ge, uint32_t gcap, hipStream_t st)
 {
     if (!ap.n_reads) return;
     uint32_t blocks = n_blocks < ap.n_reads ? n_blocks : ap.n_reads;
-    hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr);
+    LvTables *tab = static_cast<LvTables *>(lvtab);
+    hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap);
+    if (!gcap) return;
+    // the deferred gapped passes: distances by (read, strand, 32 candidates), then one finishing wave per read
+    hipLaunchKernelGGL(k_gap, dim3(n_blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap);
+    hipLaunchKernelGGL(k_gapfin, dim3(n_blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap);
 }
+
+size_t gap_e_bytes_per_read() { return 2u * MAXLOC; }
 
 } // namespace salt

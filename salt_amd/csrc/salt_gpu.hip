@@ -34,6 +34,8 @@ struct salt_gpu_ws {
     uint4 *d_sai_c = nullptr, *d_sai_r = nullptr; uint64_t sai_cap = 0;
     unsigned long long *d_ctr = nullptr;
     uint32_t *d_queue = nullptr, *d_qctl = nullptr;   // reads k_light hands to k_heavy; {count, head}
+    void *d_lvtab = nullptr;                          // one LV traceback table per persistent k_heavy block
+    uint32_t *d_gq = nullptr; uint8_t *d_ge = nullptr; uint32_t gcap = 0;   // deferred gapped passes
     uint32_t heavy_blocks = 2048;
     int all_heavy = 0;
     hipStream_t stream = nullptr;
@@ -220,11 +222,20 @@ extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint
     CHKW(hipMalloc((void **)&ws->d_results, (uint64_t)max_reads * sizeof(salt_result_t)));
     CHKW(hipMemset(ws->d_results, 0, (uint64_t)max_reads * sizeof(salt_result_t)));
     CHKW(hipMalloc((void **)&ws->d_queue, (uint64_t)max_reads * 4));
-    CHKW(hipMalloc((void **)&ws->d_qctl, 2 * 4));
+    CHKW(hipMalloc((void **)&ws->d_qctl, 8 * 4));
+    ws->gcap = max_reads < 8192 ? max_reads : 8192;
+    if (const char *e3 = getenv("SALT_GPU_NO_GAP_DEFER")) if (atoi(e3)) ws->gcap = 0;
+    if (ws->gcap) {
+        CHKW(hipMalloc((void **)&ws->d_gq, (uint64_t)ws->gcap * 4));
+        CHKW(hipMalloc((void **)&ws->d_ge, (uint64_t)ws->gcap * gap_e_bytes_per_read()));
+    }
     {
         hipDeviceProp_t prop;
         CHKW(hipGetDeviceProperties(&prop, ix->device));
-        ws->heavy_blocks = (uint32_t)prop.multiProcessorCount * heavy_blocks_per_cu();   // persistent waves (LDS-bound)
+        uint32_t per_cu = heavy_blocks_per_cu();                           // what LDS / VGPRs admit
+        if (const char *e2 = getenv("SALT_GPU_HEAVY_PER_CU")) { int v = atoi(e2); if (v > 0 && (uint32_t)v < per_cu) per_cu = (uint32_t)v; }
+        ws->heavy_blocks = (uint32_t)prop.multiProcessorCount * per_cu;    // persistent one-wave blocks
+        CHKW(hipMalloc(&ws->d_lvtab, (uint64_t)ws->heavy_blocks * lv_table_bytes()));
         const char *e = getenv("SALT_GPU_ALL_HEAVY");
         ws->all_heavy = e && atoi(e) != 0;
     }
@@ -240,7 +251,7 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
 {
     if (!ws) return;
     hipSetDevice(ws->ix->device);
-    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl);
+    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gq); hipFree(ws->d_ge);
     if (ws->stream) hipStreamDestroy(ws->stream);
     for (auto &e : ws->ev) if (e) hipEventDestroy(e);
     delete ws;
@@ -255,7 +266,7 @@ static int check_opt(const salt_gpu_index *ix, const salt_aln_opt_t *o, uint32_t
     if (max_len > SALT_MAX_READ_LEN) return fail(SALT_E_INVAL, "read longer than SALT_MAX_READ_LEN (512)");
     uint32_t spr = 1;
     if (max_len >= (uint32_t)o->l_seed) spr = (max_len - (uint32_t)o->l_seed) / (uint32_t)o->l_overlap + 1;
-    if (spr > SALT_MAX_SEED_SLOTS) return fail(SALT_E_INVAL, "more than 256 seeds per strand: raise -r or shorten the reads");
+    if (spr > SALT_MAX_SEED_SLOTS) return fail(SALT_E_INVAL, "more than 128 seeds per strand: raise -r or shorten the reads");
     *spr_out = spr;
     return SALT_OK;
 }
@@ -286,7 +297,7 @@ extern "C" int salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_
     unsigned long long *ctr = o->collect_counters ? ws->d_ctr : nullptr;
     const bool timed = ws->timing && ws->n_timed < MAX_TIMED;
     hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * 4] : nullptr;
-    HIPCHK(hipMemsetAsync(ws->d_qctl, 0, 8, st));
+    HIPCHK(hipMemsetAsync(ws->d_qctl, 0, 32, st));
     if (timed) HIPCHK(hipEventRecord(ev[0], st));
     launch_seed(ws->ix->view, sp, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r, ctr, st);
     if (timed) HIPCHK(hipEventRecord(ev[1], st));
@@ -295,7 +306,7 @@ extern "C" int salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_
                      static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, st);
     if (timed) HIPCHK(hipEventRecord(ev[2], st));
     launch_heavy(ws->ix->view, ap, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
-                 static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, ws->heavy_blocks, st);
+                 static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, ws->heavy_blocks, ws->d_lvtab, ws->d_gq, ws->d_ge, ws->gcap, st);
     if (timed) { HIPCHK(hipEventRecord(ev[3], st)); ++ws->n_timed; }
     HIPCHK(hipGetLastError());
     return SALT_OK;
@@ -417,12 +428,14 @@ extern "C" int salt_gpu_diag_lv(const uint32_t *ref_words, uint32_t ref_len, uin
     HIPCHK(hipMalloc((void **)&d_cig, (uint64_t)n_cases * SALT_MAX_CIGAR_OPS * 2)); HIPCHK(hipMemset(d_cig, 0, (uint64_t)n_cases * SALT_MAX_CIGAR_OPS * 2));
     IndexView v; memset(&v, 0, sizeof v);
     v.ref = d_ref; v.ref_len = ref_len;
-    launch_diag_lv(v, n_cases, d_pos, d_k, d_seqs, d_offs, d_out, d_cig, nullptr);
+    void *d_tab = nullptr;
+    HIPCHK(hipMalloc(&d_tab, (uint64_t)n_cases * lv_table_bytes()));
+    launch_diag_lv(v, n_cases, d_pos, d_k, d_seqs, d_offs, d_out, d_cig, d_tab, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out4, d_out, (uint64_t)n_cases * 16, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(cigars, d_cig, (uint64_t)n_cases * SALT_MAX_CIGAR_OPS * 2, hipMemcpyDeviceToHost));
-    hipFree(d_ref); hipFree(d_pos); hipFree(d_k); hipFree(d_offs); hipFree(d_seqs); hipFree(d_out); hipFree(d_cig);
+    hipFree(d_ref); hipFree(d_pos); hipFree(d_k); hipFree(d_offs); hipFree(d_seqs); hipFree(d_out); hipFree(d_cig); hipFree(d_tab);
     return SALT_OK;
 }
 
@@ -431,8 +444,8 @@ extern "C" int salt_gpu_ws_heavy_reads(salt_gpu_ws_t *ws, uint32_t *ids, uint32_
     if (!ws || !n) return fail(SALT_E_INVAL, "null argument");
     HIPCHK(hipSetDevice(ws->ix->device));
     HIPCHK(hipDeviceSynchronize());
-    uint32_t ctl[2];
-    HIPCHK(hipMemcpy(ctl, ws->d_qctl, 8, hipMemcpyDeviceToHost));
+    uint32_t ctl[8];
+    HIPCHK(hipMemcpy(ctl, ws->d_qctl, 32, hipMemcpyDeviceToHost));
     *n = ctl[0];
     if (ids && cap) HIPCHK(hipMemcpy(ids, ws->d_queue, (uint64_t)(ctl[0] < cap ? ctl[0] : cap) * 4, hipMemcpyDeviceToHost));
     return SALT_OK;

@@ -27,11 +27,13 @@ void launch_light(const IndexView &ix, const AlignParams &ap, const uint8_t *seq
                   const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, unsigned long long *ctr, hipStream_t st);
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, uint32_t *qctl, unsigned long long *ctr,
-                  uint32_t n_blocks, hipStream_t st);
+                  uint32_t n_blocks, void *lvtab, uint32_t *gq, uint8_t *ge, uint32_t gcap, hipStream_t st);
+size_t gap_e_bytes_per_read();
+size_t lv_table_bytes();                // per-block LV traceback table (global memory)
 
 uint32_t heavy_blocks_per_cu();
 void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const uint32_t *kdiff, const uint8_t *seqs,
-                    const uint32_t *offs, int32_t *out, uint16_t *cig, hipStream_t st);
+                    const uint32_t *offs, int32_t *out, uint16_t *cig, void *lvtab, hipStream_t st);
 
 // attach-time expansion kernels (salt_index.hip)
 void launch_build_c_sa(const IndexView &ix, const uint32_t *sa_sampled, uint32_t sa_intv, uint32_t *out, hipStream_t st);
