@@ -136,3 +136,95 @@ def test_cli_salt_matches_reference_golden(tmp_path):
         got = b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
         want = open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
         assert got == want, case
+
+
+def _oracle_compare(prefix, seqs, offs, optargs=()):
+    import sys
+    import salt_amd
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    idx = salt_amd.Index.reload(prefix)
+    opt, _ = salt_amd.AlnOpt.from_argv(list(optargs), idx.l_seed)
+    aln = salt_amd.GpuAligner(idx, device=0, max_reads=max(len(offs) - 1, 1), max_bases=max(int(offs[-1]), 1) + 64)
+    res = aln.alnse_core1(opt, seqs, offs)
+    aln.close()
+    ora = oracle_py.Oracle(prefix)
+    oo = ora.opt(l_overlap=opt.l_overlap, max_seed=opt.max_seed, max_locate=opt.max_locate, seed_only_ref=opt.seed_only_ref)
+    want = ora.align(oo, seqs, offs, n_threads=8)
+    ora.close()
+    idx.destroy()
+    return res, want, oracle_py.compare(res, want)
+
+
+def test_gpu_ragged_lengths_n_runs_and_extremes():
+    """Edge cases of the batch interface: read lengths from the seed length to 512 in one batch (k_light takes
+    <= 160, the rest go through the k_heavy queue and the diagonal-per-lane LV), reads full of N (> 200 N are
+    skipped like alnse.c:1328), a read of exactly the seed length, contig-end reads."""
+    import salt_amd
+    rng = np.random.default_rng(5)
+    from salt_amd import api
+    g = api.read_fastq  # noqa: F841
+    genome = []
+    with open(os.path.join(LAMBDA, "genome.fa")) as f:
+        cur = []
+        for line in f:
+            if line.startswith(">"):
+                if cur:
+                    genome.append("".join(cur))
+                cur = []
+            else:
+                cur.append(line.strip())
+        genome.append("".join(cur))
+    code = {"A": 0, "C": 1, "G": 2, "T": 3, "N": 4}
+    reads = []
+    lens = [19, 20, 36, 50, 75, 100, 101, 120, 121, 129, 130, 150, 160, 161, 200, 250, 300, 400, 512] * 12
+    for L in lens:
+        ci = int(rng.integers(0, 2)); s = genome[ci]
+        p = int(rng.integers(0, len(s) - L))
+        if rng.random() < 0.1:
+            p = len(s) - L                              # at the very end of a contig / the genome
+        r = np.array([code[c] for c in s[p:p + L]], dtype=np.uint8)
+        k = rng.random()
+        if k < 0.3:                                     # substitutions
+            for _ in range(int(rng.integers(1, 6))):
+                q = int(rng.integers(0, L)); r[q] = (r[q] + 1 + rng.integers(0, 3)) & 3 if r[q] < 4 else r[q]
+        elif k < 0.5 and L > 30:                        # an indel
+            q = int(rng.integers(10, L - 10))
+            r = np.concatenate([r[:q], r[q + 1:], r[-1:]]) if rng.random() < 0.5 else np.concatenate([r[:q], [rng.integers(0, 4)], r[q:-1]])
+        elif k < 0.6:
+            r[rng.integers(0, L, size=min(L, int(rng.integers(1, 12))))] = 4
+        if rng.random() < 0.5:
+            r = np.where(r[::-1] < 4, 3 - r[::-1], r[::-1])
+        reads.append(r.astype(np.uint8))
+    reads.append(np.full(300, 4, dtype=np.uint8))       # > 200 N: skipped
+    reads.append(np.concatenate([np.full(201, 4), np.zeros(99)]).astype(np.uint8))
+    reads.append(np.concatenate([np.full(200, 4), np.array([code[c] for c in genome[0][500:600]])]).astype(np.uint8))   # exactly 200 N: processed
+    offs = np.zeros(len(reads) + 1, dtype=np.uint32)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    seqs = np.concatenate(reads)
+    res, want, bad = _oracle_compare(os.path.join(LAMBDA, "idx"), seqs, offs)
+    assert len(bad) == 0, bad[:10]
+    assert res["skipped"][-3] == 1 and res["skipped"][-2] == 1 and res["skipped"][-1] == 0
+    # a one-read batch and a stride-1 seeding batch on short reads
+    res1, want1, bad1 = _oracle_compare(os.path.join(LAMBDA, "idx"), reads[5], np.array([0, len(reads[5])], dtype=np.uint32))
+    assert len(bad1) == 0
+    short = [r for r in reads if len(r) <= 120][:60]
+    so = np.zeros(len(short) + 1, dtype=np.uint32); so[1:] = np.cumsum([len(r) for r in short])
+    _, _, bad2 = _oracle_compare(os.path.join(LAMBDA, "idx"), np.concatenate(short), so, ["-r", "1", "-m", "500"])
+    assert len(bad2) == 0
+
+
+def test_gpu_rejects_what_it_cannot_do():
+    """Loud errors instead of silent fallbacks: -m above 1024, reads above 512 bp, too many seed slots."""
+    import salt_amd
+    idx = salt_amd.Index.reload(os.path.join(LAMBDA, "idx"))
+    aln = salt_amd.GpuAligner(idx, device=0, max_reads=8, max_bases=8192)
+    seq = np.zeros(600, dtype=np.uint8)
+    with pytest.raises(salt_amd.SaltError):
+        aln.alnse_core1(salt_amd.AlnOpt(l_seed=idx.l_seed), seq, np.array([0, 600], dtype=np.uint32))
+    with pytest.raises(salt_amd.SaltError):
+        aln.alnse_core1(salt_amd.AlnOpt(l_seed=idx.l_seed, max_locate=5000), seq[:100], np.array([0, 100], dtype=np.uint32))
+    with pytest.raises(salt_amd.SaltError):
+        aln.alnse_core1(salt_amd.AlnOpt(l_seed=idx.l_seed, l_overlap=1), seq[:300], np.array([0, 300], dtype=np.uint32))
+    aln.close()
+    idx.destroy()
