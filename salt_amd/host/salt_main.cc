@@ -31,7 +31,8 @@ const int N_SEQS = 100000;
 
 struct Batch {
     long seq_no = 0;
-    std::vector<std::string> name, qual;
+    std::vector<char> raw;                    // the FASTQ text; names and qualities are NUL-terminated in place
+    std::vector<uint32_t> name, qual;         // offsets into raw
     std::vector<uint8_t> seqs;
     std::vector<uint32_t> offs{ 0 };
     std::vector<salt_result_t> res;
@@ -45,41 +46,50 @@ inline uint8_t nt4(int c)
                  case 'T': case 't': return 3; default: return 4; }
 }
 
-bool gets_trim(gzFile fp, std::string &s, std::vector<char> &buf)
-{
-    s.clear();
-    for (;;) {
-        if (!gzgets(fp, buf.data(), (int)buf.size())) return !s.empty();
-        size_t n = strlen(buf.data());
-        bool eol = n && buf[n - 1] == '\n';
-        while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) --n;
-        s.append(buf.data(), n);
-        if (eol) return true;
+// Raw text of up to N_SEQS FASTQ records.  The reader thread only finds record boundaries (4 lines per
+// record, like the 4-line FASTQ the reference's test data uses); parsing runs on the worker threads.
+struct RawReader {
+    gzFile fp; std::vector<char> buf; size_t have = 0, pos = 0; bool eof = false;
+    explicit RawReader(gzFile f) : fp(f), buf(8u << 20) {}
+    bool fill()
+    {
+        if (eof) return false;
+        if (pos > 0) { memmove(buf.data(), buf.data() + pos, have - pos); have -= pos; pos = 0; }
+        if (have == buf.size()) buf.resize(buf.size() * 2);
+        int n = gzread(fp, buf.data() + have, (unsigned)(buf.size() - have));
+        if (n <= 0) { eof = true; return false; }
+        have += (size_t)n;
+        return true;
     }
-}
+    // appends whole records to out until n_rec records or end of file; returns records appended
+    int take(std::vector<char> &out, int n_rec)
+    {
+        int got = 0;
+        for (;;) {
+            size_t scan = pos; int lines = 0; size_t rec_end = pos;
+            while (got < n_rec) {
+                const char *nl = (const char *)memchr(buf.data() + scan, '\n', have - scan);
+                if (!nl) break;
+                scan = (size_t)(nl - buf.data()) + 1;
+                if (++lines == 4) { lines = 0; ++got; rec_end = scan; }
+            }
+            out.insert(out.end(), buf.begin() + (long)pos, buf.begin() + (long)rec_end);
+            pos = rec_end;
+            if (got >= n_rec) return got;
+            if (!fill()) {                                  // end of file: a last record without trailing newline
+                if (have > pos) {
+                    int nl = 0; for (size_t i = pos; i < have; ++i) nl += buf[i] == '\n';
+                    if (nl >= 3) { out.insert(out.end(), buf.begin() + (long)pos, buf.begin() + (long)have); out.push_back('\n'); ++got; }
+                    pos = have;
+                }
+                return got;
+            }
+        }
+    }
+};
 
-std::unique_ptr<Batch> read_batch(gzFile fp, long seq_no, std::vector<char> &buf)
-{
-    auto b = std::make_unique<Batch>();
-    b->seq_no = seq_no;
-    std::string line, seq, plus, qual;
-    while (b->n() < N_SEQS && gets_trim(fp, line, buf)) {
-        if (line.empty() || line[0] != '@') continue;
-        size_t e = 1;
-        while (e < line.size() && !isspace((unsigned char)line[e])) ++e;
-        std::string nm = line.substr(1, e - 1);
-        if (nm.size() > 2 && nm[nm.size() - 2] == '/' && isdigit((unsigned char)nm.back())) nm.resize(nm.size() - 2);   // query.c:139-143
-        if (!gets_trim(fp, seq, buf)) break;
-        if (!gets_trim(fp, plus, buf)) break;
-        if (!gets_trim(fp, qual, buf)) break;
-        if (seq.empty()) continue;
-        b->name.push_back(nm); b->qual.push_back(qual);
-        for (char c : seq) b->seqs.push_back(nt4((unsigned char)c));
-        b->offs.push_back((uint32_t)b->seqs.size());
-    }
-    if (b->n() == 0) return nullptr;
-    return b;
-}
+struct Batch;
+void parse_batch(std::vector<char> &raw, Batch &b, int n_threads);
 
 void format_batch(const salt_index_t *ix, const salt_sam_opt_t *so, Batch &b, int n_threads)
 {
@@ -95,8 +105,8 @@ void format_batch(const salt_index_t *ix, const salt_sam_opt_t *so, Batch &b, in
             for (int i = lo; i < hi; ++i) {
                 const int L = (int)(b.offs[i + 1] - b.offs[i]);
                 if ((size_t)L * 4 + 4096 > buf.size()) buf.resize((size_t)L * 4 + 4096);
-                int w = salt_sam_se(ix, so, b.name[i].c_str(), b.seqs.data() + b.offs[i], L, b.qual[i].c_str(), &b.res[i], buf.data(), buf.size());
-                if (w < 0) { fprintf(stderr, "[salt] SAM record too long for read %s\n", b.name[i].c_str()); exit(1); }
+                int w = salt_sam_se(ix, so, b.raw.data() + b.name[i], b.seqs.data() + b.offs[i], L, b.raw.data() + b.qual[i], &b.res[i], buf.data(), buf.size());
+                if (w < 0) { fprintf(stderr, "[salt] SAM record too long for read %s\n", b.raw.data() + b.name[i]); exit(1); }
                 out.append(buf.data(), (size_t)w);
                 out.push_back('\n');
             }
@@ -104,6 +114,63 @@ void format_batch(const salt_index_t *ix, const salt_sam_opt_t *so, Batch &b, in
     for (auto &t : th) t.join();
     b.sam.clear();
     for (auto &p : part) b.sam += p;
+}
+
+void parse_batch(std::vector<char> &raw, Batch &b, int n_threads)
+{
+    // line starts of every record (serial scan), then per-thread parsing of record ranges
+    std::vector<size_t> rec;                                   // offset of each record's '@' line
+    {
+        size_t p = 0; int lines = 0;
+        rec.push_back(0);
+        while (p < raw.size()) {
+            const char *nl = (const char *)memchr(raw.data() + p, '\n', raw.size() - p);
+            if (!nl) break;
+            p = (size_t)(nl - raw.data()) + 1;
+            if (++lines == 4) { lines = 0; if (p < raw.size()) rec.push_back(p); }
+        }
+    }
+    const int n = (int)rec.size();
+    b.name.assign((size_t)n, 0u); b.qual.assign((size_t)n, 0u);
+    std::vector<uint32_t> len((size_t)n, 0);
+    std::vector<std::pair<size_t, size_t>> seq_span((size_t)n);
+    auto line_end = [&](size_t p) { const char *nl = (const char *)memchr(raw.data() + p, '\n', raw.size() - p); size_t e = nl ? (size_t)(nl - raw.data()) : raw.size(); return e; };
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t)
+        th.emplace_back([&, t]() {
+            for (int i = (int)((long)n * t / n_threads); i < (int)((long)n * (t + 1) / n_threads); ++i) {
+                size_t p = rec[(size_t)i], e = line_end(p);
+                size_t ne = p + 1;
+                while (ne < e && !isspace((unsigned char)raw[ne])) ++ne;
+                size_t nl_ = ne - (p + 1);
+                if (nl_ > 2 && raw[ne - 2] == '/' && isdigit((unsigned char)raw[ne - 1])) ne -= 2;   // trim_readno (query.c:139-143)
+                b.name[(size_t)i] = (uint32_t)(p + 1);
+                const size_t name_end = ne;
+                size_t s0 = e + 1, s1 = line_end(s0);
+                size_t se = s1; while (se > s0 && raw[se - 1] == '\r') --se;
+                seq_span[(size_t)i] = { s0, se }; len[(size_t)i] = (uint32_t)(se - s0);
+                size_t p2 = s1 + 1, e2 = line_end(p2);           // '+' line
+                size_t q0 = e2 + 1, q1 = line_end(q0);
+                while (q1 > q0 && raw[q1 - 1] == '\r') --q1;
+                b.qual[(size_t)i] = (uint32_t)q0;
+                raw[name_end] = 0;                               // terminate in place (after every read of these lines)
+                if (q1 < raw.size()) raw[q1] = 0;
+            }
+        });
+    for (auto &t : th) t.join();
+    b.offs.assign((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) b.offs[(size_t)i + 1] = b.offs[(size_t)i] + len[(size_t)i];
+    b.seqs.resize(b.offs[(size_t)n]);
+    th.clear();
+    for (int t = 0; t < n_threads; ++t)
+        th.emplace_back([&, t]() {
+            for (int i = (int)((long)n * t / n_threads); i < (int)((long)n * (t + 1) / n_threads); ++i) {
+                uint8_t *d = b.seqs.data() + b.offs[(size_t)i];
+                const char *sp = raw.data() + seq_span[(size_t)i].first;
+                for (uint32_t j = 0; j < len[(size_t)i]; ++j) d[j] = nt4((unsigned char)sp[j]);
+            }
+        });
+    for (auto &t : th) t.join();
 }
 
 double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + ts.tv_nsec * 1e-9; }
@@ -177,9 +244,10 @@ int main(int argc, char **argv)
     std::vector<salt_gpu_index_t *> gix((size_t)n_gpus, nullptr);
     if (salt_gpu_index_attach(salt_index_host_view(ix), 0, &gix[0])) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
     if (salt_gpu_index_replicate(gix[0], devs.data(), n_gpus, gix.data())) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
-    std::vector<salt_gpu_ws_t *> ws((size_t)n_gpus, nullptr);
-    for (int i = 0; i < n_gpus; ++i)
-        if (salt_gpu_ws_create(gix[(size_t)i], N_SEQS, (uint64_t)N_SEQS * SALT_MAX_READ_LEN, &ws[(size_t)i])) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
+    const int WPG = 2;                                    // workers per GPU: one batch on the device while another is parsed / formatted
+    std::vector<salt_gpu_ws_t *> ws((size_t)n_gpus * WPG, nullptr);
+    for (int i = 0; i < n_gpus * WPG; ++i)
+        if (salt_gpu_ws_create(gix[(size_t)(i / WPG)], N_SEQS, (uint64_t)N_SEQS * SALT_MAX_READ_LEN, &ws[(size_t)i])) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
     fprintf(stderr, "%lf sec escaped.\n", now() - t0);
     t0 = now();
 
@@ -201,15 +269,22 @@ int main(int argc, char **argv)
     std::deque<std::unique_ptr<Batch>> todo;          // read, not yet aligned
     std::deque<std::unique_ptr<Batch>> done;          // aligned + formatted, any order
     bool eof = false; long n_tot = 0; std::atomic<bool> failed{ false };
-    const size_t max_inflight = (size_t)n_gpus * 2 + 1;
+    const size_t max_inflight = (size_t)n_gpus * WPG * 2 + 1;
     size_t inflight = 0;
 
+    std::atomic<double> t_parse{ 0 }, t_gpu{ 0 }, t_fmt{ 0 };
+    double t_write = 0, t_read = 0;
     std::thread reader([&]() {
-        std::vector<char> buf(1 << 16);
+        RawReader rr(fp);
         long seq_no = 0;
         for (;;) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return inflight < max_inflight || failed; }); if (failed) break; }
-            auto b = read_batch(fp, seq_no, buf);
+            auto b = std::make_unique<Batch>();
+            b->seq_no = seq_no;
+            b->raw.reserve((size_t)N_SEQS * 260);
+            double tr0 = now();
+            if (rr.take(b->raw, N_SEQS) == 0) b.reset();
+            t_read += now() - tr0;
             std::unique_lock<std::mutex> lk(mu);
             if (!b) { eof = true; cv.notify_all(); break; }
             ++seq_no; ++inflight;
@@ -218,8 +293,8 @@ int main(int argc, char **argv)
         }
     });
     std::vector<std::thread> workers;
-    const int fmt_threads = n_threads / n_gpus > 0 ? n_threads / n_gpus : 1;
-    for (int g = 0; g < n_gpus; ++g)
+    const int fmt_threads = n_threads / (n_gpus * WPG) > 0 ? n_threads / (n_gpus * WPG) : 1;
+    for (int g = 0; g < n_gpus * WPG; ++g)
         workers.emplace_back([&, g]() {
             for (;;) {
                 std::unique_ptr<Batch> b;
@@ -229,12 +304,21 @@ int main(int argc, char **argv)
                     if (failed || (todo.empty() && eof)) break;
                     b = std::move(todo.front()); todo.pop_front();
                 }
+                double tp0 = now();
+                parse_batch(b->raw, *b, fmt_threads);
+                t_parse = t_parse + (now() - tp0);
+                if (b->n() == 0) { std::unique_lock<std::mutex> lk(mu); done.push_back(std::move(b)); cv.notify_all(); continue; }
                 b->res.resize((size_t)b->n());
-                if (salt_gpu_align_se(ws[(size_t)g], &ao, (uint32_t)b->n(), b->seqs.data(), b->offs.data(), b->res.data())) {
+                double tg0 = now();
+                int grc = salt_gpu_align_se(ws[(size_t)g], &ao, (uint32_t)b->n(), b->seqs.data(), b->offs.data(), b->res.data());
+                t_gpu = t_gpu + (now() - tg0);
+                if (grc) {
                     fprintf(stderr, "[salt] %s\n", salt_gpu_last_error());
                     failed = true; cv.notify_all(); break;
                 }
+                double tf0 = now();
                 format_batch(ix, &so, *b, fmt_threads);
+                t_fmt = t_fmt + (now() - tf0);
                 std::unique_lock<std::mutex> lk(mu);
                 done.push_back(std::move(b));
                 cv.notify_all();
@@ -254,7 +338,9 @@ int main(int argc, char **argv)
             for (auto it = done.begin(); it != done.end(); ++it) if ((*it)->seq_no == next) { b = std::move(*it); done.erase(it); break; }
             if (!b) break;                                   // eof and nothing in flight
         }
+        double tw0 = now();
         fwrite(b->sam.data(), 1, b->sam.size(), stdout);
+        t_write += now() - tw0;
         n_tot += b->n(); ++next;
         fprintf(stderr, "%ld reads have been aligned!\n", n_tot);
         { std::unique_lock<std::mutex> lk(mu); --inflight; cv.notify_all(); }
@@ -264,9 +350,10 @@ int main(int argc, char **argv)
     fflush(stdout);
     double dt = now() - t0;
     fprintf(stderr, "[alnse_core]: total %lf sec escaped\n", dt);
+    fprintf(stderr, "[salt] host phases (s, summed over workers): read %.3f parse %.3f gpu-call %.3f format %.3f write %.3f\n", t_read, t_parse.load(), t_gpu.load(), t_fmt.load(), t_write);
     fprintf(stderr, "[salt] %ld reads, %.3f Mreads/s end to end (FASTQ -> SAM, %d GPU(s), %d host thread(s))\n", n_tot, dt > 0 ? n_tot / dt / 1e6 : 0.0, n_gpus, n_threads);
     gzclose(fp);
-    for (int i = 0; i < n_gpus; ++i) salt_gpu_ws_destroy(ws[(size_t)i]);
+    for (int i = 0; i < n_gpus * WPG; ++i) salt_gpu_ws_destroy(ws[(size_t)i]);
     for (int i = n_gpus - 1; i >= 0; --i) salt_gpu_index_detach(gix[(size_t)i]);
     salt_index_free(ix);
     return failed ? 1 : 0;
