@@ -1139,3 +1139,505 @@ int so_sam_se(const so_index_t *ix, const so_opt_t *o, const char *name, const u
     free(rseq);
     return s.ovf ? -1 : (int)s.l;
 }
+
+/* ========================================================================================== */
+/* Paired end (Align_src/alnpe.c, ssw.c, sam.c:331-457)                                        */
+/* ========================================================================================== */
+#include <time.h>
+
+/* L2: alnse_locate (alnse.c:501-629): per-interval cap, 0x40000 global cap, rand() subsampling of big R
+ * intervals (srand(time(0)) as there: outputs are only defined when no R interval exceeds max_locate) */
+static void locate_pe(const so_index_t *ix, const so_opt_t *o, uint32_t l_seq, so_aux_t *aux, so_counters_t *ctr)
+{
+    const uint32_t l_ref = ix->ref_len, MAX_LOC_POS = 0x40000u;
+    int i; uint32_t j;
+    aux->n_loci = 0;
+#define PUSH_LOCUS(p) do { if (aux->n_loci == aux->cap_loci) { aux->cap_loci = aux->cap_loci ? aux->cap_loci * 2 : 1024; \
+        aux->loci = realloc(aux->loci, 4 * (size_t)aux->cap_loci); } aux->loci[aux->n_loci++] = (p); } while (0)
+    for (i = 0; i < aux->n_c; ++i) {
+        const so_sai_t *c = aux->sai_c + i;
+        for (j = c->sp; j <= c->ep && j - c->sp <= o->max_locate; ++j) {
+            uint32_t pos = c_sa(ix, j, ctr) - c->offset;
+            if (pos + l_seq > l_ref) continue;
+            PUSH_LOCUS(pos);
+            if (aux->n_loci == MAX_LOC_POS) goto done;
+        }
+    }
+    srand((unsigned)time(0));
+    for (i = 0; i < aux->n_r; ++i) {
+        const so_sai_t *r = aux->sai_r + i;
+        if (r->ep - r->sp > o->max_locate) {
+            uint32_t range = (r->ep - r->sp) / o->max_locate, pick = (uint32_t)-1;
+            for (j = r->sp; j <= r->ep; ++j) {
+                uint32_t iter = j - r->sp;
+                if (iter % range == 0) pick = (uint32_t)rand() % range;
+                if (iter % range != pick) continue;
+                uint32_t pos = r_back_sa(ix, j, ctr) - r->offset;
+                if (pos > l_ref || pos + l_seq > l_ref) continue;
+                PUSH_LOCUS(pos);
+                if (aux->n_loci == MAX_LOC_POS) goto done;
+            }
+        } else {
+            for (j = r->sp; j <= r->ep; ++j) {
+                uint32_t pos = r_back_sa(ix, j, ctr) - r->offset;
+                if (pos > l_ref || pos + l_seq > l_ref) continue;
+                PUSH_LOCUS(pos);
+                if (aux->n_loci == MAX_LOC_POS) goto done;
+            }
+        }
+    }
+done:
+    qsort(aux->loci, aux->n_loci, 4, cmp_u32);
+    if (aux->n_loci > aux->cap_hits) { aux->hits = realloc(aux->hits, sizeof(so_hit_t) * (size_t)aux->n_loci); aux->cap_hits = aux->n_loci; }
+}
+
+/* one mate: alnse_overlap (alnse.c:985-1044): gap-free bound 3, gapped bound stays 3 */
+static void align_pe_mate(const so_index_t *ix, const so_opt_t *o, const uint8_t *seq, int l_seq, so_result_t *q,
+                          so_aux_t *aux[2], uint8_t *rseq, so_counters_t *ctr)
+{
+    int n_amb = 0, i, n0, n1, max_diff;
+    result_init(q, l_seq);
+    for (i = 0; i < l_seq; ++i) n_amb += seq[i] > 3;
+    if (n_amb > 5) return;                                     /* alnpe.c:481,495 */
+    revcomp(seq, l_seq, rseq);
+    int n_sai = l_seq - o->l_seed + 1;
+    for (i = 0; i < 2; ++i) {
+        aux_reserve(aux[i], n_sai > 1 ? n_sai : 1, 1024);
+        aux[i]->n_c = aux[i]->n_r = 0; aux[i]->n_loci = 0; aux[i]->n_hits = 0;
+    }
+    seed_overlap(ix, o, seq, l_seq, aux[0], ctr);
+    locate_pe(ix, o, (uint32_t)l_seq, aux[0], ctr);
+    seed_overlap(ix, o, rseq, l_seq, aux[1], ctr);
+    locate_pe(ix, o, (uint32_t)l_seq, aux[1], ctr);
+    max_diff = 3;
+    n0 = check_nogap(ix, q, seq, (uint32_t)l_seq, max_diff, 0, aux[0], ctr);
+    if (n0 != NO_MATCH && n0 < max_diff) max_diff = n0;
+    n1 = check_nogap(ix, q, rseq, (uint32_t)l_seq, max_diff, 1, aux[1], ctr);
+    if (n1 != NO_MATCH && n1 < max_diff) max_diff = n1;
+    if (n0 == NO_MATCH && n1 == NO_MATCH) {
+        int d0 = check_withgap(ix, q, seq, (uint32_t)l_seq, max_diff, 0, aux[0], ctr);
+        if (d0 != NO_MATCH && d0 < max_diff) max_diff = d0;
+        (void)check_withgap(ix, q, rseq, (uint32_t)l_seq, max_diff, 1, aux[1], ctr);
+    }
+    set_hits(q, o->max_hits, aux);
+}
+
+/* ---- SSW 0.1.4 word kernel, emulated lane by lane (ssw.c:347-547) ---- */
+typedef struct { int score, ref, read; } so_aend_t;
+static inline int16_t sat_adds16(int a, int b) { int v = a + b; return (int16_t)(v > 32767 ? 32767 : v < -32768 ? -32768 : v); }
+static inline int16_t sat_subu16(int16_t a, int b) { unsigned x = (uint16_t)a; return (int16_t)(uint16_t)(x > (unsigned)b ? x - (unsigned)b : 0); }
+static inline int16_t max16(int16_t a, int16_t b) { return a > b ? a : b; }
+
+static int16_t *ssw_profile(const int8_t *read, const int8_t *mat, int readLen, int n)        /* qP_word */
+{
+    int segLen = (readLen + 7) / 8, nt, i, seg;
+    int16_t *t0 = xcalloc((size_t)n * segLen * 8, 2), *t = t0;
+    for (nt = 0; nt < n; ++nt)
+        for (i = 0; i < segLen; ++i) {
+            int j = i;
+            for (seg = 0; seg < 8; ++seg) { *t++ = j >= readLen ? 0 : mat[nt * n + read[j]]; j += segLen; }
+        }
+    return t0;
+}
+
+static void ssw_word(const int8_t *ref, int ref_dir, int refLen, int readLen, int go, int ge, const int16_t *prof,
+                     uint16_t terminate, int maskLen, so_aend_t bests[2])
+{
+    int segLen = (readLen + 7) / 8, i, j, k, l, begin = 0, end = refLen, step = 1, edge;
+    uint16_t max = 0; int end_read = readLen - 1, end_ref = 0;
+    uint16_t *maxColumn = xcalloc((size_t)refLen, 2);
+    int16_t (*Hs)[8] = xcalloc((size_t)segLen, 16), (*Hl)[8] = xcalloc((size_t)segLen, 16), (*E)[8] = xcalloc((size_t)segLen, 16),
+            (*Hmax)[8] = xcalloc((size_t)segLen, 16);
+    int16_t vMaxScore[8] = { 0 }, vMaxMark[8] = { 0 };
+    if (ref_dir == 1) { begin = refLen - 1; end = -1; step = -1; }
+    for (i = begin; i != end; i += step) {
+        int16_t e[8], vF[8] = { 0 }, vH[8], vMaxColumn[8] = { 0 };
+        int16_t (*pv)[8];
+        const int16_t *vP = prof + (size_t)ref[i] * segLen * 8;
+        vH[0] = 0; for (l = 1; l < 8; ++l) vH[l] = Hs[segLen - 1][l - 1];
+        pv = Hl; Hl = Hs; Hs = pv;
+        for (j = 0; j < segLen; ++j) {
+            for (l = 0; l < 8; ++l) {
+                int16_t h = sat_adds16(vH[l], vP[j * 8 + l]);
+                e[l] = E[j][l];
+                h = max16(h, e[l]); h = max16(h, vF[l]);
+                vMaxColumn[l] = max16(vMaxColumn[l], h);
+                Hs[j][l] = h;
+                h = sat_subu16(h, go);
+                e[l] = sat_subu16(e[l], ge); e[l] = max16(e[l], h); E[j][l] = e[l];
+                vF[l] = sat_subu16(vF[l], ge); vF[l] = max16(vF[l], h);
+                vH[l] = Hl[j][l];
+            }
+        }
+        for (k = 0; k < 8; ++k) {                                   /* lazy F */
+            int16_t t7[8];
+            t7[0] = 0; for (l = 1; l < 8; ++l) t7[l] = vF[l - 1];
+            memcpy(vF, t7, sizeof vF);
+            for (j = 0; j < segLen; ++j) {
+                int any = 0;
+                for (l = 0; l < 8; ++l) {
+                    int16_t h = max16(Hs[j][l], vF[l]);
+                    Hs[j][l] = h;
+                    h = sat_subu16(h, go);
+                    vF[l] = sat_subu16(vF[l], ge);
+                    if (vF[l] > h) any = 1;
+                }
+                if (!any) goto lazy_done;
+            }
+        }
+lazy_done:
+        {
+            int diff = 0;
+            for (l = 0; l < 8; ++l) { vMaxScore[l] = max16(vMaxScore[l], vMaxColumn[l]); if (vMaxMark[l] != vMaxScore[l]) diff = 1; }
+            if (diff) {
+                uint16_t temp = 0; int16_t m = vMaxScore[0];
+                memcpy(vMaxMark, vMaxScore, sizeof vMaxMark);
+                for (l = 1; l < 8; ++l) m = max16(m, vMaxScore[l]);
+                temp = (uint16_t)m;
+                if (temp > max) { max = temp; end_ref = i; memcpy(Hmax, Hs, (size_t)segLen * 16); }
+            }
+        }
+        { int16_t m = vMaxColumn[0]; for (l = 1; l < 8; ++l) m = max16(m, vMaxColumn[l]); maxColumn[i] = (uint16_t)m; }
+        if (maxColumn[i] == terminate) break;
+    }
+    for (i = 0; i < segLen * 8; ++i) {
+        if ((uint16_t)Hmax[i / 8][i % 8] == max) { int temp = i / 8 + i % 8 * segLen; if (temp < end_read) end_read = temp; }
+    }
+    bests[0].score = max; bests[0].ref = end_ref; bests[0].read = end_read;
+    bests[1].score = 0; bests[1].ref = 0; bests[1].read = 0;
+    edge = (end_ref - maskLen) > 0 ? (end_ref - maskLen) : 0;
+    for (i = 0; i < edge; ++i) if (maxColumn[i] > bests[1].score) { bests[1].score = maxColumn[i]; bests[1].ref = i; }
+    edge = (end_ref + maskLen) > refLen ? refLen : (end_ref + maskLen);
+    for (i = edge; i < refLen; ++i) if (maxColumn[i] > bests[1].score) { bests[1].score = maxColumn[i]; bests[1].ref = i; }
+    free(maxColumn); free(Hs); free(Hl); free(E); free(Hmax);
+}
+
+/* banded_sw (ssw.c:549-727): returns ops (len<<4|op) in out, count as return value (0 on traceback error) */
+static int ssw_banded(const int8_t *ref, const int8_t *read, int refLen, int readLen, int score, int go, int ge, int band_width,
+                      const int8_t *mat, int n, uint32_t *out, int out_cap)
+{
+#define SET_U(u, w, i, j) { int x_ = (i) - (w); x_ = x_ > 0 ? x_ : 0; (u) = (j) - x_ + 1; }
+#define SET_D(u, w, i, j, p) { int x_ = (i) - (w); x_ = x_ > 0 ? x_ : 0; x_ = (j) - x_; (u) = x_ * 3 + p; }
+    int32_t i, j, e, f, temp1, temp2, l, max = 0, width, width_d;
+    int32_t *h_b = NULL, *e_b = NULL, *h_c = NULL; int8_t *direction = NULL, *direction_line;
+    uint32_t c[256];
+    do {
+        width = band_width * 2 + 3; width_d = band_width * 2 + 1;
+        free(h_b); free(e_b); free(h_c); free(direction);
+        h_b = xcalloc((size_t)width + 8, 4); e_b = xcalloc((size_t)width + 8, 4); h_c = xcalloc((size_t)width + 8, 4);
+        direction = xcalloc((size_t)width_d * readLen * 3 + 64, 1);
+        max = 0;                                                  /* the reference keeps max across retries: it only grows */
+        for (j = 1; j < width - 1; ++j) h_b[j] = 0;
+        for (i = 0; i < readLen; ++i) {
+            int32_t beg = 0, end = refLen - 1, u = 0, edge;
+            j = i - band_width; beg = beg > j ? beg : j;
+            j = i + band_width; end = end < j ? end : j;
+            edge = end + 1 < width - 1 ? end + 1 : width - 1;
+            f = h_b[0] = e_b[0] = h_b[edge] = e_b[edge] = h_c[0] = 0;
+            direction_line = direction + width_d * i * 3;
+            for (j = beg; j <= end; ++j) {
+                int32_t b, e1, f1, d, de, df, dh;
+                SET_U(u, band_width, i, j); SET_U(e, band_width, i - 1, j);
+                SET_U(b, band_width, i, j - 1); SET_U(d, band_width, i - 1, j - 1);
+                SET_D(de, band_width, i, j, 0); SET_D(df, band_width, i, j, 1); SET_D(dh, band_width, i, j, 2);
+                temp1 = i == 0 ? -go : h_b[e] - go;
+                temp2 = i == 0 ? -ge : e_b[e] - ge;
+                e_b[u] = temp1 > temp2 ? temp1 : temp2;
+                direction_line[de] = temp1 > temp2 ? 3 : 2;
+                temp1 = h_c[b] - go; temp2 = f - ge;
+                f = temp1 > temp2 ? temp1 : temp2;
+                direction_line[df] = temp1 > temp2 ? 5 : 4;
+                e1 = e_b[u] > 0 ? e_b[u] : 0; f1 = f > 0 ? f : 0;
+                temp1 = e1 > f1 ? e1 : f1;
+                temp2 = h_b[d] + mat[ref[j] * n + read[i]];
+                h_c[u] = temp1 > temp2 ? temp1 : temp2;
+                if (h_c[u] > max) max = h_c[u];
+                if (temp1 <= temp2) direction_line[dh] = 1;
+                else direction_line[dh] = e1 > f1 ? direction_line[de] : direction_line[df];
+            }
+            for (j = 1; j <= u; ++j) h_b[j] = h_c[j];
+        }
+        band_width *= 2;
+    } while (max < score);
+    band_width /= 2;
+    i = readLen - 1; j = refLen - 1; e = 0; l = 0; f = max = 0; temp2 = 2;
+    direction_line = direction + width_d * (readLen - 1) * 3;
+    while (i > 0) {
+        SET_D(temp1, band_width, i, j, temp2);
+        switch (direction_line[temp1]) {
+        case 1: --i; --j; temp2 = 2; direction_line -= width_d * 3; f = 0; break;
+        case 2: --i; temp2 = 0; direction_line -= width_d * 3; f = 1; break;
+        case 3: --i; temp2 = 2; direction_line -= width_d * 3; f = 1; break;
+        case 4: --j; temp2 = 1; f = 2; break;
+        case 5: --j; temp2 = 2; f = 2; break;
+        default: free(h_b); free(e_b); free(h_c); free(direction); return 0;
+        }
+        if (f == max) ++e;
+        else { ++l; if (l < 256) c[l - 1] = (uint32_t)e << 4 | (uint32_t)max; max = f; e = 1; }
+    }
+    if (f == 0) { ++l; if (l <= 256) c[l - 1] = (uint32_t)(e + 1) << 4; }
+    else { l += 2; if (l <= 256) { c[l - 2] = (uint32_t)e << 4 | (uint32_t)f; c[l - 1] = 16; } }
+    if (l > out_cap) l = out_cap;
+    for (i = 0; i < l; ++i) out[i] = c[l - 1 - i];
+    free(h_b); free(e_b); free(h_c); free(direction);
+    return l;
+}
+
+typedef struct { int score1, score2, ref_begin1, ref_end1, read_begin1, read_end1, n_cigar; uint32_t cigar[256]; } so_ssw_t;
+
+/* ssw_align with flag = 2, filters = 0 (ssw.c:771-856) */
+static void ssw_align2(const int8_t *read, int readLen, const int8_t *mat, int n, const int8_t *ref, int refLen, int go, int ge,
+                       int maskLen, so_ssw_t *r)
+{
+    so_aend_t b[2];
+    int16_t *prof = ssw_profile(read, mat, readLen, n);
+    memset(r, 0, sizeof *r); r->ref_begin1 = -1; r->read_begin1 = -1;
+    ssw_word(ref, 0, refLen, readLen, go, ge, prof, (uint16_t)-1, maskLen, b);
+    free(prof);
+    r->score1 = b[0].score; r->ref_end1 = b[0].ref; r->read_end1 = b[0].read;
+    if (maskLen >= 15) r->score2 = b[1].score; else r->score2 = 0;
+    {
+        int rl = r->read_end1 + 1, i;
+        int8_t *rev = xcalloc((size_t)rl + 1, 1);
+        for (i = 0; i < rl; ++i) rev[i] = read[r->read_end1 - i];
+        prof = ssw_profile(rev, mat, rl, n);
+        ssw_word(ref, 1, r->ref_end1 + 1, rl, go, ge, prof, (uint16_t)r->score1, maskLen, b);
+        free(prof); free(rev);
+        r->ref_begin1 = b[0].ref; r->read_begin1 = r->read_end1 - b[0].read;
+    }
+    {
+        int rfl = r->ref_end1 - r->ref_begin1 + 1, rdl = r->read_end1 - r->read_begin1 + 1;
+        int bw = abs(rfl - rdl) + 1;
+        r->n_cigar = ssw_banded(ref + r->ref_begin1, read + r->read_begin1, rfl, rdl, r->score1, go, ge, bw, mat, n, r->cigar, 256);
+    }
+}
+
+static const int8_t SCORE_MAT[25] = { 1, -3, -3, -3, -1,  -3, 1, -3, -3, -1,  -3, -3, 1, -3, -1,  -3, -3, -3, 1, -1,  -1, -1, -1, -1, -1 };
+static int8_t SCORE_MAT2[256 + 16];                           /* alnpe.c:58-73 (+16: the N read code indexes one row further) */
+static void score_mat2_init(void)
+{
+    static int done = 0; int r, c;
+    if (done) return;
+    for (r = 0; r < 16; ++r) for (c = 0; c < 16; ++c) {
+        int v = -3;
+        if (r == 1 && (c & 1)) v = 1;
+        if (r == 2 && (c & 2)) v = 1;
+        if (r == 4 && (c & 4)) v = 1;
+        if (r == 8 && (c & 8)) v = 1;
+        SCORE_MAT2[r * 16 + c] = (int8_t)v;
+    }
+    for (c = 0; c < 16; ++c) SCORE_MAT2[256 + c] = -3;         /* past the array in the reference: undefined there */
+    done = 1;
+}
+
+typedef struct { so_result_t r; const uint8_t *seq; uint8_t *rseq; int l_seq; } so_mate_t;
+
+/* snpaln_sw_snpaware / snpaln_sw (alnpe.c:261-393); aware: 4-bit ref + score_mat2, else 2-bit pac + score_mat */
+static int pe_sw(const so_index_t *ix, uint32_t start, uint32_t end, so_mate_t *m, int strand, int aware)
+{
+    const uint8_t *seq = strand ? m->rseq : m->seq;
+    int l_seq = m->l_seq, i, l_ref = (int)(end - start + 1), ok = 0;
+    so_ssw_t res;
+    if ((int64_t)start >= ix->l_pac) { fprintf(stderr, "[salt_oracle] SW window starts past the genome\n"); return 0; }
+    if (l_ref <= 0) return 0;
+    int8_t *ref = xcalloc((size_t)l_ref + 1, 1), *read = xcalloc((size_t)l_seq + 1, 1);
+    if (aware) {
+        score_mat2_init();
+        for (i = 0; i < l_ref; ++i) ref[i] = (int8_t)ref_nib(ix->ref, start + (uint32_t)i);
+        for (i = 0; i < l_seq; ++i) read[i] = (int8_t)(1 << seq[i]);
+        ssw_align2(read, l_seq, SCORE_MAT2, 16, ref, l_ref, 3, 1, l_seq / 2, &res);
+    } else {
+        for (i = 0; i < l_ref; ++i) ref[i] = (int8_t)pac_base(ix->pac, start + (uint32_t)i);
+        for (i = 0; i < l_seq; ++i) read[i] = (int8_t)seq[i];
+        ssw_align2(read, l_seq, SCORE_MAT, 5, ref, l_ref, 3, 1, l_seq / 2, &res);
+    }
+    if (res.score1 >= 0 && res.read_end1 - res.read_begin1 + 1 >= 20) {
+        so_result_t *q = &m->r; char *o = q->cigar; int cap = SO_CIGAR_MAX, j;
+        q->b0 = res.score1; q->b1 = res.score2; q->mapq = (uint8_t)gen_mapq((uint32_t)q->b0, (uint32_t)q->b1);
+        q->pos = (uint32_t)res.ref_begin1 + start; q->strand = strand;
+        q->seq_start = (uint32_t)res.read_begin1; q->seq_end = (uint32_t)res.read_end1;
+        q->cigar[0] = 0;
+        for (j = 0; j < res.n_cigar; ++j) {
+            int w = snprintf(o, (size_t)cap, "%u%c", res.cigar[j] >> 4, "MID"[res.cigar[j] & 15]);
+            if (w >= cap) break;
+            o += w; cap -= w;
+        }
+        ok = 1;
+    }
+    free(ref); free(read);
+    return ok;
+}
+
+static void pe_gen_cigar(const so_index_t *ix, so_mate_t *m) { gen_cigar(ix, &m->r, m->seq, m->rseq, m->l_seq); }
+
+static int in_range(uint32_t a, uint32_t b, uint32_t small, uint32_t large)        /* CHECK_IN_RANGE: -1 low, 0 in, 1 high */
+{
+    uint32_t r = a < b ? b - a : a - b;
+    if (a > b || r < small) return -1;
+    return r > large ? 1 : 0;
+}
+
+/* pairing2 (alnpe.c:94-258) */
+static void pairing2(const so_index_t *ix, so_mate_t *m0, so_mate_t *m1, uint32_t min_tlen, uint32_t max_tlen)
+{
+    so_result_t *q0 = &m0->r, *q1 = &m1->r;
+    uint32_t l2 = (uint32_t)(m0->l_seq + m1->l_seq);
+    uint32_t min_isize = min_tlen > l2 ? min_tlen - l2 : 0, max_isize = max_tlen > l2 ? max_tlen - l2 : 0;
+    uint32_t min_erros = (uint32_t)-1, l_pac = (uint32_t)ix->l_pac, start, end;
+    so_hit_t b0, b1; int pass;
+    memset(&b0, 0, sizeof b0); memset(&b1, 0, sizeof b1);
+    if (q0->strand == 0 && q1->strand == 1 && q0->pos < q1->pos) {
+        if (in_range(q0->pos + (uint32_t)m0->l_seq, q1->pos, min_isize, max_isize) == 0) { pe_gen_cigar(ix, m0); pe_gen_cigar(ix, m1); return; }
+    } else if (q1->strand == 0 && q0->strand == 1 && q1->pos < q0->pos) {
+        if (in_range(q1->pos + (uint32_t)m1->l_seq, q0->pos, min_isize, max_isize) == 0) { pe_gen_cigar(ix, m0); pe_gen_cigar(ix, m1); return; }
+    }
+    for (pass = 0; pass < 2; ++pass) {                          /* alternative hits only; `j == jj;` is a no-op there */
+        so_result_t *qf = pass == 0 ? q0 : q1, *qb = pass == 0 ? q1 : q0;
+        uint32_t nf = (uint32_t)qf->n_hits[0], nb = (uint32_t)qb->n_hits[1], lf = (uint32_t)(pass == 0 ? m0->l_seq : m1->l_seq), i, jj;
+        if (nf > SO_MAX_HITS) nf = SO_MAX_HITS;
+        if (nb > SO_MAX_HITS) nb = SO_MAX_HITS;
+        if (!(nf > 0 && nb > 0)) continue;
+        for (i = 0; i < nf; ++i)
+            for (jj = 0; jj < nb; ++jj) {
+                int rg = in_range(qf->hits[0][i].pos + lf, qb->hits[1][jj].pos, min_isize, max_isize);
+                if (rg == 0) {
+                    uint32_t e = (uint32_t)qf->hits[0][i].n_diff + qb->hits[1][jj].n_diff;
+                    if (e < min_erros) { min_erros = e; if (pass == 0) { b0 = qf->hits[0][i]; b1 = qb->hits[1][jj]; } else { b1 = qf->hits[0][i]; b0 = qb->hits[1][jj]; } }
+                } else if (rg == 1) break;
+            }
+    }
+    if (min_erros != (uint32_t)-1) {
+        q0->pos = b0.pos; q0->strand = b0.strand; q0->n_diff = b0.n_diff; q0->is_gap = b0.is_gap;
+        q1->pos = b1.pos; q1->strand = b1.strand; q1->n_diff = b1.n_diff; q1->is_gap = b1.is_gap;
+        pe_gen_cigar(ix, m0); pe_gen_cigar(ix, m1);
+        return;
+    }
+    /* mate rescue by SNP-aware SW, q0 then q1 as the anchor */
+    if (q0->strand == 0) {
+        start = q0->pos + min_isize + (uint32_t)m0->l_seq; end = q0->pos + max_isize + (uint32_t)m0->l_seq + (uint32_t)m1->l_seq; end = end >= l_pac ? l_pac : end;
+        if (pe_sw(ix, start, end, m1, 1, 1)) { pe_gen_cigar(ix, m0); return; }
+    } else {
+        start = q0->pos > max_isize + (uint32_t)m1->l_seq ? q0->pos - max_isize - (uint32_t)m1->l_seq : 0;
+        end = q0->pos > min_isize ? q0->pos - min_isize : 0; end = end >= l_pac ? l_pac : end;
+        if (pe_sw(ix, start, end, m1, 0, 1)) { pe_gen_cigar(ix, m0); return; }
+    }
+    if (q1->strand == 0) {
+        start = q1->pos + min_isize + (uint32_t)m1->l_seq; end = q1->pos + max_isize + (uint32_t)m1->l_seq + (uint32_t)m0->l_seq; end = end >= l_pac ? l_pac : end;
+        if (pe_sw(ix, start, end, m0, 1, 1)) { pe_gen_cigar(ix, m1); return; }
+    } else {
+        start = q1->pos > max_isize + (uint32_t)m0->l_seq ? q1->pos - max_isize - (uint32_t)m0->l_seq : 0;
+        end = q1->pos > min_isize ? q1->pos - min_isize : 0; end = end >= l_pac ? l_pac : end;
+        if (pe_sw(ix, start, end, m0, 0, 1)) { pe_gen_cigar(ix, m1); return; }
+    }
+    if (q0->pos != 0xFFFFFFFFu) pe_gen_cigar(ix, m0);
+    if (q1->pos != 0xFFFFFFFFu) pe_gen_cigar(ix, m1);
+}
+
+/* pairing_singleton (alnpe.c:395-480) */
+static void pairing_singleton(const so_index_t *ix, so_mate_t *m0, so_mate_t *m1, uint32_t min_tlen, uint32_t max_tlen)
+{
+    so_result_t *q0 = &m0->r, *q1 = &m1->r;
+    uint32_t l2 = (uint32_t)(m0->l_seq + m1->l_seq), lim = (uint32_t)ix->l_pac - 1, start, end;
+    uint32_t min_isize = min_tlen > l2 ? min_tlen - l2 : 0, max_isize = max_tlen > l2 ? max_tlen - l2 : 0;
+#define UMIN(a, b) ((a) < (b) ? (a) : (b))
+    if (q0->pos != 0xFFFFFFFFu) {
+        if (q0->strand == 0) {
+            start = UMIN(q0->pos + min_isize + (uint32_t)m0->l_seq, lim); end = UMIN(q0->pos + max_isize + (uint32_t)m0->l_seq + (uint32_t)m1->l_seq, lim);
+            if (pe_sw(ix, start, end, m1, 1, 0)) { pe_gen_cigar(ix, m0); return; }
+        } else {
+            start = q0->pos > max_isize + (uint32_t)m1->l_seq ? q0->pos - max_isize - (uint32_t)m1->l_seq : 0; start = UMIN(start, lim);
+            end = q0->pos > min_isize ? q0->pos - min_isize : 0; end = UMIN(end, lim);
+            if (pe_sw(ix, start, end, m1, 0, 0)) { pe_gen_cigar(ix, m0); return; }
+        }
+    }
+    if (q1->pos != 0xFFFFFFFFu) {
+        if (q1->strand == 0) {
+            start = UMIN(q1->pos + min_isize + (uint32_t)m1->l_seq, lim); end = UMIN(q1->pos + max_isize + (uint32_t)m1->l_seq + (uint32_t)m0->l_seq, lim);
+            if (pe_sw(ix, start, end, m0, 1, 0)) { pe_gen_cigar(ix, m1); return; }
+        } else {
+            start = q1->pos > max_isize + (uint32_t)m0->l_seq ? q1->pos - max_isize - (uint32_t)m0->l_seq : 0; start = UMIN(start, lim);
+            end = q1->pos > min_isize ? q1->pos - min_isize : 0; end = UMIN(end, lim);
+            if (pe_sw(ix, start, end, m0, 0, 0)) { pe_gen_cigar(ix, m1); return; }
+        }
+    }
+    if (q0->pos != 0xFFFFFFFFu) pe_gen_cigar(ix, m0);
+    if (q1->pos != 0xFFFFFFFFu) pe_gen_cigar(ix, m1);
+}
+
+/* alnpe_core1 for one pair (alnpe.c:482-528) */
+void so_align_pe1(const so_index_t *ix, const so_opt_t *o, uint32_t min_tlen, uint32_t max_tlen, const uint8_t *seq0, int l0,
+                  const uint8_t *seq1, int l1, so_result_t res[2])
+{
+    so_aux_t a0, a1, *aux[2] = { &a0, &a1 };
+    so_mate_t m[2];
+    int k;
+    memset(&a0, 0, sizeof a0); memset(&a1, 0, sizeof a1);
+    m[0].seq = seq0; m[0].l_seq = l0; m[1].seq = seq1; m[1].l_seq = l1;
+    for (k = 0; k < 2; ++k) {
+        m[k].rseq = xcalloc((size_t)m[k].l_seq + 1, 1);
+        revcomp(m[k].seq, m[k].l_seq, m[k].rseq);
+        align_pe_mate(ix, o, m[k].seq, m[k].l_seq, &m[k].r, aux, m[k].rseq, NULL);
+    }
+    if (m[0].r.pos != 0xFFFFFFFFu && m[1].r.pos != 0xFFFFFFFFu) pairing2(ix, &m[0], &m[1], min_tlen, max_tlen);
+    else if (m[0].r.pos != 0xFFFFFFFFu || m[1].r.pos != 0xFFFFFFFFu) pairing_singleton(ix, &m[0], &m[1], min_tlen, max_tlen);
+    res[0] = m[0].r; res[1] = m[1].r;
+    free(m[0].rseq); free(m[1].rseq); aux_free(&a0); aux_free(&a1);
+}
+
+/* alnpe_sam (sam.c:331-457): both records of a pair, each followed by '\n' (the driver's printf adds another) */
+int so_sam_pe(const so_index_t *ix, const so_opt_t *o, uint32_t min_tlen, uint32_t max_tlen, const char *const name[2],
+              const uint8_t *const seq[2], const int l_seq[2], const char *const qual[2], const so_result_t q[2], char *buf, size_t cap)
+{
+    so_str_t s = { buf, 0, cap, 0 };
+    int rid[2] = { -1, -1 }, is_map[2] = { 0, 0 }, i, j, tlen = 0;
+    uint32_t pos[2] = { 0, 0 };
+    for (i = 0; i < 2; ++i) if (q[i].pos != 0xFFFFFFFFu) { is_map[i] = 1; rid[i] = coor_rid(ix, q[i].pos); pos[i] = q[i].pos - (uint32_t)ix->anns[rid[i]].offset + 1; }
+    if (is_map[0] && is_map[1]) {
+        if (rid[0] != rid[1]) tlen = 0;
+        else if (pos[0] < pos[1]) tlen = (int)(pos[1] + q[1].seq_end - q[1].seq_start + 1 - pos[0]);
+        else tlen = (int)(pos[0] + q[0].seq_end - q[1].seq_start + 1 - pos[1]);            /* sam.c:355-356 uses q[1].seq_start twice */
+        if ((uint32_t)tlen > max_tlen || (uint32_t)tlen < min_tlen) tlen = 0;
+    }
+    for (i = 0; i < 2; ++i) {
+        unsigned flag = 0x1;
+        uint8_t *rseq = xcalloc((size_t)l_seq[i] + 1, 1);
+        revcomp(seq[i], l_seq[i], rseq);
+        sput(&s, "%s\t", name[i]);
+        if (!is_map[i]) flag |= 0x4;
+        if (!is_map[1 - i]) flag |= 0x8;
+        if (q[i].strand == 1) flag |= 0x10;
+        if (q[1 - i].strand == 1) flag |= 0x20;
+        if (tlen != 0) flag |= 0x2;
+        flag |= i == 0 ? 0x40 : 0x80;
+        sput(&s, "%u\t", flag);
+        if (is_map[i]) {
+            sput(&s, "%s\t%lu\t%u\t", ix->anns[rid[i]].name, (unsigned long)pos[i], (unsigned)q[i].mapq);
+            if (q[i].seq_start != 0) sput(&s, "%dS", (int)q[i].seq_start);
+            sput(&s, "%s", q[i].cigar);
+            if (q[i].seq_end != (uint32_t)l_seq[i] - 1) sput(&s, "%dS", l_seq[i] - (int)q[i].seq_end - 1);
+            sput(&s, "\t");
+        } else if (is_map[1 - i]) sput(&s, "%s\t%lu\t255\t*\t", ix->anns[rid[1 - i]].name, (unsigned long)pos[1 - i]);
+        else sput(&s, "*\t0\t255\t*\t");
+        if (is_map[1 - i]) {
+            if (rid[i] == rid[1 - i] || is_map[i] != 1) sput(&s, "=\t"); else sput(&s, "%s\t", ix->anns[rid[1 - i]].name);
+            sput(&s, "%lu\t", (unsigned long)pos[1 - i]);
+        } else sput(&s, "*\t0\t");
+        if (tlen != 0) { if (q[i].pos >= q[1 - i].pos) sput(&s, "-%d\t", tlen); else sput(&s, "%d\t", tlen); }
+        else sput(&s, "0\t");
+        if (q[i].strand == 1) {
+            for (j = 0; j < l_seq[i]; ++j) sput(&s, "%c", "ACGTN"[rseq[j]]);
+            sput(&s, "\t");
+            if (qual[i] && qual[i][0]) for (j = l_seq[i] - 1; j >= 0; --j) sput(&s, "%c", qual[i][j]); else sput(&s, "*");
+        } else {
+            for (j = 0; j < l_seq[i]; ++j) sput(&s, "%c", "ACGTN"[seq[i][j]]);
+            sput(&s, "\t");
+            if (qual[i] && qual[i][0]) sput(&s, "%s", qual[i]); else sput(&s, "*");
+        }
+        sam_xa(&s, ix, o, seq[i], rseq, l_seq[i], &q[i]);
+        if (o->print_nm_md && q[i].pos != 0xFFFFFFFFu) sam_md_nm(&s, ix, q[i].strand == 0 ? seq[i] : rseq, l_seq[i], &q[i]);
+        if (o->rg_id) sput(&s, "\tRG:Z:%s", o->rg_id);
+        sput(&s, "\n\n");
+        free(rseq);
+    }
+    return s.ovf ? -1 : (int)s.l;
+}

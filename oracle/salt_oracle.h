@@ -82,6 +82,13 @@ int so_sam_se(const so_index_t *, const so_opt_t *, const char *name, const uint
 /* header without the @PG line (sam.c:56-84) */
 int so_sam_header(const so_index_t *, const so_opt_t *, char *buf, size_t cap);
 
+/* paired end: one pair through alnpe_core1 (alnpe.c:482-528); res[0], res[1] = the two mates.
+ * so_sam_pe writes both records, each followed by the empty line the reference prints (sam.c:450, alnpe.c:620). */
+void so_align_pe1(const so_index_t *, const so_opt_t *, uint32_t min_tlen, uint32_t max_tlen, const uint8_t *seq0, int l0,
+                  const uint8_t *seq1, int l1, so_result_t res[2]);
+int so_sam_pe(const so_index_t *, const so_opt_t *, uint32_t min_tlen, uint32_t max_tlen, const char *const name[2],
+              const uint8_t *const seq[2], const int l_seq[2], const char *const qual[2], const so_result_t q[2], char *buf, size_t cap);
+
 /* unit entry points for the golden vectors (editdistance.c:88,174,234) */
 int so_ed_mismatch(const uint32_t *mixref, uint32_t pos, const uint8_t *seq, uint32_t L, int max_err);
 int so_ed_diff(const uint32_t *mixref, uint32_t l_mref, uint32_t pos, uint32_t l_ref,

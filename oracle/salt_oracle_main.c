@@ -31,7 +31,7 @@ static char *gets_trim(gzFile fp, char *buf, int cap)
 
 int main(int argc, char **argv)
 {
-    int c, n_threads = 1, overlap = -1, quiet_sam = 0;
+    int c, n_threads = 1, overlap = -1, quiet_sam = 0, pe = 0; unsigned min_tlen = 250, max_tlen = 550;   /* aln.c:43-44 */
     so_opt_t o; memset(&o, 0, sizeof o);
     uint32_t max_seed = 50, max_locate = 1000; int only_ref = 0, xa = 0, md = 0; const char *rg = NULL;
     while ((c = getopt(argc, argv, "t:n:hpa:b:g:em:s:l:cdr:vM:O:E:X:q")) >= 0) {
@@ -45,17 +45,50 @@ int main(int argc, char **argv)
         case 'v': only_ref = 1; break;
         case 'r': overlap = atoi(optarg); break;
         case 'q': quiet_sam = 1; break;   /* timing only */
-        case 'p': fprintf(stderr, "[salt_oracle] paired-end is not restated yet\n"); return 1;
+        case 'p': pe = 1; break;
+        case 'a': min_tlen = (unsigned)atoi(optarg); break;
+        case 'b': max_tlen = (unsigned)atoi(optarg); break;
         default: break;                    /* -n -e -l -a -b -M -O -E -X parsed and ignored (aln.c:189-197) */
         }
     }
-    if (optind + 2 > argc) { fprintf(stderr, "usage: salt_oracle [opts] <idx> <reads.fq>\n"); return 1; }
+    if (optind + 2 + pe > argc) { fprintf(stderr, "usage: salt_oracle [opts] <idx> <reads.fq> [mates.fq]\n"); return 1; }
     so_index_t *ix = so_index_load(argv[optind]);
     if (!ix) return 1;
     so_opt_default(ix, &o);
     o.max_seed = max_seed; o.max_locate = max_locate; o.seed_only_ref = only_ref; o.print_xa_cigar = xa;
     o.print_nm_md = md; o.rg_id = rg;
     if (overlap > 0) o.l_overlap = overlap;
+    if (pe) {                                                   /* alnpe_core (alnpe.c:530-661), one pair at a time */
+        gzFile f1 = gzopen(argv[optind + 1], "r"), f2 = gzopen(argv[optind + 2], "r");
+        if (!f1 || !f2) { fprintf(stderr, "[salt_oracle] cannot open read files\n"); return 1; }
+        static char l1[1 << 16], l2[1 << 16];
+        char *hdr = malloc(1 << 20), *sam = malloc(1 << 17);
+        if (so_sam_header(ix, &o, hdr, 1 << 20) < 0) return 1;
+        fputs(hdr, stdout);
+        for (;;) {
+            char *nm[2]; char *ql[2]; uint8_t *sq[2]; int ln[2]; gzFile ff[2] = { f1, f2 }; char *lb[2] = { l1, l2 }; int k, okp = 1;
+            for (k = 0; k < 2 && okp; ++k) {
+                if (!gets_trim(ff[k], lb[k], 1 << 16)) { okp = 0; break; }
+                char *p = lb[k] + 1, *q = p; while (*q && !isspace((unsigned char)*q)) ++q; *q = 0;
+                size_t n = strlen(p);
+                if (n > 2 && p[n - 2] == '/' && isdigit((unsigned char)p[n - 1])) p[n - 2] = 0;
+                nm[k] = strdup(p);
+                if (!gets_trim(ff[k], lb[k], 1 << 16)) { okp = 0; break; }
+                ln[k] = (int)strlen(lb[k]); sq[k] = malloc((size_t)ln[k] + 1);
+                for (int i = 0; i < ln[k]; ++i) sq[k][i] = nt4(lb[k][i]);
+                if (!gets_trim(ff[k], lb[k], 1 << 16) || !gets_trim(ff[k], lb[k], 1 << 16)) { okp = 0; break; }
+                ql[k] = strdup(lb[k]);
+            }
+            if (!okp) break;
+            so_result_t r2[2];
+            so_align_pe1(ix, &o, min_tlen, max_tlen, sq[0], ln[0], sq[1], ln[1], r2);
+            const char *cn[2] = { nm[0], nm[1] }, *cq[2] = { ql[0], ql[1] }; const uint8_t *cs[2] = { sq[0], sq[1] };
+            if (so_sam_pe(ix, &o, min_tlen, max_tlen, cn, cs, ln, cq, r2, sam, 1 << 17) < 0) return 1;
+            fputs(sam, stdout);
+            for (k = 0; k < 2; ++k) { free(nm[k]); free(ql[k]); free(sq[k]); }
+        }
+        return 0;
+    }
     gzFile fp = gzopen(argv[optind + 1], "r");
     if (!fp) { fprintf(stderr, "[salt_oracle] cannot open %s\n", argv[optind + 1]); return 1; }
     static char line[1 << 16];

@@ -58,3 +58,18 @@ def test_oracle_units_match_reference_vectors(oracle_lib):
                 assert (buf.value.decode() or "-") == cig
             n += 1
     assert n == 4000
+
+
+PE_CASES = [c for c in read_cases() if c.startswith("pe_")]
+
+
+@pytest.mark.parametrize("case", PE_CASES)
+def test_oracle_pe_sam_matches_reference(case, oracle_cli):
+    """Paired end: pairing2 / pairing_singleton / SSW mate rescue (emulated lane by lane) / alnpe_sam against the
+    SAM the real reference printed.  (The reference's PE locate calls rand() when an R interval exceeds max_locate;
+    this fixture has none, so its output is deterministic.)"""
+    args = read_cases()[case]
+    out = subprocess.run([oracle_cli] + args + [os.path.join(LAMBDA, "idx"), os.path.join(LAMBDA, "reads_pe_1.fq"),
+                                                os.path.join(LAMBDA, "reads_pe_2.fq")], check=True, capture_output=True).stdout
+    want = open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
+    assert out == want
