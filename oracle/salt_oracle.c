@@ -1641,3 +1641,19 @@ int so_sam_pe(const so_index_t *ix, const so_opt_t *o, uint32_t min_tlen, uint32
     }
     return s.ovf ? -1 : (int)s.l;
 }
+
+/* unit entry for tests/golden/ssw_vectors.txt: ssw_init + ssw_align as snpaln_sw[_snpaware] call them */
+int so_ssw_unit(int aware, const uint8_t *ref_syms, int refLen, const uint8_t *codes, int L, int out6[6], char *cigar, int cap)
+{
+    so_ssw_t res; int i, j; char *o = cigar;
+    int8_t *ref = xcalloc((size_t)refLen + 1, 1), *read = xcalloc((size_t)L + 1, 1);
+    score_mat2_init();
+    for (i = 0; i < refLen; ++i) ref[i] = (int8_t)ref_syms[i];
+    for (i = 0; i < L; ++i) read[i] = aware ? (int8_t)(1 << codes[i]) : (int8_t)codes[i];
+    ssw_align2(read, L, aware ? SCORE_MAT2 : SCORE_MAT, aware ? 16 : 5, ref, refLen, 3, 1, L / 2, &res);
+    out6[0] = res.score1; out6[1] = res.score2; out6[2] = res.ref_begin1; out6[3] = res.ref_end1; out6[4] = res.read_begin1; out6[5] = res.read_end1;
+    cigar[0] = 0;
+    for (j = 0; j < res.n_cigar; ++j) { int w = snprintf(o, (size_t)cap, "%u%c", res.cigar[j] >> 4, "MID"[res.cigar[j] & 15]); if (w >= cap) break; o += w; cap -= w; }
+    free(ref); free(read);
+    return res.n_cigar;
+}

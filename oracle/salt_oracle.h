@@ -89,6 +89,8 @@ void so_align_pe1(const so_index_t *, const so_opt_t *, uint32_t min_tlen, uint3
 int so_sam_pe(const so_index_t *, const so_opt_t *, uint32_t min_tlen, uint32_t max_tlen, const char *const name[2],
               const uint8_t *const seq[2], const int l_seq[2], const char *const qual[2], const so_result_t q[2], char *buf, size_t cap);
 
+int so_ssw_unit(int aware, const uint8_t *ref_syms, int refLen, const uint8_t *codes, int L, int out6[6], char *cigar, int cap);
+
 /* unit entry points for the golden vectors (editdistance.c:88,174,234) */
 int so_ed_mismatch(const uint32_t *mixref, uint32_t pos, const uint8_t *seq, uint32_t L, int max_err);
 int so_ed_diff(const uint32_t *mixref, uint32_t l_mref, uint32_t pos, uint32_t l_ref,

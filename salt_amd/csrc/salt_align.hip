@@ -261,6 +261,7 @@ struct CandStats { uint32_t n_cand, n_sa_c, n_sa_r, n_loci; };
 struct CandArgs {                      // everything by value: a by-reference IndexView would live in scratch memory
     const uint32_t *c_sa, *r_pos; const uint4 *sai_c, *sai_r;
     uint32_t ref_len, spr, max_locate, r, L; int strand; bool gap_mode; unsigned long long *phase;
+    uint32_t *loci; uint32_t loci_cap; int pe;
 };
 __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, WaveLds &w)
 {
@@ -271,6 +272,7 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
     struct { gp_u32 c_sa, r_pos; uint32_t ref_len; } ix = { as_global(a.c_sa), as_global(a.r_pos), a.ref_len };
     struct { uint32_t spr, max_locate; } ap = { a.spr, a.max_locate };
     uint32_t n_sa_c = 0, n_sa_r = 0, n_loci_out = 0;
+    uint32_t *const loci = a.loci;
     PhaseClock pc(a.phase);
     const uint64_t base_item = ((uint64_t)r * 2u + (uint32_t)strand) * ap.spr;
     uint32_t n_list[2] = { 0, 0 };
@@ -292,11 +294,15 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
     if (lane < 2) sai_introsort(w.u.sai, (int)lane, (int)n_list[lane]);      // alnse.c:307-308
     WSYNC();
     pc.stamp(SALT_CTR_T_GATHER);
-    // locate under the global cap (alnse_locate_alt, alnse.c:633-731)
+    // locate: SE under the global max_locate cap (alnse_locate_alt, alnse.c:633-731); PE with the per-interval cap
+    // and the 0x40000 global cap of alnse_locate (alnse.c:501-629; here bounded by the scratch capacity)
     uint32_t n = 0;
     bool full = false;
+    const uint32_t cap_total = a.pe ? a.loci_cap : ap.max_locate;
     for (uint32_t i = 0; i < n_list[0] && !full; ++i) {
-        const uint32_t sp = w.u.sai.sp[0][i], ep = w.u.sai.ep[0][i], off = w.u.sai.off[0][i];
+        const uint32_t sp = w.u.sai.sp[0][i], off = w.u.sai.off[0][i];
+        uint32_t ep = w.u.sai.ep[0][i];
+        if (a.pe && ep - sp > ap.max_locate) ep = sp + ap.max_locate;             // j - sp <= max_locate (alnse.c:523)
         for (uint64_t j0 = sp; j0 <= ep && !full; j0 += 64) {
             pc.add(SALT_CTR_X0, 1);
             uint64_t j = j0 + lane;
@@ -305,16 +311,16 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
             if (in) { pos = ix.c_sa[j] - off; keep = !(pos + L > ix.ref_len); }        // u32 wrap as in alnse.c:672-673
             uint64_t m = __ballot(keep);
             uint32_t rank = (uint32_t)__popcll(m & lt);
-            if (keep && n + rank < ap.max_locate) w.loci[n + rank] = pos;
+            if (keep && n + rank < cap_total) loci[n + rank] = pos;
             uint32_t tot = (uint32_t)__popcll(m);
-            if (n + tot >= ap.max_locate) {
+            if (n + tot >= cap_total) {
                 // lookups the sequential loop would have made before stopping
-                uint64_t last = m;                       // position of the max_locate-th kept lane
-                uint32_t need = ap.max_locate - n;       // >= 1
+                uint64_t last = m;                       // position of the cap_total-th kept lane
+                uint32_t need = cap_total - n;           // >= 1
                 for (uint32_t q = 1; q < need; ++q) last &= last - 1;
                 uint32_t stop_lane = (uint32_t)__ffsll((long long)last) - 1;
                 n_sa_c += stop_lane + 1;
-                n = ap.max_locate; full = true;
+                n = cap_total; full = true;
             } else { n += tot; n_sa_c += (uint32_t)__popcll(__ballot(in)); }
         }
     }
@@ -323,6 +329,9 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
         const uint32_t sp = w.u.sai.sp[1][i], ep = w.u.sai.ep[1][i], off = w.u.sai.off[1][i];
         uint32_t skip = (ep + 1 - sp) / 0x40000u;                                       // alnse.c:707-708
         if ((int)skip <= 0) skip = 1;
+        // PE: an interval wider than max_locate is subsampled with rand() in the reference (alnse.c:587-595), i.e. its
+        // result is not defined; the stand-in keeps the first row of every block of (ep-sp)/max_locate rows
+        if (a.pe) skip = ep - sp > ap.max_locate ? (ep - sp) / ap.max_locate : 1;
         for (uint64_t j0 = sp; j0 <= ep && !full; j0 += 64ull * skip) {
             pc.add(SALT_CTR_X1, 1);
             uint64_t j = j0 + (uint64_t)lane * skip;
@@ -331,20 +340,20 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
             if (in) { pos = ix.r_pos[j] - off; keep = !(pos > ix.ref_len || pos + L > ix.ref_len); }   // alnse.c:715-717
             uint64_t m = __ballot(keep);
             uint32_t rank = (uint32_t)__popcll(m & lt);
-            if (keep && n + rank < ap.max_locate) w.loci[n + rank] = pos;
+            if (keep && n + rank < cap_total) loci[n + rank] = pos;
             uint32_t tot = (uint32_t)__popcll(m);
-            if (n + tot >= ap.max_locate) {
-                uint64_t last = m; uint32_t need = ap.max_locate - n;
+            if (n + tot >= cap_total) {
+                uint64_t last = m; uint32_t need = cap_total - n;
                 for (uint32_t q = 1; q < need; ++q) last &= last - 1;
                 n_sa_r += (uint32_t)__ffsll((long long)last);
-                n = ap.max_locate; full = true;
+                n = cap_total; full = true;
             } else { n += tot; n_sa_r += (uint32_t)__popcll(__ballot(in)); }
         }
     }
     n_loci_out += n;
     WSYNC();
     pc.stamp(SALT_CTR_T_LOCATE);
-    sort_loci(w.loci, n);
+    sort_loci(loci, n);
     WSYNC();
     pc.stamp(SALT_CTR_T_SORT);
     // drop duplicates and out-of-range loci, keeping order (alnse.c:758-762 / 890-894)
@@ -353,14 +362,14 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
         uint32_t i = b + lane;
         bool keep = false; uint32_t pos = 0;
         if (i < n) {
-            pos = w.loci[i];
-            bool dup = i > 0 && w.loci[i - 1] == pos;
+            pos = loci[i];
+            bool dup = i > 0 && loci[i - 1] == pos;
             bool out = gap_mode ? (pos + L + 4 >= ix.ref_len) : (pos >= ix.ref_len);
             keep = !dup && !out;
         }
         uint64_t m = __ballot(keep);
         WSYNC();                                           // all reads of this chunk are done
-        if (keep) w.loci[n_out + (uint32_t)__popcll(m & lt)] = pos;
+        if (keep) loci[n_out + (uint32_t)__popcll(m & lt)] = pos;
         n_out += (uint32_t)__popcll(m);
         WSYNC();
     }
@@ -648,7 +657,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                               const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
                               const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r,
                               salt_result_t *__restrict__ results, unsigned long long *__restrict__ ctr,
-                              unsigned long long *phase, LvTables *lvtab, const GapCtx g)
+                              unsigned long long *phase, LvTables *lvtab, const GapCtx g, uint32_t *pe_loci, uint8_t *pe_cand)
 {
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -657,6 +666,9 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_lv = 0, c_loci = 0;
     PhaseClock pc(phase);
     const uint64_t rt0 = phase ? __builtin_amdgcn_s_memrealtime() : 0;
+    uint32_t *const loci = ap.pe ? pe_loci : w.loci;          // candidate loci: LDS, or global scratch for PE mates
+    uint8_t *const cand_e = ap.pe ? pe_cand : w.cand_e;
+    const uint32_t loci_cap = ap.pe ? PE_LOCI_CAP : (uint32_t)MAXLOC;
 
     // ---- load the read, both strands (query.c:177-183, 46-71) ----
     uint32_t n_amb = 0;
@@ -674,7 +686,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     // result defaults (query_read_seq, query.c:199-206)
     uint32_t q_pos = 0xFFFFFFFFu; uint32_t q_strand = 3, q_ndiff = 255, q_gap = 255;
     const bool too_short = L < (uint32_t)ap.l_seed;
-    if (n_amb > 200) {                                        // alnse.c:1328: record left untouched
+    if (n_amb > ap.max_amb) {                                 // alnse.c:1328 (200) / alnpe.c:495 (5): record left untouched
         if (lane == 0) {
             out->pos = q_pos; out->strand = 3; out->n_diff = 255; out->is_gap = 255; out->mapq = 0;
             out->b0 = -1; out->b1 = -1; out->seq_start = 0; out->seq_end = (uint16_t)(L - 1);
@@ -706,29 +718,29 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     if (MODE == 0 && !too_short)
     for (int strand = 0; strand < 2; ++strand) {
         pc.stamp(SALT_CTR_T_SCAN);
-        const CandStats cs = build_candidates(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase }, w);
+        const CandStats cs = build_candidates(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, loci, loci_cap, ap.pe }, w);
         pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
         const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
         uint32_t call_best_n = INF, call_best_pos = 0;
         // phase A: every candidate's distance, 4 per lane with all loads in flight
-        if (L <= 120) verify_quads(ix.ref, w.pm[strand], L, w.loci, n_cand, w.cand_e);
+        if (L <= 120) verify_quads(ix.ref, w.pm[strand], L, loci, n_cand, cand_e);
         else if (L <= 8 * 13) {
             for (uint32_t b = 0; b < n_cand; b += 256) {
                 uint32_t pp[4], vv[4]; bool aa[4];
                 const uint32_t *const pms[4] = { w.pm[strand], w.pm[strand], w.pm[strand], w.pm[strand] };
-                for (int u = 0; u < 4; ++u) { const uint32_t i = b + 64u * u + lane; aa[u] = i < n_cand; pp[u] = aa[u] ? w.loci[i] : 0u; }
+                for (int u = 0; u < 4; ++u) { const uint32_t i = b + 64u * u + lane; aa[u] = i < n_cand; pp[u] = aa[u] ? loci[i] : 0u; }
                 mismatch_batch<13, 4>(ix, pms, L, pp, aa, vv);
-                for (int u = 0; u < 4; ++u) { const uint32_t i = b + 64u * u + lane; if (i < n_cand) w.cand_e[i] = (uint8_t)vv[u]; }
+                for (int u = 0; u < 4; ++u) { const uint32_t i = b + 64u * u + lane; if (i < n_cand) cand_e[i] = (uint8_t)vv[u]; }
             }
         } else {
-            for (uint32_t i = lane; i < n_cand; i += 64) w.cand_e[i] = (uint8_t)mismatch_capped(ix, w.pm[strand], L, w.loci[i]);
+            for (uint32_t i = lane; i < n_cand; i += 64) cand_e[i] = (uint8_t)mismatch_capped(ix, w.pm[strand], L, loci[i]);
         }
         WSYNC();
         pc.stamp(SALT_CTR_T_VERIFY);
         // phase B: the sequential rule, replayed by ballots over 64 candidates at a time
         for (uint32_t b = 0; b < n_cand; b += 64) {
             uint32_t i = b + lane, v = INF, pos = 0;
-            if (i < n_cand) { pos = w.loci[i]; v = w.cand_e[i]; }
+            if (i < n_cand) { pos = loci[i]; v = cand_e[i]; }
             // ballots by value: m[t] = lanes with v <= t
             uint64_t m0 = __ballot(v <= 0), m1 = __ballot(v <= 1), m2 = __ballot(v <= 2), m3 = __ballot(v <= 3);
             // a candidate passes iff v <= bound and no earlier candidate of this chunk is smaller
@@ -754,7 +766,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             (void)m3;
         }
         c_verify += n_cand; n_cand_nogap += n_cand;
-        for (uint32_t b = lane; b < n_cand; b += 64) c_vwords += ((w.loci[b] & 7u) + L + 7) >> 3;
+        for (uint32_t b = lane; b < n_cand; b += 64) c_vwords += ((loci[b] & 7u) + L + 7) >> 3;
         if (found[strand]) { q_pos = call_best_pos; q_ndiff = call_best_n; q_gap = 0; q_strand = (uint32_t)strand; }
         WSYNC();
         pc.stamp(SALT_CTR_T_SCAN);
@@ -762,9 +774,10 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
 
     // ---- gapped pass (alnse.c:1089-1096): sequential per candidate, LV across lanes ----
     if (!too_short && !found[0] && !found[1]) {
-        int maxd = (int)(L / 10);
-        const bool lanes_fit = (int)(L / 10) <= LLV_K && L + 4 <= 8u * (LLV_TW - 1);
-        if (MODE == 0 && lanes_fit && g.cap && n_cand_nogap >= GAP_DEFER_MIN) {
+        int maxd = ap.pe ? 3 : (int)(L / 10);                    // alnse.c:1090 (SE) / alnse.c:1016-1028 (PE keeps 3)
+        const int gap_k0 = maxd;
+        const bool lanes_fit = gap_k0 <= LLV_K && L + 4 <= 8u * (LLV_TW - 1);
+        if (MODE == 0 && !ap.pe && lanes_fit && g.cap && n_cand_nogap >= GAP_DEFER_MIN) {
             uint32_t slot = 0;
             if (lane == 0) slot = atomicAdd(&g.gctl[2], 1u);
             slot = (uint32_t)__shfl((int)slot, 0);
@@ -773,7 +786,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         for (int strand = 0; strand < 2; ++strand) {
             if (MODE == 1 && strand != (int)g.strand) continue;
             pc.stamp(SALT_CTR_T_GAP);
-            const CandStats cs = build_candidates(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase }, w);
+            const CandStats cs = build_candidates(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, loci, loci_cap, ap.pe }, w);
             pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
             const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
             bool any = false;
@@ -782,16 +795,16 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             const bool lanes_ok = lanes_fit;
             uint8_t *ge = (MODE != 0) ? g.ge + ((size_t)g.slot * 2 + (uint32_t)strand) * MAXLOC : nullptr;
             if (MODE == 2) {                                          // distances were computed by k_gap
-                for (uint32_t i = lane; i < n_cand; i += 64) w.cand_e[i] = ge[i];
+                for (uint32_t i = lane; i < n_cand; i += 64) cand_e[i] = ge[i];
                 WSYNC();
             } else if (lanes_ok) {
-                const int k0 = (int)(L / 10);
+                const int k0 = gap_k0;
                 for (uint32_t b = (MODE == 1 ? g.chunk * LLV_N : 0u); b < (MODE == 1 ? (g.chunk + 1) * LLV_N : n_cand) && b < n_cand; b += LLV_N) {
                     WSYNC();
                     const uint32_t i = b + lane;
                     bool act = false;
                     if (lane < LLV_N && i < n_cand) {
-                        const uint32_t pos = w.loci[i];
+                        const uint32_t pos = loci[i];
                         act = !(pos > ix.ref_len || pos + L + 4 > ix.ref_len);           // ed_diff guard (editdistance.c:178)
                         if (act) {
                             const uint32_t tl = L + 4, w0 = pos >> 3, sh = (pos & 7u) * 4u, nwt = (tl + 7) >> 3;
@@ -810,15 +823,15 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                         }
                     }
                     const uint32_t e = lv_lanes(w.u.llv, w.pm[strand], (int)L, (int)L + 4, k0, act);
-                    if (lane < LLV_N && i < n_cand) { if (MODE == 1) ge[i] = (uint8_t)e; else w.cand_e[i] = (uint8_t)e; }
+                    if (lane < LLV_N && i < n_cand) { if (MODE == 1) ge[i] = (uint8_t)e; else cand_e[i] = (uint8_t)e; }
                 }
                 WSYNC();
             }
             if (MODE == 1) return;                                    // this item's 32 distances are stored
             for (uint32_t i = 0; i < n_cand; ++i) {
-                uint32_t pos = w.loci[i];
+                uint32_t pos = loci[i];
                 int e = -1;
-                if (lanes_ok) { const uint32_t ev = w.cand_e[i]; e = (ev != 255 && (int)ev <= maxd) ? (int)ev : -1; }
+                if (lanes_ok) { const uint32_t ev = cand_e[i]; e = (ev != 255 && (int)ev <= maxd) ? (int)ev : -1; }
                 else if (!(pos > ix.ref_len || pos + L + 4 > ix.ref_len)) {   // ed_diff guard (editdistance.c:178)
                     lv_unpack(ix.ref, w, strand, L, pos);
                     int dd;
@@ -922,7 +935,7 @@ __device__ __forceinline__ void persistent_body(const IndexView &ix, const Align
                                                 const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
                                                 const uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl,
                                                 unsigned long long *__restrict__ ctr, LvTables *__restrict__ lvtab,
-                                                uint32_t *__restrict__ gq, uint8_t *__restrict__ ge, uint32_t gcap)
+                                                uint32_t *__restrict__ gq, uint8_t *__restrict__ ge, uint32_t gcap, uint8_t *__restrict__ pe_scr)
 {
     __shared__ WaveLds w;
     __shared__ uint32_t s_item;
@@ -945,7 +958,9 @@ __device__ __forceinline__ void persistent_body(const IndexView &ix, const Align
         if (MODE == 0) r = ap.all_heavy ? it : queue[it];
         else if (MODE == 1) { const uint32_t per = 2u * (MAXLOC / LLV_N); g.slot = it / per; g.strand = (it % per) / (MAXLOC / LLV_N); g.chunk = it % (MAXLOC / LLV_N); r = gq[g.slot]; }
         else { g.slot = it; r = gq[it]; }
-        align_general<MODE>(ix, ap, w, r, seqs, offs, sai_c, sai_r, results, MODE == 1 ? nullptr : ctr, MODE == 1 ? nullptr : phase, lvtab + blockIdx.x, g);
+        align_general<MODE>(ix, ap, w, r, seqs, offs, sai_c, sai_r, results, MODE == 1 ? nullptr : ctr, MODE == 1 ? nullptr : phase, lvtab + blockIdx.x, g,
+                            pe_scr ? reinterpret_cast<uint32_t *>(pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5) : nullptr,
+                            pe_scr ? pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5 + (size_t)PE_LOCI_CAP * 4 : nullptr);
         if (MODE == 0 && phase && threadIdx.x == 0) s_phase[SALT_CTR_HEAVY_READS] += 1;
         WSYNC();
     }
@@ -960,8 +975,9 @@ __global__ void __launch_bounds__(64)                                           
 NAME(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,                  \
      const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,             \
      const uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl, unsigned long long *__restrict__ ctr,             \
-     LvTables *__restrict__ lvtab, uint32_t *__restrict__ gq, uint8_t *__restrict__ ge, uint32_t gcap)                   \
-{ persistent_body<MODE>(ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, lvtab, gq, ge, gcap); }
+     LvTables *__restrict__ lvtab, uint32_t *__restrict__ gq, uint8_t *__restrict__ ge, uint32_t gcap,                  \
+     uint8_t *__restrict__ pe_scr)                                                                                      \
+{ persistent_body<MODE>(ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, lvtab, gq, ge, gcap, pe_scr); }
 PERSISTENT_KERNEL(k_heavy, 0)
 PERSISTENT_KERNEL(k_gap, 1)
 PERSISTENT_KERNEL(k_gapfin, 2)
@@ -1290,16 +1306,16 @@ uint32_t heavy_blocks_per_cu()
 
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, uint32_t *qctl, unsigned long long *ctr,
-                  uint32_t n_blocks, void *lvtab, uint32_t *gq, uint8_t *ge, uint32_t gcap, hipStream_t st)
+                  uint32_t n_blocks, void *lvtab, uint32_t *gq, uint8_t *ge, uint32_t gcap, uint8_t *pe_scr, hipStream_t st)
 {
     if (!ap.n_reads) return;
     uint32_t blocks = n_blocks < ap.n_reads ? n_blocks : ap.n_reads;
     LvTables *tab = static_cast<LvTables *>(lvtab);
-    hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap);
-    if (!gcap) return;
+    hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, ap.pe ? 0u : gcap, pe_scr);
+    if (!gcap || ap.pe) return;
     // the deferred gapped passes: distances by (read, strand, 32 candidates), then one finishing wave per read
-    hipLaunchKernelGGL(k_gap, dim3(n_blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap);
-    hipLaunchKernelGGL(k_gapfin, dim3(n_blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap);
+    hipLaunchKernelGGL(k_gap, dim3(n_blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
+    hipLaunchKernelGGL(k_gapfin, dim3(n_blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
 }
 
 size_t gap_e_bytes_per_read() { return 2u * MAXLOC; }

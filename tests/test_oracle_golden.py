@@ -73,3 +73,29 @@ def test_oracle_pe_sam_matches_reference(case, oracle_cli):
                                                 os.path.join(LAMBDA, "reads_pe_2.fq")], check=True, capture_output=True).stdout
     want = open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
     assert out == want
+
+
+def _ssw_vectors():
+    out = []
+    with open(os.path.join(GOLDEN, "ssw_vectors.txt")) as f:
+        for line in f:
+            t = line.split()
+            out.append((int(t[1]), np.array([int(c, 16) for c in t[2]], dtype=np.uint8),
+                        np.frombuffer(t[3].encode(), dtype=np.uint8) - 48, [int(x) for x in t[4:10]], t[10]))
+    return out
+
+
+def test_oracle_ssw_matches_reference_vectors(oracle_lib):
+    """SSW 0.1.4 word kernel (forward, reverse, second best, banded traceback) emulated lane by lane, against answers
+    printed by the reference's own ssw.c (oracle/ref_harness_ssw.c) for both score matrices."""
+    lib = oracle_lib
+    n = 0
+    for aware, ref, codes, want6, cig in _ssw_vectors():
+        out6 = (ctypes.c_int * 6)()
+        buf = ctypes.create_string_buffer(512)
+        codes = np.ascontiguousarray(codes)
+        lib.so_ssw_unit(aware, ref.ctypes.data_as(ctypes.c_void_p), len(ref), codes.ctypes.data_as(ctypes.c_void_p), len(codes), out6, buf, 512)
+        assert list(out6) == want6, (n, list(out6), want6)
+        assert (buf.value.decode() or "-") == cig, (n, buf.value, cig)
+        n += 1
+    assert n == 600
