@@ -132,6 +132,17 @@ void salt_gpu_ws_destroy(salt_gpu_ws_t *ws);
 int  salt_gpu_align_se(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, uint32_t n_reads,
                        const uint8_t *seqs, const uint32_t *offs, salt_result_t *results);
 
+/* Paired end: the per-batch call that stands where alnpe_core1 runs (Align_src/alnpe.c:482-528, 596-606).
+ * Mates are interleaved as query_read_multiPairedSeqs lays them out (query.c:252-268): pair i = reads 2i, 2i+1 of
+ * seqs/offs; results[2i], results[2i+1].  Per mate: alnse_overlap (alnse.c:985-1044); per pair: pairing2 /
+ * pairing_singleton with Smith-Waterman mate rescue (alnpe.c:94-480, ssw.c); CIGARs by query_gen_cigar or from the
+ * rescue.  A rescued mate has seq_start / seq_end set (soft clips), b0 / b1 = SW scores.  `pac`: the 2-bit genome
+ * (<P>.C.pac bytes, needed by the singleton rescue), l_pac bases. */
+typedef struct { uint32_t min_tlen, max_tlen; } salt_pe_opt_t;      /* -a 250, -b 550 (aln.c:43-44) */
+int  salt_gpu_index_set_pac(salt_gpu_index_t *ix, const uint8_t *pac, uint64_t l_pac);
+int  salt_gpu_align_pe(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, const salt_pe_opt_t *pe, uint32_t n_pairs,
+                       const uint8_t *seqs, const uint32_t *offs, salt_result_t *results);
+
 /* Same work on device-resident buffers; only enqueues on `hip_stream` (a hipStream_t, NULL = default). */
 int  salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, uint32_t n_reads,
                                 uint32_t max_read_len, const void *d_seqs, const void *d_offs,
@@ -159,6 +170,13 @@ int  salt_gpu_ws_counters(salt_gpu_ws_t *ws, uint64_t out[SALT_CTR_N]);
  * ed_diff, ed_diff_withcigar (editdistance.c:88,174,234). */
 int  salt_gpu_diag_lv(const uint32_t *ref_words, uint32_t ref_len, uint32_t n_cases, const uint32_t *pos,
                       const uint32_t *kdiff, const uint8_t *seqs, const uint32_t *offs, int32_t *out4, uint16_t *cigars);
+
+/* Unit entry of the Smith-Waterman mate-rescue kernel (ssw_init + ssw_align as snpaln_sw[_snpaware] call them,
+ * alnpe.c:260-393; ssw.c): case i aligns codes[read_offs[i]..read_offs[i+1]) against reference symbols
+ * ref_syms[ref_offs[i]..ref_offs[i+1]) -- 4-bit allele masks when aware[i], bases 0..3 otherwise.
+ * out6[6i..]: score1, score2, ref_begin1, ref_end1, read_begin1, read_end1; cigars[i][SALT_MAX_CIGAR_OPS], n_cigar[i]. */
+int  salt_gpu_diag_ssw(uint32_t n_cases, const uint8_t *aware, const uint8_t *ref_syms, const uint32_t *ref_offs,
+                       const uint8_t *codes, const uint32_t *read_offs, int32_t *out6, uint16_t *cigars, uint16_t *n_cigar);
 
 const char *salt_gpu_last_error(void);
 uint32_t    salt_gpu_result_size(void);         /* sizeof(salt_result_t), for bindings */

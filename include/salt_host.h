@@ -6,6 +6,7 @@
  *   salt_index_host_view         the arrays of index_t                            indexio.h:26-33
  *   salt_sam_header              aln_samhead (without the dated @PG line)         sam.c:56-84
  *   salt_sam_se                  aln_samse + sam_add_xa + sam_add_md_nm           sam.c:87-328
+ *   salt_sam_pe                  alnpe_sam                                        sam.c:331-457
  *   salt_lkt_build               LKT_build_lookuptable                            Index_src/LookUpTable.c:70-150
  */
 #ifndef SALT_HOST_H
@@ -28,6 +29,7 @@ void          salt_index_free(salt_index_t *ix);
 const salt_host_index_t *salt_index_host_view(const salt_index_t *ix);
 int32_t       salt_index_seed_len(const salt_index_t *ix);
 int32_t       salt_index_n_seqs(const salt_index_t *ix);
+const uint8_t *salt_index_pac(const salt_index_t *ix, uint64_t *l_pac);   /* <P>.C.pac bytes (bntseq.c 2-bit packing) for salt_gpu_index_set_pac */
 const char   *salt_host_last_error(void);
 
 /* 12-mer table exactly as salt-idx writes it; out must hold 4^len + 1 entries. */
@@ -45,6 +47,12 @@ typedef struct {
 int salt_sam_header(const salt_index_t *ix, const salt_sam_opt_t *opt, char *buf, size_t cap);
 int salt_sam_se(const salt_index_t *ix, const salt_sam_opt_t *opt, const char *name, const uint8_t *seq,
                 int32_t l_seq, const char *qual, const salt_result_t *res, char *buf, size_t cap);
+
+/* alnpe_sam (sam.c:331-457): both records of a pair (q[0], q[1]), each followed by "\n\n" as the reference's
+ * driver prints them (alnpe.c:640-648).  Names are the mates' names with a trailing /1 /2 already removed. */
+int salt_sam_pe(const salt_index_t *ix, const salt_sam_opt_t *opt, const salt_pe_opt_t *pe, const char *const name[2],
+                const uint8_t *const seq[2], const int32_t l_seq[2], const char *const qual[2],
+                const salt_result_t *q, char *buf, size_t cap);
 
 /* Index builder (row N1): writes <prefix>.{R.seedLen,C.pac,C.ann,C.amb,C.lkt,C.bwt,C.sa,lp,
  * R.backward.bwt,R.backward.occ,R.backward.sa,ref} in salt-idx's formats from a FASTA (plain or .gz)

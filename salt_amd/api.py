@@ -63,6 +63,10 @@ class _AlnOpt(ctypes.Structure):
                 ("collect_counters", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class _PeOpt(ctypes.Structure):
+    _fields_ = [("min_tlen", ctypes.c_uint32), ("max_tlen", ctypes.c_uint32)]
+
+
 class _SamOpt(ctypes.Structure):
     _fields_ = [("print_xa_cigar", ctypes.c_int32), ("print_nm_md", ctypes.c_int32), ("rg_id", ctypes.c_char_p)]
 
@@ -87,6 +91,11 @@ def host_lib():
         lib.salt_index_n_seqs.argtypes = [ctypes.c_void_p]
         lib.salt_host_last_error.restype = ctypes.c_char_p
         lib.salt_sam_header.argtypes = [ctypes.c_void_p, ctypes.POINTER(_SamOpt), ctypes.c_char_p, ctypes.c_size_t]
+        lib.salt_index_pac.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        lib.salt_index_pac.restype = ctypes.c_void_p
+        lib.salt_sam_pe.argtypes = [ctypes.c_void_p, ctypes.POINTER(_SamOpt), ctypes.POINTER(_PeOpt), ctypes.POINTER(ctypes.c_char_p),
+                                    ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_char_p),
+                                    ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         lib.salt_sam_se.argtypes = [ctypes.c_void_p, ctypes.POINTER(_SamOpt), ctypes.c_char_p, ctypes.c_void_p,
                                     ctypes.c_int32, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         lib.salt_lkt_build.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
@@ -115,6 +124,9 @@ def gpu_lib():
                                           ctypes.c_void_p, ctypes.c_void_p]
         lib.salt_gpu_align_se_resident.argtypes = [ctypes.c_void_p, ctypes.POINTER(_AlnOpt), ctypes.c_uint32, ctypes.c_uint32,
                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.salt_gpu_index_set_pac.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        lib.salt_gpu_align_pe.argtypes = [ctypes.c_void_p, ctypes.POINTER(_AlnOpt), ctypes.POINTER(_PeOpt), ctypes.c_uint32,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.salt_gpu_ws_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
         lib.salt_gpu_index_image_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
         lib.salt_gpu_ws_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -143,6 +155,12 @@ class AlnOpt:
     print_nm_md: int = 0
     rg_id: str = None
     collect_counters: int = 0
+    paired: int = 0             # -p
+    min_tlen: int = 250         # -a (aln.c:43)
+    max_tlen: int = 550         # -b (aln.c:44)
+
+    def _pe(self):
+        return _PeOpt(self.min_tlen, self.max_tlen)
 
     def _c(self):
         ov = self.l_overlap if self.l_overlap > 0 else self.l_seed          # aln.c:223
@@ -174,7 +192,11 @@ class AlnOpt:
             elif k == "-g":
                 o.rg_id = v
             elif k == "-p":
-                raise SaltError("paired-end mode is not implemented on the GPU path yet")
+                o.paired = 1
+            elif k == "-a":
+                o.min_tlen = int(v)
+            elif k == "-b":
+                o.max_tlen = int(v)
         return o, rest
 
 
@@ -210,6 +232,26 @@ class Index:
         n = host_lib().salt_sam_header(self._h, ctypes.byref(so), buf, len(buf))
         if n < 0:
             raise SaltError("SAM header too large")
+        return buf.raw[:n]
+
+    def pac(self):
+        n = ctypes.c_uint64()
+        p = host_lib().salt_index_pac(self._h, ctypes.byref(n))
+        return p, n.value
+
+    def sampe(self, opt, names, seqs, quals, result_rows):
+        """Both SAM records of a pair (bytes, with the reference's blank line after each)."""
+        buf = ctypes.create_string_buffer(16384 + 16 * (len(seqs[0]) + len(seqs[1])))
+        so, pe = opt._sam(), opt._pe()
+        sq = [np.ascontiguousarray(x, dtype=np.uint8) for x in seqs]
+        rows = np.ascontiguousarray(result_rows)
+        nm = (ctypes.c_char_p * 2)(names[0], names[1])
+        ql = (ctypes.c_char_p * 2)(quals[0], quals[1])
+        sp = (ctypes.c_void_p * 2)(sq[0].ctypes.data, sq[1].ctypes.data)
+        ls = (ctypes.c_int32 * 2)(len(sq[0]), len(sq[1]))
+        n = host_lib().salt_sam_pe(self._h, ctypes.byref(so), ctypes.byref(pe), nm, sp, ls, ql, rows.ctypes.data, buf, len(buf))
+        if n < 0:
+            raise SaltError("SAM record too large")
         return buf.raw[:n]
 
     def samse(self, opt, name, seq, qual, result_row):
@@ -291,6 +333,33 @@ class GpuAligner:
             done += m
         return res
 
+    def alnpe_core1(self, opt, index, seqs, offs):
+        """Paired end: mates interleaved (pair i = reads 2i, 2i+1).  Returns RESULT_DTYPE[2 * n_pairs]."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint32)
+        n = len(offs) - 1
+        if n % 2:
+            raise SaltError("paired end needs an even number of reads")
+        lib = gpu_lib()
+        if not getattr(self, "_pac_set", False):
+            pac, l_pac = index.pac()
+            _gpu_check(lib.salt_gpu_index_set_pac(self._ix, pac, l_pac))
+            self._pac_set = True
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        co, pe = opt._c(), opt._pe()
+        done = 0
+        cap = self.max_reads & ~1
+        while done < n:
+            m = min(cap, n - done)
+            while m > 2 and int(offs[done + m]) - int(offs[done]) > self.max_bases:
+                m = (m // 2) & ~1
+            o = (offs[done:done + m + 1] - offs[done]).astype(np.uint32)
+            s = seqs[int(offs[done]):int(offs[done + m])]
+            _gpu_check(lib.salt_gpu_align_pe(self._ws, ctypes.byref(co), ctypes.byref(pe), m // 2, s.ctypes.data,
+                                             o.ctypes.data, res[done:].ctypes.data))
+            done += m
+        return res
+
     def align_resident(self, opt, n_reads, max_read_len, d_seqs, d_offs, d_results, stream=0):
         co = opt._c()
         _gpu_check(gpu_lib().salt_gpu_align_se_resident(self._ws, ctypes.byref(co), n_reads, max_read_len, d_seqs, d_offs,
@@ -342,6 +411,30 @@ def read_fastq(path):
             offs.append(offs[-1] + len(s))
     seqs = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint8)
     return names, seqs, np.array(offs, dtype=np.uint32), quals
+
+
+def interleave_pairs(r1, r2):
+    """Two read_fastq() results -> one with mates interleaved as query_read_multiPairedSeqs (query.c:252-268)."""
+    n1, s1, o1, q1 = r1
+    n2, s2, o2, q2 = r2
+    if len(n1) != len(n2):
+        raise SaltError("mate files differ in length")
+    names, quals, chunks, offs = [], [], [], [0]
+    for i in range(len(n1)):
+        for nm, sq, of, ql in ((n1, s1, o1, q1), (n2, s2, o2, q2)):
+            names.append(nm[i]); quals.append(ql[i]); chunks.append(sq[of[i]:of[i + 1]])
+            offs.append(offs[-1] + int(of[i + 1] - of[i]))
+    seqs = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint8)
+    return names, seqs, np.array(offs, dtype=np.uint32), quals
+
+
+def sam_text_pe(index, opt, names, seqs, offs, quals, results, header=True):
+    """The SAM stream `salt -p` prints (without @PG)."""
+    out = [index.sam_header(opt)] if header else []
+    for i in range(0, len(names), 2):
+        out.append(index.sampe(opt, names[i:i + 2], [seqs[offs[i]:offs[i + 1]], seqs[offs[i + 1]:offs[i + 2]]],
+                               quals[i:i + 2], results[i:i + 2]))
+    return b"".join(out)
 
 
 def sam_text(index, opt, names, seqs, offs, quals, results, header=True):

@@ -1022,6 +1022,7 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
     if (!heavy) {
         // ---- round trip 1: the read (as one-hot nibble words, both strands) and its seeds ----
         const uint32_t nw = (L + 7) >> 3;
+        uint32_t n_amb = 0;
         if (lane < 2 * nw) {
             const uint32_t s = lane >= nw, j = s ? lane - nw : lane;
             uint32_t word = 0;
@@ -1031,10 +1032,21 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
                     uint32_t c = s ? seqs[off + (L - 1 - i)] : seqs[off + i];
                     if (s && c < 4) c = 3 - c;
                     msk = c < 4 ? (1u << c) : 15u;                         // nt2bit (editdistance.c:40)
+                    n_amb += (!s && c > 3);
                 }
                 word |= msk << (4 * q);
             }
             w.pm[s][j] = word;
+        }
+        for (int o = 32; o > 0; o >>= 1) n_amb += (uint32_t)__shfl_xor((int)n_amb, o);
+        if (n_amb > ap.max_amb) {                                           // alnse.c:1328 / alnpe.c:495: record left untouched
+            if (lane == 0) {
+                salt_result_t *out = results + r;
+                out->pos = 0xFFFFFFFFu; out->strand = 3; out->n_diff = 255; out->is_gap = 255; out->mapq = 0;
+                out->b0 = -1; out->b1 = -1; out->seq_start = 0; out->seq_end = (uint16_t)(L - 1);
+                out->n_hits[0] = out->n_hits[1] = 0; out->n_cigar = 0; out->skipped = 1;
+            }
+            return;
         }
         {
             // lane = (list, slot); list: 0 C/fwd 1 R/fwd 2 C/rev 3 R/rev.  The reference orders each list by
@@ -1203,6 +1215,72 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
             atomicAdd(ctr + SALT_CTR_READS, 1ull); atomicAdd(ctr + SALT_CTR_BASES, L); atomicAdd(ctr + SALT_CTR_LOCI, c_loci);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pe_final: one wave per pair -- apply the first successful mate rescue (in the order pairing2 /
+// pairing_singleton try them, alnpe.c:213-252, 420-470), then query_gen_cigar for the mates that keep their
+// seed-and-verify mapping (query.c:282-296)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_pe_final(IndexView ix, uint32_t n_pairs, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+           salt_result_t *__restrict__ res, const PePair *__restrict__ pairs, const PeSwRes *__restrict__ sw, LvTables *__restrict__ lvtab,
+           uint32_t *__restrict__ head)
+{
+    __shared__ WaveLds w;
+    __shared__ uint32_t s_item;
+    const uint32_t lane = lane_id();
+  for (;;) {                                                              // persistent: the LV table slot is this block's own
+    if (threadIdx.x == 0) s_item = atomicAdd(head, 1u);
+    WSYNC();
+    const uint32_t p = s_item;
+    WSYNC();
+    if (p >= n_pairs) break;
+    const PePair pr = pairs[p];
+    int rescued = -1;
+    for (int k = 0; k < pr.n_req && rescued < 0; ++k) {
+        const PeSwRes &r = sw[pr.req0 + k];
+        if (!r.ok) continue;
+        rescued = pr.rescued[k];
+        salt_result_t *q = res + 2 * p + rescued;
+        if (lane == 0) {
+            const int b0 = r.score1, b1 = r.score2;
+            uint32_t mapq = 0;
+            if (b0 != 0) { const uint32_t x = (uint32_t)(b0 > b1 ? b0 - b1 : b1 - b0); const uint64_t v = (uint64_t)255 * x / (uint32_t)b0; mapq = v < 254 ? (uint32_t)v : 254u; }
+            q->b0 = b0; q->b1 = b1; q->mapq = (uint8_t)mapq;
+            q->pos = (uint32_t)r.ref_begin + r.start; q->strand = (uint8_t)r.strand;
+            q->seq_start = (uint16_t)r.read_begin; q->seq_end = (uint16_t)r.read_end;
+            q->n_cigar = (uint8_t)r.n_cigar;
+        }
+        if (lane < r.n_cigar) q->cigar[lane] = r.cigar[lane];
+    }
+    for (int m = 0; m < 2; ++m) {
+        if (m == rescued) continue;
+        salt_result_t *q = res + 2 * p + m;
+        const uint32_t off = offs[2 * p + m], L = offs[2 * p + m + 1] - off;
+        if (lane == 0) { q->seq_start = 0; q->seq_end = (uint16_t)(L - 1); }
+        const uint32_t pos = q->pos;
+        if (pos == 0xFFFFFFFFu) { if (lane == 0) q->n_cigar = 0; continue; }
+        if (q->is_gap) {
+            const int strand = q->strand;
+            for (uint32_t i = lane; i < L; i += 64) { uint8_t c = seqs[off + i]; if (c > 4) c = 4; w.seq[0][i] = c; w.seq[1][L - 1 - i] = c < 4 ? (uint8_t)(3 - c) : c; }
+            WSYNC();
+            lv_cigar(ix.ref, w, lvtab + blockIdx.x, strand, L, pos, (int)q->n_diff);
+            if (lane < (uint32_t)w.n_cig) q->cigar[lane] = w.cig[lane];
+            if (lane == 0) q->n_cigar = (uint8_t)w.n_cig;
+            WSYNC();
+        } else if (lane == 0) { q->cigar[0] = (uint16_t)((L << 4) | 0u); q->n_cigar = 1; }
+    }
+    WSYNC();
+  }
+}
+
+void launch_pe_final(const IndexView &ix, uint32_t n_pairs, const uint8_t *seqs, const uint32_t *offs, salt_result_t *res, const PePair *pairs,
+                     const PeSwRes *sw, void *lvtab, uint32_t *head, uint32_t n_blocks, hipStream_t st)
+{
+    if (!n_pairs) return;
+    const uint32_t blocks = n_blocks < n_pairs ? n_blocks : n_pairs;
+    hipLaunchKernelGGL(k_pe_final, dim3(blocks), dim3(64), 0, st, ix, n_pairs, seqs, offs, res, pairs, sw, static_cast<LvTables *>(lvtab), head);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -25,6 +25,7 @@ struct salt_gpu_index {
     bool owns = true;
     ImageHeader hdr;               // host copy
     IndexView view;
+    uint8_t *d_pac = nullptr; uint64_t l_pac = 0;      // 2-bit genome for the PE singleton rescue (not part of the image)
 };
 
 struct salt_gpu_ws {
@@ -36,6 +37,10 @@ struct salt_gpu_ws {
     uint32_t *d_queue = nullptr, *d_qctl = nullptr;   // reads k_light hands to k_heavy; {count, head}
     void *d_lvtab = nullptr;                          // one LV traceback table per persistent k_heavy block
     uint32_t *d_gq = nullptr; uint8_t *d_ge = nullptr; uint32_t gcap = 0;   // deferred gapped passes
+    // paired end (allocated on first use)
+    uint8_t *d_pe_scr = nullptr;                       // per persistent block: PE_LOCI_CAP loci + distances
+    PePair *d_pairs = nullptr; PeSwReq *d_req = nullptr; PeSwRes *d_swres = nullptr; uint32_t *d_pctl = nullptr;
+    uint8_t *d_sw_scr = nullptr; uint32_t sw_blocks = 0; uint32_t pe_pairs_cap = 0;
     uint32_t heavy_blocks = 2048;
     int all_heavy = 0;
     hipStream_t stream = nullptr;
@@ -184,6 +189,7 @@ extern "C" void salt_gpu_index_detach(salt_gpu_index_t *ix)
 {
     if (!ix) return;
     if (ix->owns && ix->image) { hipSetDevice(ix->device); hipFree(ix->image); }
+    if (ix->d_pac) { hipSetDevice(ix->device); hipFree(ix->d_pac); }
     delete ix;
 }
 
@@ -252,6 +258,7 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
     if (!ws) return;
     hipSetDevice(ws->ix->device);
     hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gq); hipFree(ws->d_ge);
+    hipFree(ws->d_pe_scr); hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres); hipFree(ws->d_pctl); hipFree(ws->d_sw_scr);
     if (ws->stream) hipStreamDestroy(ws->stream);
     for (auto &e : ws->ev) if (e) hipEventDestroy(e);
     delete ws;
@@ -271,8 +278,17 @@ static int check_opt(const salt_gpu_index *ix, const salt_aln_opt_t *o, uint32_t
     return SALT_OK;
 }
 
+static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint32_t n_reads, uint32_t max_read_len,
+                               const void *d_seqs, const void *d_offs, void *d_results, void *hip_stream, int pe);
+
 extern "C" int salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint32_t n_reads, uint32_t max_read_len,
                                           const void *d_seqs, const void *d_offs, void *d_results, void *hip_stream)
+{
+    return align_resident_impl(ws, o, n_reads, max_read_len, d_seqs, d_offs, d_results, hip_stream, 0);
+}
+
+static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint32_t n_reads, uint32_t max_read_len,
+                               const void *d_seqs, const void *d_offs, void *d_results, void *hip_stream, int pe)
 {
     if (!ws || !o || !d_seqs || !d_offs || !d_results) return fail(SALT_E_INVAL, "null argument");
     if (n_reads == 0) return SALT_OK;
@@ -293,7 +309,8 @@ extern "C" int salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_
     sp.max_seed = o->max_seed; sp.seed_only_ref = o->seed_only_ref;
     if (n_reads > ws->max_reads) return fail(SALT_E_CAPACITY, "more reads than the workspace holds");
     AlignParams ap; ap.n_reads = n_reads; ap.spr = spr; ap.l_seed = o->l_seed; ap.max_locate = o->max_locate; ap.max_hits = o->max_hits;
-    ap.all_heavy = ws->all_heavy;
+    ap.all_heavy = ws->all_heavy; ap.pe = pe; ap.max_amb = pe ? 5u : 200u;
+    if (pe && !ws->d_pe_scr) HIPCHK(hipMalloc((void **)&ws->d_pe_scr, (uint64_t)ws->heavy_blocks * PE_LOCI_CAP * 5));
     unsigned long long *ctr = o->collect_counters ? ws->d_ctr : nullptr;
     const bool timed = ws->timing && ws->n_timed < MAX_TIMED;
     hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * 4] : nullptr;
@@ -306,7 +323,7 @@ extern "C" int salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_
                      static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, st);
     if (timed) HIPCHK(hipEventRecord(ev[2], st));
     launch_heavy(ws->ix->view, ap, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
-                 static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, ws->heavy_blocks, ws->d_lvtab, ws->d_gq, ws->d_ge, ws->gcap, st);
+                 static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, ws->heavy_blocks, ws->d_lvtab, ws->d_gq, ws->d_ge, ws->gcap, pe ? ws->d_pe_scr : nullptr, st);
     if (timed) { HIPCHK(hipEventRecord(ev[3], st)); ++ws->n_timed; }
     HIPCHK(hipGetLastError());
     return SALT_OK;
@@ -439,6 +456,56 @@ extern "C" int salt_gpu_diag_lv(const uint32_t *ref_words, uint32_t ref_len, uin
     return SALT_OK;
 }
 
+// Unit entry of the Smith-Waterman rescue kernel: case i aligns read codes[read_offs[i]..) against the reference symbols
+// ref_syms[ref_offs[i]..) (4-bit allele masks when aware[i], bases 0..3 otherwise), the way snpaln_sw_snpaware / snpaln_sw
+// call ssw_init + ssw_align (alnpe.c:260-393).  out6: score1, score2, ref_begin, ref_end, read_begin, read_end.
+extern "C" int salt_gpu_diag_ssw(uint32_t n_cases, const uint8_t *aware, const uint8_t *ref_syms, const uint32_t *ref_offs,
+                                 const uint8_t *codes, const uint32_t *read_offs, int32_t *out6, uint16_t *cigars, uint16_t *n_cigar)
+{
+    if (!aware || !ref_syms || !ref_offs || !codes || !read_offs || !out6 || !cigars || !n_cigar) return fail(SALT_E_INVAL, "null argument");
+    if (n_cases == 0) return SALT_OK;
+    const uint64_t n_sym = ref_offs[n_cases], n_base = read_offs[n_cases];
+    std::vector<uint32_t> h_ref(n_sym / 8 + 8, 0u);
+    std::vector<uint8_t> h_pac(n_sym / 4 + 8, 0);
+    std::vector<PeSwReq> h_req(n_cases);
+    for (uint32_t i = 0; i < n_cases; ++i) {
+        if (ref_offs[i + 1] <= ref_offs[i] || read_offs[i + 1] <= read_offs[i]) return fail(SALT_E_INVAL, "empty case");
+        for (uint64_t p = ref_offs[i]; p < ref_offs[i + 1]; ++p) {
+            h_ref[p >> 3] |= (uint32_t)(ref_syms[p] & 15u) << (4 * (p & 7u));
+            h_pac[p >> 2] |= (uint8_t)((ref_syms[p] & 3u) << ((~p & 3u) << 1));
+        }
+        h_req[i] = PeSwReq{ ref_offs[i], ref_offs[i + 1] - 1, i, 0, (uint8_t)(aware[i] ? 1 : 0), 0 };
+    }
+    uint32_t *d_ref = nullptr, *d_offs = nullptr, *d_ctl = nullptr; uint8_t *d_pac = nullptr, *d_codes = nullptr, *d_scr = nullptr;
+    PeSwReq *d_req = nullptr; PeSwRes *d_res = nullptr;
+    const uint32_t blocks = n_cases / 8 + 1 < 256 ? n_cases / 8 + 1 : 256;
+    HIPCHK(hipMalloc((void **)&d_ref, h_ref.size() * 4)); HIPCHK(hipMemcpy(d_ref, h_ref.data(), h_ref.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_pac, h_pac.size())); HIPCHK(hipMemcpy(d_pac, h_pac.data(), h_pac.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_codes, n_base + 16)); HIPCHK(hipMemcpy(d_codes, codes, n_base, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_offs, ((uint64_t)n_cases + 1) * 4)); HIPCHK(hipMemcpy(d_offs, read_offs, ((uint64_t)n_cases + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_req, (uint64_t)n_cases * sizeof(PeSwReq))); HIPCHK(hipMemcpy(d_req, h_req.data(), (uint64_t)n_cases * sizeof(PeSwReq), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_res, (uint64_t)n_cases * sizeof(PeSwRes)));
+    HIPCHK(hipMalloc((void **)&d_scr, (uint64_t)blocks * 8 * SW_SCRATCH_BYTES));
+    const uint32_t ctl[2] = { n_cases, 0 };
+    HIPCHK(hipMalloc((void **)&d_ctl, 8)); HIPCHK(hipMemcpy(d_ctl, ctl, 8, hipMemcpyHostToDevice));
+    IndexView v; memset(&v, 0, sizeof v);
+    v.ref = d_ref; v.ref_len = (uint32_t)n_sym;
+    launch_sw(v, d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 1, d_scr, blocks, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<PeSwRes> h_res(n_cases);
+    HIPCHK(hipMemcpy(h_res.data(), d_res, (uint64_t)n_cases * sizeof(PeSwRes), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n_cases; ++i) {
+        const PeSwRes &r = h_res[i];
+        int32_t *o = out6 + 6 * (uint64_t)i;
+        o[0] = r.score1; o[1] = r.score2; o[2] = r.ref_begin; o[3] = r.ref_end; o[4] = r.read_begin; o[5] = r.read_end;
+        n_cigar[i] = r.n_cigar;
+        memcpy(cigars + (uint64_t)i * SALT_MAX_CIGAR_OPS, r.cigar, sizeof r.cigar);
+    }
+    hipFree(d_ref); hipFree(d_pac); hipFree(d_codes); hipFree(d_offs); hipFree(d_req); hipFree(d_res); hipFree(d_scr); hipFree(d_ctl);
+    return SALT_OK;
+}
+
 extern "C" int salt_gpu_ws_heavy_reads(salt_gpu_ws_t *ws, uint32_t *ids, uint32_t cap, uint32_t *n)
 {
     if (!ws || !n) return fail(SALT_E_INVAL, "null argument");
@@ -448,6 +515,67 @@ extern "C" int salt_gpu_ws_heavy_reads(salt_gpu_ws_t *ws, uint32_t *ids, uint32_
     HIPCHK(hipMemcpy(ctl, ws->d_qctl, 32, hipMemcpyDeviceToHost));
     *n = ctl[0];
     if (ids && cap) HIPCHK(hipMemcpy(ids, ws->d_queue, (uint64_t)(ctl[0] < cap ? ctl[0] : cap) * 4, hipMemcpyDeviceToHost));
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_index_set_pac(salt_gpu_index_t *ix, const uint8_t *pac, uint64_t l_pac)
+{
+    if (!ix || !pac || l_pac == 0) return fail(SALT_E_INVAL, "null argument");
+    HIPCHK(hipSetDevice(ix->device));
+    if (ix->d_pac) { hipFree(ix->d_pac); ix->d_pac = nullptr; }
+    const uint64_t bytes = l_pac / 4 + 2;
+    HIPCHK(hipMalloc((void **)&ix->d_pac, bytes + 16));
+    HIPCHK(hipMemset(ix->d_pac, 0, bytes + 16));
+    HIPCHK(hipMemcpy(ix->d_pac, pac, bytes, hipMemcpyHostToDevice));
+    ix->l_pac = l_pac;
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_align_pe(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_pe_opt_t *pe, uint32_t n_pairs,
+                                 const uint8_t *seqs, const uint32_t *offs, salt_result_t *results)
+{
+    if (!ws || !o || !pe || !seqs || !offs || !results) return fail(SALT_E_INVAL, "null argument");
+    if (n_pairs == 0) return SALT_OK;
+    const uint32_t n_reads = 2 * n_pairs;
+    if (n_reads > ws->max_reads) return fail(SALT_E_CAPACITY, "more mates than the workspace holds");
+    if (!ws->ix->d_pac) return fail(SALT_E_INVAL, "paired end needs the 2-bit genome: call salt_gpu_index_set_pac first");
+    if (offs[0] != 0) return fail(SALT_E_INVAL, "offs[0] must be 0");
+    const uint64_t bases = offs[n_reads];
+    if (bases > ws->max_bases) return fail(SALT_E_CAPACITY, "more bases than the workspace holds");
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n_reads; ++i) {
+        if (offs[i + 1] <= offs[i]) return fail(SALT_E_INVAL, "empty read or decreasing offsets");
+        const uint32_t l = offs[i + 1] - offs[i];
+        max_len = l > max_len ? l : max_len;
+    }
+    HIPCHK(hipSetDevice(ws->ix->device));
+    hipStream_t st = ws->stream;
+    if (n_pairs > ws->pe_pairs_cap) {
+        HIPCHK(hipStreamSynchronize(st));
+        hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres);
+        HIPCHK(hipMalloc((void **)&ws->d_pairs, (uint64_t)n_pairs * sizeof(PePair)));
+        HIPCHK(hipMalloc((void **)&ws->d_req, (uint64_t)n_pairs * 2 * sizeof(PeSwReq)));
+        HIPCHK(hipMalloc((void **)&ws->d_swres, (uint64_t)n_pairs * 2 * sizeof(PeSwRes)));
+        ws->pe_pairs_cap = n_pairs;
+    }
+    if (!ws->d_pctl) {
+        HIPCHK(hipMalloc((void **)&ws->d_pctl, 8 * 4));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, ws->ix->device));
+        ws->sw_blocks = (uint32_t)prop.multiProcessorCount * 4u;
+        HIPCHK(hipMalloc((void **)&ws->d_sw_scr, (uint64_t)ws->sw_blocks * 8 * SW_SCRATCH_BYTES));
+    }
+    HIPCHK(hipMemcpyAsync(ws->d_seqs, seqs, bases, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ws->d_offs, offs, ((uint64_t)n_reads + 1) * 4, hipMemcpyHostToDevice, st));
+    int rc = align_resident_impl(ws, o, n_reads, max_len, ws->d_seqs, ws->d_offs, ws->d_results, st, 1);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(ws->d_pctl, 0, 32, st));
+    launch_pair(n_pairs, pe->min_tlen, pe->max_tlen, (uint32_t)ws->ix->l_pac, ws->d_offs, ws->d_results, ws->d_pairs, ws->d_req, ws->d_pctl, st);
+    launch_sw(ws->ix->view, ws->ix->d_pac, ws->d_seqs, ws->d_offs, ws->d_req, ws->d_pctl, ws->d_swres, ws->d_pctl + 1, ws->d_sw_scr, ws->sw_blocks, st);
+    launch_pe_final(ws->ix->view, n_pairs, ws->d_seqs, ws->d_offs, ws->d_results, ws->d_pairs, ws->d_swres, ws->d_lvtab, ws->d_pctl + 2, ws->heavy_blocks, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(results, ws->d_results, (uint64_t)n_reads * sizeof(salt_result_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return SALT_OK;
 }
 

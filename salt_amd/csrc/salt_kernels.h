@@ -35,6 +35,21 @@ void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint8_t *seq
 size_t gap_e_bytes_per_read();
 size_t lv_table_bytes();                // per-block LV traceback table (global memory)
 
+// ---- paired end (salt_pe.hip) ----
+static const uint32_t SW_MAX_SEG = 64;              // stripes: reads up to 512 bases
+static const uint32_t SW_BAND_W = 1100;             // ints per banded-SW row buffer (band width <= 548)
+static const uint32_t SW_MAXCOL_BYTES = 16384;      // per-column maxima: rescue windows up to 8192 bases
+static const uint32_t SW_SCRATCH_BYTES = 16384 + 3 * 1100 * 4 + 262144 - 3 * 1100 * 4;   // = 16 KiB + 256 KiB per group
+struct PeSwReq { uint32_t start, end, mate; uint8_t strand, aware; uint16_t pad; };          // mate: index of the rescued mate (2p or 2p+1)
+struct PeSwRes { int32_t score1, score2, ref_begin, ref_end, read_begin, read_end; uint32_t start, strand; uint16_t n_cigar, ok; uint16_t cigar[SALT_MAX_CIGAR_OPS]; };
+struct PePair { uint32_t req0; uint8_t n_req; uint8_t rescued[2]; uint8_t pad; };             // requests req0 .. req0+n_req-1, in the order tried
+void launch_pair(uint32_t n_pairs, uint32_t min_tlen, uint32_t max_tlen, uint32_t l_pac, const uint32_t *offs, salt_result_t *res,
+                 PePair *pairs, PeSwReq *req, uint32_t *pctl, hipStream_t st);
+void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, const uint32_t *offs, const PeSwReq *req, const uint32_t *pctl,
+               PeSwRes *res, uint32_t *head, uint8_t *scratch, uint32_t n_blocks, hipStream_t st);
+void launch_pe_final(const IndexView &ix, uint32_t n_pairs, const uint8_t *seqs, const uint32_t *offs, salt_result_t *res, const PePair *pairs,
+                     const PeSwRes *sw, void *lvtab, uint32_t *head, uint32_t n_blocks, hipStream_t st);
+
 uint32_t heavy_blocks_per_cu();
 void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const uint32_t *kdiff, const uint8_t *seqs,
                     const uint32_t *offs, int32_t *out, uint16_t *cig, void *lvtab, hipStream_t st);

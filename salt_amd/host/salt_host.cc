@@ -182,6 +182,7 @@ extern "C" salt_index_t *salt_index_load(const char *prefix_c, int rebuild_lkt)
 extern "C" void salt_index_free(salt_index_t *ix) { delete ix; }
 extern "C" const salt_host_index_t *salt_index_host_view(const salt_index_t *ix) { return &ix->view; }
 extern "C" int32_t salt_index_seed_len(const salt_index_t *ix) { return ix->seed_len; }
+extern "C" const uint8_t *salt_index_pac(const salt_index_t *ix, uint64_t *l_pac) { if (l_pac) *l_pac = (uint64_t)ix->l_pac; return ix->pac.data(); }
 extern "C" int32_t salt_index_n_seqs(const salt_index_t *ix) { return (int32_t)ix->anns.size(); }
 
 // ---------------------------------------------------------------------------------------------
@@ -217,6 +218,60 @@ inline uint32_t mask_at(const salt_index *ix, uint32_t l) { return (ix->ref[l >>
 void put_cigar(Out &o, const uint16_t *ops, int n)
 {
     for (int i = 0; i < n; ++i) { o.putu(ops[i] >> 4); o.put("MID?"[ops[i] & 3]); }
+}
+
+void put_xa(Out &o, const salt_index *ix, const salt_sam_opt_t *opt, int L, const salt_result_t *q)
+{
+    // XA (sam.c:186-240)
+    bool first = true; int h = 0;
+    for (int s = 0; s < 2; ++s)
+        for (int i = 0; i < q->n_hits[s]; ++i, ++h) {
+            const salt_hit_t &hit = q->hits[s][i];
+            if (hit.pos == q->pos) continue;
+            if (first) { o.puts("\tXA:Z:"); first = false; }
+            int r2 = seq_id(ix, hit.pos);
+            o.puts(ix->anns[r2].name.c_str()); o.put(','); o.put("+-"[s]);
+            o.putu((uint64_t)((int64_t)hit.pos - ix->anns[r2].offset + 1)); o.put(',');
+            if (opt->print_xa_cigar) {
+                if (hit.is_gap) put_cigar(o, q->hit_cigar[h], q->hit_n_cigar[h]);
+                else { o.putu((uint64_t)L); o.put('M'); }
+                o.put(',');
+            } else o.puts("*,");
+            o.putu(hit.n_diff); o.put(';');
+        }
+}
+
+void put_md_nm(Out &o, const salt_index *ix, const uint8_t *sq, const salt_result_t *q)
+{
+    static const char NT[] = "ACGTN";
+    // MD / NM / XV against the 2-bit pac (sam.c:246-328)
+    {
+        int nm = 0, n_match = 0, n_rs = 0, rsv[64];
+        uint32_t rp = q->pos; int si = q->seq_start;
+        o.puts("\tMD:Z:");
+        for (int c = 0; c < q->n_cigar; ++c) {
+            int n = q->cigar[c] >> 4, op = q->cigar[c] & 15;
+            if (op == 0) {
+                for (int i = 0; i < n; ++i, ++rp, ++si) {
+                    uint32_t bt = pac_at(ix, rp);
+                    if (bt == sq[si]) { ++n_match; continue; }
+                    if (sq[si] < 5 && (mask_at(ix, rp) & (1u << sq[si])) != 0 && n_rs < 64) rsv[n_rs++] = si - q->seq_start;
+                    ++nm;
+                    if (n_match) o.putu((uint64_t)n_match);
+                    n_match = 0;
+                    o.put(NT[bt]);
+                }
+            } else if (op == 1) { nm += n; si += n; }
+            else if (op == 2) {
+                if (n_match) o.putu((uint64_t)n_match);
+                n_match = 0; nm += n; o.put('^');
+                for (int i = 0; i < n; ++i, ++rp) o.put(NT[pac_at(ix, rp)]);
+            }
+        }
+        if (n_match) o.putu((uint64_t)n_match);
+        o.puts("\tNM:i:"); o.putu((uint64_t)nm);
+        if (n_rs > 0) { o.puts("\tXV:i:"); for (int i = 0; i < n_rs; ++i) { if (i) o.put(','); o.putu((uint64_t)rsv[i]); } }
+    }
 }
 
 } // namespace
@@ -262,51 +317,68 @@ extern "C" int salt_sam_se(const salt_index_t *ix, const salt_sam_opt_t *opt, co
     o.put('\t');
     if (q->strand) { if (qual) for (int i = L - 1; i >= 0; --i) o.put(qual[i]); else o.put('*'); }
     else o.puts(qual && qual[0] ? qual : "*");
-    // XA (sam.c:186-240)
-    bool first = true; int h = 0;
-    for (int s = 0; s < 2; ++s)
-        for (int i = 0; i < q->n_hits[s]; ++i, ++h) {
-            const salt_hit_t &hit = q->hits[s][i];
-            if (hit.pos == q->pos) continue;
-            if (first) { o.puts("\tXA:Z:"); first = false; }
-            int r2 = seq_id(ix, hit.pos);
-            o.puts(ix->anns[r2].name.c_str()); o.put(','); o.put("+-"[s]);
-            o.putu((uint64_t)((int64_t)hit.pos - ix->anns[r2].offset + 1)); o.put(',');
-            if (opt->print_xa_cigar) {
-                if (hit.is_gap) put_cigar(o, q->hit_cigar[h], q->hit_n_cigar[h]);
-                else { o.putu((uint64_t)L); o.put('M'); }
-                o.put(',');
-            } else o.puts("*,");
-            o.putu(hit.n_diff); o.put(';');
-        }
-    // MD / NM / XV against the 2-bit pac (sam.c:246-328)
-    if (opt->print_nm_md) {
-        int nm = 0, n_match = 0, n_rs = 0, rsv[64];
-        uint32_t rp = q->pos; int si = q->seq_start;
-        o.puts("\tMD:Z:");
-        for (int c = 0; c < q->n_cigar; ++c) {
-            int n = q->cigar[c] >> 4, op = q->cigar[c] & 15;
-            if (op == 0) {
-                for (int i = 0; i < n; ++i, ++rp, ++si) {
-                    uint32_t bt = pac_at(ix, rp);
-                    if (bt == sq[si]) { ++n_match; continue; }
-                    if (sq[si] < 5 && (mask_at(ix, rp) & (1u << sq[si])) != 0 && n_rs < 64) rsv[n_rs++] = si - q->seq_start;
-                    ++nm;
-                    if (n_match) o.putu((uint64_t)n_match);
-                    n_match = 0;
-                    o.put(NT[bt]);
-                }
-            } else if (op == 1) { nm += n; si += n; }
-            else if (op == 2) {
-                if (n_match) o.putu((uint64_t)n_match);
-                n_match = 0; nm += n; o.put('^');
-                for (int i = 0; i < n; ++i, ++rp) o.put(NT[pac_at(ix, rp)]);
-            }
-        }
-        if (n_match) o.putu((uint64_t)n_match);
-        o.puts("\tNM:i:"); o.putu((uint64_t)nm);
-        if (n_rs > 0) { o.puts("\tXV:i:"); for (int i = 0; i < n_rs; ++i) { if (i) o.put(','); o.putu((uint64_t)rsv[i]); } }
-    }
+    put_xa(o, ix, opt, L, q);
+    if (opt->print_nm_md) put_md_nm(o, ix, sq, q);
     if (opt->rg_id) { o.puts("\tRG:Z:"); o.puts(opt->rg_id); }
+    return o.done();
+}
+
+// alnpe_sam (sam.c:331-457): both records of pair; each is followed by "\n\n" exactly as the reference's driver
+// prints them (the record's own newline plus the printf("%s\n") around it, alnpe.c:640-648)
+extern "C" int salt_sam_pe(const salt_index_t *ix, const salt_sam_opt_t *opt, const salt_pe_opt_t *pe, const char *const name[2],
+                           const uint8_t *const seq[2], const int32_t l_seq[2], const char *const qual[2],
+                           const salt_result_t *q, char *buf, size_t cap)
+{
+    Out o{ buf, 0, cap, false };
+    static const char NT[] = "ACGTN";
+    int rid[2] = { -1, -1 }, tlen = 0;
+    bool is_map[2] = { false, false };
+    uint32_t pos[2] = { 0, 0 };
+    for (int i = 0; i < 2; ++i)
+        if (q[i].pos != 0xFFFFFFFFu) { is_map[i] = true; rid[i] = seq_id(ix, q[i].pos); pos[i] = q[i].pos - (uint32_t)ix->anns[rid[i]].offset + 1; }
+    if (is_map[0] && is_map[1]) {
+        if (rid[0] != rid[1]) tlen = 0;
+        else if (pos[0] < pos[1]) tlen = (int)(pos[1] + q[1].seq_end - q[1].seq_start + 1 - pos[0]);
+        else tlen = (int)(pos[0] + q[0].seq_end - q[1].seq_start + 1 - pos[1]);              // sam.c:355-356: q[1].seq_start in both arms
+        if ((uint32_t)tlen > pe->max_tlen || (uint32_t)tlen < pe->min_tlen) tlen = 0;
+    }
+    for (int i = 0; i < 2; ++i) {
+        const int L = l_seq[i];
+        std::vector<uint8_t> rs((size_t)L);
+        for (int k = 0; k < L; ++k) { uint8_t c = seq[i][L - 1 - k]; rs[k] = c < 4 ? (uint8_t)(3 - c) : c; }
+        unsigned flag = 0x1;
+        if (!is_map[i]) flag |= 0x4;
+        if (!is_map[1 - i]) flag |= 0x8;
+        if (q[i].strand == 1) flag |= 0x10;
+        if (q[1 - i].strand == 1) flag |= 0x20;
+        if (tlen != 0) flag |= 0x2;
+        flag |= i == 0 ? 0x40 : 0x80;
+        o.puts(name[i]); o.put('\t'); o.putu(flag); o.put('\t');
+        if (is_map[i]) {
+            o.puts(ix->anns[rid[i]].name.c_str()); o.put('\t'); o.putu(pos[i]); o.put('\t'); o.putu(q[i].mapq); o.put('\t');
+            if (q[i].seq_start != 0) { o.putu(q[i].seq_start); o.put('S'); }
+            put_cigar(o, q[i].cigar, q[i].n_cigar);
+            if (q[i].seq_end != (uint32_t)L - 1) { o.putu((uint64_t)(L - (int)q[i].seq_end - 1)); o.put('S'); }
+            o.put('\t');
+        } else if (is_map[1 - i]) { o.puts(ix->anns[rid[1 - i]].name.c_str()); o.put('\t'); o.putu(pos[1 - i]); o.puts("\t255\t*\t"); }
+        else o.puts("*\t0\t255\t*\t");
+        if (is_map[1 - i]) {
+            if (rid[i] == rid[1 - i] || !is_map[i]) o.puts("=\t"); else { o.puts(ix->anns[rid[1 - i]].name.c_str()); o.put('\t'); }
+            o.putu(pos[1 - i]); o.put('\t');
+        } else o.puts("*\t0\t");
+        if (tlen != 0) { if (q[i].pos >= q[1 - i].pos) o.put('-'); o.putu((uint64_t)tlen); o.put('\t'); }
+        else o.puts("0\t");
+        const uint8_t *sq = q[i].strand == 1 ? rs.data() : seq[i];
+        for (int k = 0; k < L; ++k) o.put(NT[sq[k] > 4 ? 4 : sq[k]]);
+        o.put('\t');
+        const bool has_q = qual[i] && qual[i][0];
+        if (!has_q) o.put('*');
+        else if (q[i].strand == 1) for (int k = L - 1; k >= 0; --k) o.put(qual[i][k]);
+        else o.puts(qual[i]);
+        put_xa(o, ix, opt, L, &q[i]);
+        if (opt->print_nm_md && is_map[i]) put_md_nm(o, ix, q[i].strand == 0 ? seq[i] : rs.data(), &q[i]);
+        if (opt->rg_id) { o.puts("\tRG:Z:"); o.puts(opt->rg_id); }
+        o.puts("\n\n");
+    }
     return o.done();
 }

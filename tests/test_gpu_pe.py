@@ -1,0 +1,113 @@
+"""GPU parity for the paired-end path (alnpe_core1: per-mate alnse_overlap, pairing2 / pairing_singleton, SSW mate
+rescue, alnpe_sam), through the C ABI: against the reference's own SAM output and its ssw.c known answers."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, LAMBDA, read_cases
+
+pytestmark = pytest.mark.gpu
+
+PE_CASES = [c for c in read_cases() if c.startswith("pe_")]
+
+
+@pytest.fixture(scope="module")
+def lam_pe():
+    import salt_amd
+    idx = salt_amd.Index.reload(os.path.join(LAMBDA, "idx"))
+    aln = salt_amd.GpuAligner(idx, device=0, max_reads=4096)
+    reads = salt_amd.interleave_pairs(salt_amd.read_fastq(os.path.join(LAMBDA, "reads_pe_1.fq")),
+                                      salt_amd.read_fastq(os.path.join(LAMBDA, "reads_pe_2.fq")))
+    yield salt_amd, idx, aln, reads
+    aln.close()
+    idx.destroy()
+
+
+def _diff_report(got, want):
+    g, w = got.split(b"\n"), want.split(b"\n")
+    bad = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]
+    msg = "\n".join("line %d\n  got  %r\n  want %r" % (i, g[i][:500], w[i][:500]) for i in bad[:6])
+    return "%d differing lines (of %d / %d)\n%s" % (len(bad), len(g), len(w), msg)
+
+
+@pytest.mark.parametrize("case", PE_CASES)
+def test_gpu_pe_sam_matches_reference_golden(case, lam_pe):
+    salt_amd, idx, aln, (names, seqs, offs, quals) = lam_pe
+    opt, _ = salt_amd.AlnOpt.from_argv(read_cases()[case], idx.l_seed)
+    assert opt.paired
+    res = aln.alnpe_core1(opt, idx, seqs, offs)
+    got = salt_amd.sam_text_pe(idx, opt, names, seqs, offs, quals, res)
+    want = open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
+    if got != want:
+        pytest.fail(_diff_report(got, want))
+
+
+def test_gpu_pe_small_batches_equal_one_batch(lam_pe):
+    """Pairs are independent: a workspace that holds 64 mates at a time gives the same rows as one big batch."""
+    salt_amd, idx, aln, (names, seqs, offs, quals) = lam_pe
+    opt, _ = salt_amd.AlnOpt.from_argv(read_cases()["pe_default"], idx.l_seed)
+    n = 600
+    whole = aln.alnpe_core1(opt, idx, seqs[:offs[n]], offs[:n + 1])
+    small = salt_amd.GpuAligner(idx, device=0, max_reads=64)
+    try:
+        parts = small.alnpe_core1(opt, idx, seqs[:offs[n]], offs[:n + 1])
+    finally:
+        small.close()
+    for f in ("pos", "strand", "n_diff", "is_gap", "mapq", "b0", "b1", "seq_start", "seq_end", "n_hits", "n_cigar"):
+        assert np.array_equal(whole[f], parts[f]), f
+    a = salt_amd.sam_text_pe(idx, opt, names[:n], seqs, offs[:n + 1], quals[:n], whole)     # CIGARs, XA lists
+    b = salt_amd.sam_text_pe(idx, opt, names[:n], seqs, offs[:n + 1], quals[:n], parts)
+    assert a == b
+
+
+def test_gpu_ssw_unit_matches_reference_vectors():
+    """k_sw (striped word kernel emulated on 8 lanes, second best, reverse pass, banded traceback) against the
+    answers the reference's ssw.c printed for 600 windows, both score matrices (tests/golden/ssw_vectors.txt)."""
+    import salt_amd
+    lib = salt_amd.gpu_lib()
+    lib.salt_gpu_diag_ssw.argtypes = [ctypes.c_uint32] + [ctypes.c_void_p] * 8
+    aware, refs, reads, want, roff, qoff = [], [], [], [], [0], [0]
+    with open(os.path.join(GOLDEN, "ssw_vectors.txt")) as f:
+        for line in f:
+            t = line.split()
+            aware.append(int(t[1]))
+            refs.append(np.array([int(c, 16) for c in t[2]], dtype=np.uint8))
+            reads.append(np.frombuffer(t[3].encode(), dtype=np.uint8) - 48)
+            want.append(([int(x) for x in t[4:10]], t[10]))
+            roff.append(roff[-1] + len(refs[-1])); qoff.append(qoff[-1] + len(reads[-1]))
+    n = len(aware)
+    assert n == 600
+    aw = np.array(aware, dtype=np.uint8)
+    rs, qs = np.concatenate(refs), np.concatenate(reads).astype(np.uint8)
+    ro, qo = np.array(roff, dtype=np.uint32), np.array(qoff, dtype=np.uint32)
+    out6 = np.zeros((n, 6), dtype=np.int32)
+    cig = np.zeros((n, 64), dtype=np.uint16)
+    ncig = np.zeros(n, dtype=np.uint16)
+    rc = lib.salt_gpu_diag_ssw(n, aw.ctypes.data, rs.ctypes.data, ro.ctypes.data, qs.ctypes.data, qo.ctypes.data,
+                               out6.ctypes.data, cig.ctypes.data, ncig.ctypes.data)
+    assert rc == 0, lib.salt_gpu_last_error()
+    for i in range(n):
+        w6, wc = want[i]
+        assert [int(x) for x in out6[i]] == w6, (i, out6[i], w6)
+        got = "".join("%d%s" % (int(x) >> 4, "MID"[int(x) & 3]) for x in cig[i, :int(ncig[i])]) or "-"
+        assert got == wc, (i, got, wc)
+
+
+def test_gpu_pe_needs_even_mates_and_pac(lam_pe):
+    salt_amd, idx, aln, (names, seqs, offs, quals) = lam_pe
+    opt, _ = salt_amd.AlnOpt.from_argv(["-p"], idx.l_seed)
+    with pytest.raises(salt_amd.SaltError):
+        aln.alnpe_core1(opt, idx, seqs[:offs[3]], offs[:4])
+    fresh = salt_amd.GpuAligner(idx, device=0, max_reads=64)
+    try:
+        lib = salt_amd.gpu_lib()
+        co, pe = opt._c(), opt._pe()
+        res = np.zeros(2, dtype=salt_amd.RESULT_DTYPE)
+        o = offs[:3].astype(np.uint32)
+        s = np.ascontiguousarray(seqs[:offs[2]])
+        rc = lib.salt_gpu_align_pe(fresh._ws, ctypes.byref(co), ctypes.byref(pe), 1, s.ctypes.data, o.ctypes.data, res.ctypes.data)
+        assert rc != 0 and b"pac" in lib.salt_gpu_last_error()
+    finally:
+        fresh.close()
