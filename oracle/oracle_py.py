@@ -41,6 +41,8 @@ def lib():
     L.so_opt_default.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Opt)]
     L.so_align_se_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Opt), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.so_align_pe_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Opt), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     return L
 
 
@@ -71,6 +73,16 @@ class Oracle:
             return res, dict(zip(CTR_FIELDS, [int(x) for x in ctr]))
         return res
 
+    def align_pe(self, opt, seqs, offs, min_tlen=250, max_tlen=550, n_threads=1):
+        """Mates interleaved (pair i = reads 2i, 2i+1) -> RESULT[2 * n_pairs] after pairing / rescue."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint32)
+        n = len(offs) - 1
+        res = np.zeros(n, dtype=RESULT)
+        self.L.so_align_pe_batch(self.h, ctypes.byref(opt), min_tlen, max_tlen, n // 2, seqs.ctypes.data, offs.ctypes.data,
+                                 res.ctypes.data, n_threads)
+        return res
+
     def close(self):
         if self.h:
             self.L.so_index_free(self.h)
@@ -81,10 +93,15 @@ def cigar_text(ops, n):
     return "".join("%d%s" % (int(x) >> 4, "MID"[int(x) & 3]) for x in ops[:n])
 
 
-def compare(gpu_res, ora_res):
+def compare(gpu_res, ora_res, pe=False):
     """Field-by-field comparison of salt_amd.RESULT_DTYPE rows with oracle RESULT rows.
-    Returns the indices of the reads that differ."""
+    Returns the indices of the reads that differ.  pe: rows after pairing (soft clips and the CIGAR text of
+    rescued mates are compared too)."""
     bad = np.zeros(len(ora_res), dtype=bool)
+    if pe:
+        mapped = ora_res["pos"] != 0xFFFFFFFF
+        for f in ("seq_start", "seq_end"):
+            bad |= mapped & (gpu_res[f].astype(np.uint32) != ora_res[f])
     bad |= gpu_res["pos"] != ora_res["pos"]
     bad |= gpu_res["strand"].astype(np.int32) != ora_res["strand"]
     for f in ("n_diff", "is_gap", "mapq", "b0", "b1"):
@@ -98,7 +115,10 @@ def compare(gpu_res, ora_res):
     mapped = np.nonzero((ora_res["pos"] != 0xFFFFFFFF) & ~bad)[0]
     # CIGARs: cheap check first (gap-free = one op), full text for the gapped ones
     for i in mapped:
-        if ora_res["is_gap"][i] == 0:
+        if pe:
+            if cigar_text(gpu_res["cigar"][i], int(gpu_res["n_cigar"][i])) != ora_res["cigar"][i].decode():
+                bad[i] = True
+        elif ora_res["is_gap"][i] == 0:
             if gpu_res["n_cigar"][i] != 1:
                 bad[i] = True
         elif cigar_text(gpu_res["cigar"][i], int(gpu_res["n_cigar"][i])) != ora_res["cigar"][i].decode():

@@ -1584,6 +1584,34 @@ void so_align_pe1(const so_index_t *ix, const so_opt_t *o, uint32_t min_tlen, ui
     free(m[0].rseq); free(m[1].rseq); aux_free(&a0); aux_free(&a1);
 }
 
+/* pairs interleaved (pair i = reads 2i, 2i+1); static interleave over threads like alnpe_core1's workers (alnpe.c:490) */
+typedef struct { const so_index_t *ix; const so_opt_t *o; uint32_t lo, hi; int n, tid, nt; const uint8_t *seqs; const uint32_t *offs; so_result_t *res; } so_pejob_t;
+static void *pe_worker(void *p)
+{
+    so_pejob_t *j = p; int i;
+    for (i = j->tid; i < j->n; i += j->nt) {
+        const uint32_t *f = j->offs + 2 * i;
+        so_align_pe1(j->ix, j->o, j->lo, j->hi, j->seqs + f[0], (int)(f[1] - f[0]), j->seqs + f[1], (int)(f[2] - f[1]), j->res + 2 * i);
+    }
+    return NULL;
+}
+void so_align_pe_batch(const so_index_t *ix, const so_opt_t *o, uint32_t min_tlen, uint32_t max_tlen, int n_pairs, const uint8_t *seqs,
+                       const uint32_t *offs, so_result_t *res, int n_threads)
+{
+    int t;
+    if (n_threads < 1) n_threads = 1;
+    so_pejob_t *jobs = xcalloc((size_t)n_threads, sizeof *jobs);
+    pthread_t *th = xcalloc((size_t)n_threads, sizeof *th);
+    score_mat2_init();                                        /* once, before the workers read it */
+    for (t = 0; t < n_threads; ++t) {
+        so_pejob_t jb = { ix, o, min_tlen, max_tlen, n_pairs, t, n_threads, seqs, offs, res };
+        jobs[t] = jb;
+        if (n_threads == 1) pe_worker(jobs + t); else pthread_create(th + t, NULL, pe_worker, jobs + t);
+    }
+    for (t = 0; t < n_threads && n_threads > 1; ++t) pthread_join(th[t], NULL);
+    free(jobs); free(th);
+}
+
 /* alnpe_sam (sam.c:331-457): both records of a pair, each followed by '\n' (the driver's printf adds another) */
 int so_sam_pe(const so_index_t *ix, const so_opt_t *o, uint32_t min_tlen, uint32_t max_tlen, const char *const name[2],
               const uint8_t *const seq[2], const int l_seq[2], const char *const qual[2], const so_result_t q[2], char *buf, size_t cap)

@@ -109,6 +109,8 @@ typedef struct {
     uint32_t ref_len; const uint32_t *ref;
     uint64_t l_pac; const uint8_t *pac;
 } so_arrays_t;
+void so_align_pe_batch(const so_index_t *, const so_opt_t *, uint32_t min_tlen, uint32_t max_tlen, int n_pairs, const uint8_t *seqs,
+                       const uint32_t *offs, so_result_t *res, int n_threads);
 void so_index_arrays(const so_index_t *, so_arrays_t *);
 
 #ifdef __cplusplus

@@ -7,7 +7,8 @@
 //   formatter threads (-t) : SAM text per read                              (aln_samse, sam.c:87-182)
 //   writer : records in input order                                         (the puts() loop, alnse.c:1433-1439)
 // Extra long options (not in the reference): --gpus N (default 1).
-// Flags the reference parses but ignores stay ignored (-n -e -M -O -E -l -X); -p is rejected for now.
+// Flags the reference parses but ignores stay ignored (-n -e -M -O -E -l -X).  -p <mate1> <mate2>: paired end
+// (alnpe_core, Align_src/alnpe.c:530-661) through salt_gpu_align_pe.
 #include "../../include/salt_host.h"
 #include <getopt.h>
 #include <zlib.h>
@@ -37,6 +38,7 @@ struct Batch {
     std::vector<uint32_t> offs{ 0 };
     std::vector<salt_result_t> res;
     std::string sam;
+    std::unique_ptr<Batch> mate;              // -p: the second file's records of the same pairs
     int n() const { return (int)name.size(); }
 };
 
@@ -116,6 +118,35 @@ void format_batch(const salt_index_t *ix, const salt_sam_opt_t *so, Batch &b, in
     for (auto &p : part) b.sam += p;
 }
 
+// -p: both SAM records of every pair (alnpe_sam, sam.c:331-457); res holds the mates interleaved
+void format_batch_pe(const salt_index_t *ix, const salt_sam_opt_t *so, const salt_pe_opt_t *po, Batch &b, int n_threads)
+{
+    const int n = b.n();
+    const Batch &m = *b.mate;
+    std::vector<std::string> part((size_t)n_threads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t)
+        th.emplace_back([&, t]() {
+            std::vector<char> buf(1 << 17);
+            int lo = (int)((long)n * t / n_threads), hi = (int)((long)n * (t + 1) / n_threads);
+            std::string &out = part[(size_t)t];
+            out.reserve((size_t)(hi - lo) * 900);
+            for (int i = lo; i < hi; ++i) {
+                const char *nm[2] = { b.raw.data() + b.name[i], m.raw.data() + m.name[i] };
+                const char *ql[2] = { b.raw.data() + b.qual[i], m.raw.data() + m.qual[i] };
+                const uint8_t *sq[2] = { b.seqs.data() + b.offs[i], m.seqs.data() + m.offs[i] };
+                const int32_t ls[2] = { (int32_t)(b.offs[i + 1] - b.offs[i]), (int32_t)(m.offs[i + 1] - m.offs[i]) };
+                if ((size_t)(ls[0] + ls[1]) * 8 + 16384 > buf.size()) buf.resize((size_t)(ls[0] + ls[1]) * 8 + 16384);
+                int w = salt_sam_pe(ix, so, po, nm, sq, ls, ql, &b.res[2 * (size_t)i], buf.data(), buf.size());
+                if (w < 0) { fprintf(stderr, "[salt] SAM record too long for pair %s\n", nm[0]); exit(1); }
+                out.append(buf.data(), (size_t)w);
+            }
+        });
+    for (auto &t : th) t.join();
+    b.sam.clear();
+    for (auto &p : part) b.sam += p;
+}
+
 void parse_batch(std::vector<char> &raw, Batch &b, int n_threads)
 {
     // line starts of every record (serial scan), then per-thread parsing of record ranges
@@ -188,9 +219,11 @@ int usage()
             "           -v, --ref                    only seed on the primary reference\n"
             "           -s, --max_seed      <int>    max seed occ [50]\n"
             "           -m, --max_locate    <int>    max loci per strand [1000]\n"
-            "           -p, --pe                     paired end mode (not available on the GPU path yet)\n"
+            "           -p, --pe                     paired end mode (two read files)\n"
+            "           -a, --min_tlen      <int>    min template length [250]\n"
+            "           -b, --max_tlen      <int>    max template length [550]\n"
             "               --gpus          <int>    GPUs to shard batches over [1]\n"
-            "           (-n -e -l -a -b -M -O -E -X are accepted and ignored like in the reference)\n\n");
+            "           (-n -e -l -M -O -E -X are accepted and ignored like in the reference)\n\n");
     return 1;
 }
 
@@ -202,6 +235,7 @@ int main(int argc, char **argv)
     salt_aln_opt_t ao; memset(&ao, 0, sizeof ao);
     ao.max_seed = 50; ao.max_locate = 1000; ao.max_hits = 5;             // aln.c:46-47, aln.h:133
     salt_sam_opt_t so; memset(&so, 0, sizeof so);
+    salt_pe_opt_t po = { 250, 550 };                                       // aln.c:43-44
     std::string cmd;
     for (int i = 0; i < argc; ++i) { if (i) cmd += " "; cmd += argv[i]; }
     static const struct option lo[] = {
@@ -221,17 +255,18 @@ int main(int argc, char **argv)
         case 'v': ao.seed_only_ref = 1; break;
         case 'r': overlap = atoi(optarg); break;
         case 'p': pe = 1; break;
+        case 'a': po.min_tlen = (uint32_t)atoi(optarg); break;
+        case 'b': po.max_tlen = (uint32_t)atoi(optarg); break;
         case 1000: n_gpus = atoi(optarg); break;
         case 'h': return usage();
         case '?': fprintf(stderr, "[ERROR]: no arg %c\n", optopt); return 1;
         default: break;
         }
     }
-    if (optind + 2 > argc) { fprintf(stderr, "[opt_parse]: index prefix and read file can't be omited!\n"); return 1; }
-    if (pe) { fprintf(stderr, "[salt] paired-end mode is not available on the GPU path yet\n"); return 1; }
+    if (optind + 2 + pe > argc) { fprintf(stderr, "[opt_parse]: index prefix and read file can't be omited!\n"); return 1; }
     if (n_threads < 1) n_threads = 1;
     if (n_gpus < 1) n_gpus = 1;
-    const char *prefix = argv[optind], *fn_reads = argv[optind + 1];
+    const char *prefix = argv[optind], *fn_reads = argv[optind + 1], *fn_mates = pe ? argv[optind + 2] : nullptr;
 
     double t0 = now();
     fprintf(stderr, "[alnse_core]:  Reload index...\n");
@@ -244,6 +279,11 @@ int main(int argc, char **argv)
     std::vector<salt_gpu_index_t *> gix((size_t)n_gpus, nullptr);
     if (salt_gpu_index_attach(salt_index_host_view(ix), 0, &gix[0])) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
     if (salt_gpu_index_replicate(gix[0], devs.data(), n_gpus, gix.data())) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
+    if (pe) {                                             // the singleton rescue aligns against the 2-bit genome (alnpe.c:327-393)
+        uint64_t l_pac = 0; const uint8_t *pac = salt_index_pac(ix, &l_pac);
+        for (int i = 0; i < n_gpus; ++i)
+            if (salt_gpu_index_set_pac(gix[(size_t)i], pac, l_pac)) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
+    }
     const int WPG = 2;                                    // workers per GPU: one batch on the device while another is parsed / formatted
     std::vector<salt_gpu_ws_t *> ws((size_t)n_gpus * WPG, nullptr);
     for (int i = 0; i < n_gpus * WPG; ++i)
@@ -254,6 +294,12 @@ int main(int argc, char **argv)
     gzFile fp = gzopen(fn_reads, "r");
     if (!fp) { fprintf(stderr, "[query_open]: file %s open fail!\n", fn_reads); return 1; }
     gzbuffer(fp, 1 << 20);
+    gzFile fp2 = nullptr;
+    if (pe) {
+        fp2 = gzopen(fn_mates, "r");
+        if (!fp2) { fprintf(stderr, "[query_open]: file %s open fail!\n", fn_mates); return 1; }
+        gzbuffer(fp2, 1 << 20);
+    }
 
     {   // header (aln_samhead, sam.c:56-84)
         std::vector<char> hb(1 << 20);
@@ -276,6 +322,8 @@ int main(int argc, char **argv)
     double t_write = 0, t_read = 0;
     std::thread reader([&]() {
         RawReader rr(fp);
+        std::unique_ptr<RawReader> rr2(pe ? new RawReader(fp2) : nullptr);
+        const int per_batch = pe ? N_SEQS / 2 : N_SEQS;    // pairs per batch: N_SEQS mates (query_read_multiPairedSeqs, query.c:252-268)
         long seq_no = 0;
         for (;;) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return inflight < max_inflight || failed; }); if (failed) break; }
@@ -283,7 +331,13 @@ int main(int argc, char **argv)
             b->seq_no = seq_no;
             b->raw.reserve((size_t)N_SEQS * 260);
             double tr0 = now();
-            if (rr.take(b->raw, N_SEQS) == 0) b.reset();
+            const int got = rr.take(b->raw, per_batch);
+            if (pe && got) {
+                b->mate = std::make_unique<Batch>();
+                b->mate->raw.reserve((size_t)per_batch * 260);
+                if (rr2->take(b->mate->raw, got) != got) { fprintf(stderr, "[salt] the two read files hold different numbers of reads\n"); failed = true; }
+            }
+            if (got == 0 || failed) b.reset();
             t_read += now() - tr0;
             std::unique_lock<std::mutex> lk(mu);
             if (!b) { eof = true; cv.notify_all(); break; }
@@ -306,18 +360,33 @@ int main(int argc, char **argv)
                 }
                 double tp0 = now();
                 parse_batch(b->raw, *b, fmt_threads);
+                std::vector<uint8_t> iseq; std::vector<uint32_t> ioff;
+                if (pe && b->n()) {                              // interleave the mates: pair i = reads 2i, 2i+1
+                    Batch &m = *b->mate;
+                    parse_batch(m.raw, m, fmt_threads);
+                    if (m.n() != b->n()) { fprintf(stderr, "[salt] the two read files hold different numbers of reads\n"); failed = true; cv.notify_all(); break; }
+                    const size_t n = (size_t)b->n();
+                    ioff.resize(2 * n + 1); ioff[0] = 0;
+                    iseq.resize(b->seqs.size() + m.seqs.size());
+                    for (size_t i = 0; i < n; ++i) {
+                        const uint32_t l0 = b->offs[i + 1] - b->offs[i], l1 = m.offs[i + 1] - m.offs[i];
+                        memcpy(iseq.data() + ioff[2 * i], b->seqs.data() + b->offs[i], l0); ioff[2 * i + 1] = ioff[2 * i] + l0;
+                        memcpy(iseq.data() + ioff[2 * i + 1], m.seqs.data() + m.offs[i], l1); ioff[2 * i + 2] = ioff[2 * i + 1] + l1;
+                    }
+                }
                 t_parse = t_parse + (now() - tp0);
                 if (b->n() == 0) { std::unique_lock<std::mutex> lk(mu); done.push_back(std::move(b)); cv.notify_all(); continue; }
-                b->res.resize((size_t)b->n());
+                b->res.resize((size_t)b->n() * (pe ? 2 : 1));
                 double tg0 = now();
-                int grc = salt_gpu_align_se(ws[(size_t)g], &ao, (uint32_t)b->n(), b->seqs.data(), b->offs.data(), b->res.data());
+                int grc = pe ? salt_gpu_align_pe(ws[(size_t)g], &ao, &po, (uint32_t)b->n(), iseq.data(), ioff.data(), b->res.data())
+                             : salt_gpu_align_se(ws[(size_t)g], &ao, (uint32_t)b->n(), b->seqs.data(), b->offs.data(), b->res.data());
                 t_gpu = t_gpu + (now() - tg0);
                 if (grc) {
                     fprintf(stderr, "[salt] %s\n", salt_gpu_last_error());
                     failed = true; cv.notify_all(); break;
                 }
                 double tf0 = now();
-                format_batch(ix, &so, *b, fmt_threads);
+                if (pe) format_batch_pe(ix, &so, &po, *b, fmt_threads); else format_batch(ix, &so, *b, fmt_threads);
                 t_fmt = t_fmt + (now() - tf0);
                 std::unique_lock<std::mutex> lk(mu);
                 done.push_back(std::move(b));
@@ -341,7 +410,7 @@ int main(int argc, char **argv)
         double tw0 = now();
         fwrite(b->sam.data(), 1, b->sam.size(), stdout);
         t_write += now() - tw0;
-        n_tot += b->n(); ++next;
+        n_tot += b->n() * (pe ? 2 : 1); ++next;
         fprintf(stderr, "%ld reads have been aligned!\n", n_tot);
         { std::unique_lock<std::mutex> lk(mu); --inflight; cv.notify_all(); }
     }
@@ -353,6 +422,7 @@ int main(int argc, char **argv)
     fprintf(stderr, "[salt] host phases (s, summed over workers): read %.3f parse %.3f gpu-call %.3f format %.3f write %.3f\n", t_read, t_parse.load(), t_gpu.load(), t_fmt.load(), t_write);
     fprintf(stderr, "[salt] %ld reads, %.3f Mreads/s end to end (FASTQ -> SAM, %d GPU(s), %d host thread(s))\n", n_tot, dt > 0 ? n_tot / dt / 1e6 : 0.0, n_gpus, n_threads);
     gzclose(fp);
+    if (fp2) gzclose(fp2);
     for (int i = 0; i < n_gpus * WPG; ++i) salt_gpu_ws_destroy(ws[(size_t)i]);
     for (int i = n_gpus - 1; i >= 0; --i) salt_gpu_index_detach(gix[(size_t)i]);
     salt_index_free(ix);

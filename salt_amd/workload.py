@@ -125,6 +125,55 @@ def make_reads(genome, pos, mask, n_reads, L, seed=1):
     return reads.reshape(-1), offs, start, strand
 
 
+def make_pairs(genome, pos, mask, n_pairs, L, seed=2, insert_mean=450, insert_sd=35, damaged=0.08, orphan=0.02):
+    """Paired-end reads, mates interleaved (pair i = reads 2i, 2i+1): FR fragments of insert_mean +- insert_sd,
+    listed SNP alleles, 0.5 % substitutions; `damaged` of the second mates get 9 % substitutions and a 2-base
+    deletion (so seed-and-verify misses them and the Smith-Waterman rescue runs), `orphan` of them are random."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = len(genome)
+    isz = np.clip(np.rint(rng.normal(insert_mean, insert_sd, size=n_pairs)).astype(np.int64), 2 * L + 10, insert_mean + 6 * insert_sd)
+    w = int(isz.max()) + 4
+    start = rng.integers(0, n - w, size=n_pairs)
+    idx = start[:, None] + np.arange(w)[None, :]
+    frag = genome[idx]
+    site = np.zeros(n, dtype=np.uint8)
+    site[pos] = mask
+    m = site[idx]
+    has = m != 0
+    mm = m[has]
+    alt = rng.random(len(mm)) < 0.5                      # a listed allele (lowest set bit other than the base, if any)
+    cur = frag[has]
+    other = mm & ~(1 << cur).astype(np.uint8)
+    low = np.zeros(len(mm), dtype=np.uint8)
+    for b in (3, 2, 1, 0):
+        low[((other >> b) & 1).astype(bool)] = b
+    use = alt & (other != 0)
+    cur[use] = low[use]
+    frag[has] = cur
+    e = rng.random(frag.shape) < 0.005
+    frag[e] = (frag[e] + rng.integers(1, 4, size=int(e.sum()))) & 3
+    m1 = frag[:, :L].copy()
+    j = (isz - L)[:, None] + np.arange(L + 4)[None, :]
+    tail = np.take_along_axis(frag, j, axis=1)           # (n_pairs, L+4) ending past the fragment end by <= 4
+    m2f = tail[:, :L].copy()
+    dmg = np.nonzero(rng.random(n_pairs) < damaged)[0]
+    for i in dmg:
+        row = tail[i].copy()
+        ee = rng.random(L + 4) < 0.09
+        row[ee] = (row[ee] + rng.integers(1, 4, size=int(ee.sum()))) & 3
+        p = int(rng.integers(20, L - 20))
+        m2f[i] = np.concatenate([row[:p], row[p + 2:]])[:L]
+    orp = np.nonzero(rng.random(n_pairs) < orphan)[0]
+    m2f[orp] = rng.integers(0, 4, size=(len(orp), L)).astype(np.uint8)
+    m2 = (3 - m2f[:, ::-1]).astype(np.uint8)             # second mate reads the reverse strand
+    flip = rng.random(n_pairs) < 0.5                     # which file holds the forward mate
+    a = np.where(flip[:, None], m2, m1)
+    b = np.where(flip[:, None], m1, m2)
+    reads = np.stack([a, b], axis=1).reshape(-1)
+    offs = (np.arange(2 * n_pairs + 1, dtype=np.uint64) * L).astype(np.uint32)
+    return reads.astype(np.uint8), offs, start, isz
+
+
 def write_fastq(path, seqs, offs, n=None):
     chars = np.frombuffer(b"ACGTN", dtype=np.uint8)
     n = len(offs) - 1 if n is None else n

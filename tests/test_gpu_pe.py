@@ -111,3 +111,57 @@ def test_gpu_pe_needs_even_mates_and_pac(lam_pe):
         assert rc != 0 and b"pac" in lib.salt_gpu_last_error()
     finally:
         fresh.close()
+
+
+@pytest.fixture(scope="module")
+def tiny_pe(tmp_path_factory):
+    """Seeded repeat-bearing genome (salt_amd/workload.py) with FR pairs: 8 % damaged second mates, 2 % orphans."""
+    from salt_amd import workload
+    w = workload.prepare("tiny", str(tmp_path_factory.mktemp("wlpe")))
+    seqs, offs, _, _ = workload.make_pairs(w["genome"], w["snp_pos"], w["snp_mask"], 3000, w["read_len"], seed=11)
+    return w, seqs, offs
+
+
+@pytest.mark.parametrize("optargs", [["-p"], ["-p", "-a", "380", "-b", "520", "-r", "5"], ["-p", "-a", "100", "-b", "460", "-m", "40", "-v"]])
+def test_gpu_pe_fields_match_oracle_on_synthetic_pairs(tiny_pe, optargs):
+    """Every result field of both mates after pairing / rescue (pos, strand, n_diff, is_gap, mapq, SW scores, soft clips,
+    alt hits, CIGAR text) against the CPU oracle on 3000 synthetic pairs; the window options move pairs between the
+    'proper pair', 'pick among alternative hits', 'SNP-aware rescue' and 'singleton rescue' branches."""
+    import sys
+    import salt_amd
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    w, seqs, offs = tiny_pe
+    idx = salt_amd.Index.reload(w["prefix"])
+    opt, _ = salt_amd.AlnOpt.from_argv(optargs, idx.l_seed)
+    aln = salt_amd.GpuAligner(idx, device=0, max_reads=len(offs) - 1)
+    res = aln.alnpe_core1(opt, idx, seqs, offs)
+    aln.close()
+    ora = oracle_py.Oracle(w["prefix"])
+    oo = ora.opt(l_overlap=opt.l_overlap, max_seed=opt.max_seed, max_locate=opt.max_locate, seed_only_ref=opt.seed_only_ref)
+    want = ora.align_pe(oo, seqs, offs, opt.min_tlen, opt.max_tlen, n_threads=8)
+    ora.close()
+    idx.destroy()
+    bad = oracle_py.compare(res, want, pe=True)
+    detail = [(int(i), [(f, res[f][i].tolist(), want[f][i].tolist()) for f in ("pos", "strand", "n_diff", "is_gap", "mapq", "b0", "b1", "seq_start", "seq_end")]) for i in bad[:4]]
+    assert len(bad) == 0, (len(bad), detail)
+    rescued = int(((want["seq_start"] != 0) | (want["seq_end"] != w["read_len"] - 1)).sum())
+    assert (want["pos"] != 0xFFFFFFFF).mean() > 0.9 and rescued > 20, rescued
+
+
+def test_cli_salt_pe_matches_reference_golden(tmp_path):
+    """`salt -p` (C++ CLI) on an index written by salt-idx: the reference's paired-end SAM stream byte for byte."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt, salt_idx = os.path.join(root, "salt_amd", "bin", "salt"), os.path.join(root, "salt_amd", "bin", "salt-idx")
+    if not (os.path.exists(salt) and os.path.exists(salt_idx)):
+        subprocess.run(["make", "-C", os.path.join(root, "salt_amd", "host")], check=True, stdout=subprocess.DEVNULL)
+    prefix = str(tmp_path / "idx")
+    subprocess.run([salt_idx, "-k", "19", os.path.join(LAMBDA, "genome.fa"), os.path.join(LAMBDA, "snps.txt"), prefix],
+                   check=True, stderr=subprocess.DEVNULL)
+    for case, extra in (("pe_default", []), ("pe_r5", ["-t", "4"])):
+        out = subprocess.run([salt] + read_cases()[case] + extra + [prefix, os.path.join(LAMBDA, "reads_pe_1.fq"), os.path.join(LAMBDA, "reads_pe_2.fq")],
+                             check=True, capture_output=True).stdout
+        got = b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+        want = open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
+        assert got == want, (case, _diff_report(got, want))
