@@ -263,6 +263,7 @@ struct CandArgs {                      // everything by value: a by-reference In
     uint32_t ref_len, spr, max_locate, r, L; int strand; bool gap_mode; unsigned long long *phase;
     uint32_t *loci; uint32_t loci_cap; int pe;
 };
+template <bool PE>
 __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, WaveLds &w)
 {
     const uint32_t lane = lane_id();
@@ -272,7 +273,7 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
     struct { gp_u32 c_sa, r_pos; uint32_t ref_len; } ix = { as_global(a.c_sa), as_global(a.r_pos), a.ref_len };
     struct { uint32_t spr, max_locate; } ap = { a.spr, a.max_locate };
     uint32_t n_sa_c = 0, n_sa_r = 0, n_loci_out = 0;
-    uint32_t *const loci = a.loci;
+    uint32_t *const loci = PE ? a.loci : w.loci;
     PhaseClock pc(a.phase);
     const uint64_t base_item = ((uint64_t)r * 2u + (uint32_t)strand) * ap.spr;
     uint32_t n_list[2] = { 0, 0 };
@@ -298,11 +299,11 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
     // and the 0x40000 global cap of alnse_locate (alnse.c:501-629; here bounded by the scratch capacity)
     uint32_t n = 0;
     bool full = false;
-    const uint32_t cap_total = a.pe ? a.loci_cap : ap.max_locate;
+    const uint32_t cap_total = PE ? a.loci_cap : ap.max_locate;
     for (uint32_t i = 0; i < n_list[0] && !full; ++i) {
         const uint32_t sp = w.u.sai.sp[0][i], off = w.u.sai.off[0][i];
         uint32_t ep = w.u.sai.ep[0][i];
-        if (a.pe && ep - sp > ap.max_locate) ep = sp + ap.max_locate;             // j - sp <= max_locate (alnse.c:523)
+        if (PE && ep - sp > ap.max_locate) ep = sp + ap.max_locate;             // j - sp <= max_locate (alnse.c:523)
         for (uint64_t j0 = sp; j0 <= ep && !full; j0 += 64) {
             pc.add(SALT_CTR_X0, 1);
             uint64_t j = j0 + lane;
@@ -331,7 +332,7 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
         if ((int)skip <= 0) skip = 1;
         // PE: an interval wider than max_locate is subsampled with rand() in the reference (alnse.c:587-595), i.e. its
         // result is not defined; the stand-in keeps the first row of every block of (ep-sp)/max_locate rows
-        if (a.pe) skip = ep - sp > ap.max_locate ? (ep - sp) / ap.max_locate : 1;
+        if (PE) skip = ep - sp > ap.max_locate ? (ep - sp) / ap.max_locate : 1;
         for (uint64_t j0 = sp; j0 <= ep && !full; j0 += 64ull * skip) {
             pc.add(SALT_CTR_X1, 1);
             uint64_t j = j0 + (uint64_t)lane * skip;
@@ -652,7 +653,7 @@ struct GapCtx {
 };
 static constexpr uint32_t GAP_DEFER_MIN = 128;    // candidates (both strands) from which the gapped pass is deferred
 
-template <int MODE>
+template <int MODE, bool PE>
 __device__ __forceinline__ void align_general(const IndexView ix, const AlignParams ap, WaveLds &w, const uint32_t r,
                               const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
                               const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r,
@@ -666,9 +667,9 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_lv = 0, c_loci = 0;
     PhaseClock pc(phase);
     const uint64_t rt0 = phase ? __builtin_amdgcn_s_memrealtime() : 0;
-    uint32_t *const loci = ap.pe ? pe_loci : w.loci;          // candidate loci: LDS, or global scratch for PE mates
-    uint8_t *const cand_e = ap.pe ? pe_cand : w.cand_e;
-    const uint32_t loci_cap = ap.pe ? PE_LOCI_CAP : (uint32_t)MAXLOC;
+    uint32_t *const loci = PE ? pe_loci : w.loci;             // candidate loci: LDS, or global scratch for PE mates
+    uint8_t *const cand_e = PE ? pe_cand : w.cand_e;
+    const uint32_t loci_cap = PE ? PE_LOCI_CAP : (uint32_t)MAXLOC;
 
     // ---- load the read, both strands (query.c:177-183, 46-71) ----
     uint32_t n_amb = 0;
@@ -718,7 +719,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     if (MODE == 0 && !too_short)
     for (int strand = 0; strand < 2; ++strand) {
         pc.stamp(SALT_CTR_T_SCAN);
-        const CandStats cs = build_candidates(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, loci, loci_cap, ap.pe }, w);
+        const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, loci, loci_cap, ap.pe }, w);
         pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
         const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
         uint32_t call_best_n = INF, call_best_pos = 0;
@@ -774,10 +775,10 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
 
     // ---- gapped pass (alnse.c:1089-1096): sequential per candidate, LV across lanes ----
     if (!too_short && !found[0] && !found[1]) {
-        int maxd = ap.pe ? 3 : (int)(L / 10);                    // alnse.c:1090 (SE) / alnse.c:1016-1028 (PE keeps 3)
+        int maxd = PE ? 3 : (int)(L / 10);                    // alnse.c:1090 (SE) / alnse.c:1016-1028 (PE keeps 3)
         const int gap_k0 = maxd;
         const bool lanes_fit = gap_k0 <= LLV_K && L + 4 <= 8u * (LLV_TW - 1);
-        if (MODE == 0 && !ap.pe && lanes_fit && g.cap && n_cand_nogap >= GAP_DEFER_MIN) {
+        if (MODE == 0 && !PE && lanes_fit && g.cap && n_cand_nogap >= GAP_DEFER_MIN) {
             uint32_t slot = 0;
             if (lane == 0) slot = atomicAdd(&g.gctl[2], 1u);
             slot = (uint32_t)__shfl((int)slot, 0);
@@ -786,7 +787,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         for (int strand = 0; strand < 2; ++strand) {
             if (MODE == 1 && strand != (int)g.strand) continue;
             pc.stamp(SALT_CTR_T_GAP);
-            const CandStats cs = build_candidates(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, loci, loci_cap, ap.pe }, w);
+            const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, loci, loci_cap, ap.pe }, w);
             pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
             const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
             bool any = false;
@@ -929,7 +930,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
 //   qctl[0] reads queued by k_light      qctl[1] k_heavy head
 //   qctl[2] reads queued for k_gap       qctl[3] k_gap head      qctl[4] k_gapfin head
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool PE>
 __device__ __forceinline__ void persistent_body(const IndexView &ix, const AlignParams &ap, const uint8_t *__restrict__ seqs,
                                                 const uint32_t *__restrict__ offs, const uint4 *__restrict__ sai_c,
                                                 const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
@@ -958,7 +959,7 @@ __device__ __forceinline__ void persistent_body(const IndexView &ix, const Align
         if (MODE == 0) r = ap.all_heavy ? it : queue[it];
         else if (MODE == 1) { const uint32_t per = 2u * (MAXLOC / LLV_N); g.slot = it / per; g.strand = (it % per) / (MAXLOC / LLV_N); g.chunk = it % (MAXLOC / LLV_N); r = gq[g.slot]; }
         else { g.slot = it; r = gq[it]; }
-        align_general<MODE>(ix, ap, w, r, seqs, offs, sai_c, sai_r, results, MODE == 1 ? nullptr : ctr, MODE == 1 ? nullptr : phase, lvtab + blockIdx.x, g,
+        align_general<MODE, PE>(ix, ap, w, r, seqs, offs, sai_c, sai_r, results, MODE == 1 ? nullptr : ctr, MODE == 1 ? nullptr : phase, lvtab + blockIdx.x, g,
                             pe_scr ? reinterpret_cast<uint32_t *>(pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5) : nullptr,
                             pe_scr ? pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5 + (size_t)PE_LOCI_CAP * 4 : nullptr);
         if (MODE == 0 && phase && threadIdx.x == 0) s_phase[SALT_CTR_HEAVY_READS] += 1;
@@ -970,17 +971,18 @@ __device__ __forceinline__ void persistent_body(const IndexView &ix, const Align
     }
 }
 
-#define PERSISTENT_KERNEL(NAME, MODE)                                                                                   \
+#define PERSISTENT_KERNEL(NAME, MODE, PE)                                                                                 \
 __global__ void __launch_bounds__(64)                                                                                   \
 NAME(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,                  \
      const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,             \
      const uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl, unsigned long long *__restrict__ ctr,             \
      LvTables *__restrict__ lvtab, uint32_t *__restrict__ gq, uint8_t *__restrict__ ge, uint32_t gcap,                  \
      uint8_t *__restrict__ pe_scr)                                                                                      \
-{ persistent_body<MODE>(ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, lvtab, gq, ge, gcap, pe_scr); }
-PERSISTENT_KERNEL(k_heavy, 0)
-PERSISTENT_KERNEL(k_gap, 1)
-PERSISTENT_KERNEL(k_gapfin, 2)
+{ persistent_body<MODE, PE>(ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, lvtab, gq, ge, gcap, pe_scr); }
+PERSISTENT_KERNEL(k_heavy, 0, false)
+PERSISTENT_KERNEL(k_gap, 1, false)
+PERSISTENT_KERNEL(k_gapfin, 2, false)
+PERSISTENT_KERNEL(k_heavy_pe, 0, true)          // paired-end mates: PE locate rule, loci in global scratch, gap bound 3, no deferral
 
 // ---------------------------------------------------------------------------------------------
 // k_light: one wave per read, the common case in three memory round trips.
@@ -1389,7 +1391,8 @@ void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint8_t *seq
     if (!ap.n_reads) return;
     uint32_t blocks = n_blocks < ap.n_reads ? n_blocks : ap.n_reads;
     LvTables *tab = static_cast<LvTables *>(lvtab);
-    hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, ap.pe ? 0u : gcap, pe_scr);
+    if (ap.pe) { hipLaunchKernelGGL(k_heavy_pe, dim3(blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, 0u, pe_scr); return; }
+    hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
     if (!gcap || ap.pe) return;
     // the deferred gapped passes: distances by (read, strand, 32 candidates), then one finishing wave per read
     hipLaunchKernelGGL(k_gap, dim3(n_blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
