@@ -193,26 +193,31 @@ def main():
             out["parity"] = {"checked_reads": int(ns), "mismatching_reads": int(len(bad))}
             b_seed, b_align = algorithmic_bytes(ctr, L)
             n_heavy = len(heavy_ids)
+            # k_heavy, k_gap and k_gapfin share one byte figure: the oracle counts per read, and a read that k_light queues
+            # is finished by those three kernels together ("heavy stage")
+            HEAVY = ("k_heavy", "k_gap", "k_gapfin")
             per_launch = {"k_seed": b_seed * n_reads,
                           "k_light": (algorithmic_bytes(ctr_l, L)[1] if ctr_l else 0.0) * (n_reads - n_heavy),
-                          "k_heavy": (algorithmic_bytes(ctr_h, L)[1] if ctr_h else 0.0) * n_heavy}
-            k_ms = kms
-            dom = max(k_ms, key=lambda k: k_ms[k])
-            b = per_launch[dom] / n_reads
-            ach = per_launch[dom] / (k_ms[dom] / 1e3) / 1e9
+                          "heavy_stage": (algorithmic_bytes(ctr_h, L)[1] if ctr_h else 0.0) * n_heavy}
+            stage_ms = {"k_seed": kms["k_seed"], "k_light": kms["k_light"], "heavy_stage": sum(kms[k] for k in HEAVY)}
+            dom = max(kms, key=lambda k: kms[k])                      # the single kernel with the longest launch
+            grp = "heavy_stage" if dom in HEAVY else dom
+            ach = per_launch[grp] / (stage_ms[grp] / 1e3) / 1e9
             traffic = None
             tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tf):
                 try:
-                    traffic = json.load(open(tf)).get(args.workload, {}).get(dom)
+                    tj = json.load(open(tf)).get(args.workload, {})
+                    traffic = sum(tj[k] for k in HEAVY) if grp == "heavy_stage" else tj.get(dom)
                 except Exception:
                     traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+            out["roofline"] = {"bound": "hbm", "kernel": dom if grp == dom else "k_heavy+k_gap+k_gapfin", "achieved": round(ach, 2),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "algorithmic_bytes_per_read": {"seed_stage": round(b_seed, 1), "align_stage": round(b_align, 1)},
                                "bytes_per_launch": {k: round(v, 0) for k, v in per_launch.items()},
-                               "avg_launch_ms": round(k_ms[dom], 3),
-                               "all_kernels_GBps": {k: round(per_launch[k] / (k_ms[k] / 1e3) / 1e9, 1) for k in k_ms if k_ms[k] > 0}}
+                               "avg_launch_ms": round(stage_ms[grp], 3),
+                               "all_stages_GBps": {k: round(per_launch[k] / (stage_ms[k] / 1e3) / 1e9, 1) for k in stage_ms if stage_ms[k] > 0},
+                               "whole_step_GBps": round(sum(per_launch.values()) / (sum(stage_ms.values()) / 1e3) / 1e9, 1)}
             ora.close()
         print(json.dumps(out), flush=True)
     aln.close()

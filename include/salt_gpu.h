@@ -103,7 +103,9 @@ enum { SALT_CTR_LKT, SALT_CTR_OCC_C, SALT_CTR_OCC_R, SALT_CTR_SA_C, SALT_CTR_SA_
        SALT_CTR_VERIFY_WORDS, SALT_CTR_LV, SALT_CTR_READS, SALT_CTR_BASES, SALT_CTR_LOCI,
        /* diagnostics: shader-clock cycles k_heavy waves spent per phase (only with collect_counters) */
        SALT_CTR_T_LOAD, SALT_CTR_T_GATHER, SALT_CTR_T_LOCATE, SALT_CTR_T_SORT, SALT_CTR_T_DEDUP, SALT_CTR_T_VERIFY,
-       SALT_CTR_T_SCAN, SALT_CTR_T_GAP, SALT_CTR_T_TAIL, SALT_CTR_HEAVY_READS, SALT_CTR_X0, SALT_CTR_X1, SALT_CTR_X2, SALT_CTR_X3, SALT_CTR_N };
+       SALT_CTR_T_SCAN, SALT_CTR_T_GAP, SALT_CTR_T_TAIL, SALT_CTR_HEAVY_READS, SALT_CTR_X0, SALT_CTR_X1, SALT_CTR_X2, SALT_CTR_X3,
+       SALT_CTR_LT_SEEDS, SALT_CTR_LT_LOCATE, SALT_CTR_LT_SORT, SALT_CTR_LT_VERIFY, SALT_CTR_LT_OUT, SALT_CTR_LT_SAMPLES,   /* k_light: s_memtime ticks of every 128th read */
+       SALT_CTR_N };
 
 typedef struct salt_gpu_index salt_gpu_index_t;
 typedef struct salt_gpu_ws    salt_gpu_ws_t;
@@ -150,10 +152,11 @@ int  salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, ui
 
 /* Per-kernel device time.  After salt_gpu_ws_timing(ws, 1) every resident/host align call brackets its
  * kernels with HIP events on the stream it launches on; salt_gpu_ws_kernel_ms synchronises, adds the
- * elapsed times of all calls since the last read into ms[0] (k_seed), ms[1] (k_light) and ms[2]
- * (k_heavy), returns the number of calls in *n_calls and resets.  At most 256 calls are kept. */
+ * elapsed times of all calls since the last read into ms[0] k_seed, ms[1] k_light, ms[2] k_heavy,
+ * ms[3] k_gap, ms[4] k_gapfin, returns the number of calls in *n_calls and resets.  At most 256 calls are kept. */
+#define SALT_N_KERNELS 5
 int  salt_gpu_ws_timing(salt_gpu_ws_t *ws, int enable);
-int  salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[3], uint32_t *n_calls);
+int  salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[SALT_N_KERNELS], uint32_t *n_calls);
 
 /* The reads of the LAST batch that k_light handed to k_heavy (diagnostics / per-kernel accounting):
  * *n = how many; ids[0..min(*n,cap)) = their indices in the batch, in queue order. */

@@ -21,7 +21,8 @@ LIB_DIR = os.path.join(_HERE, "lib")
 MAX_HITS = 5
 MAX_CIGAR_OPS = 64
 CTR_NAMES = ["lkt", "occ_c", "occ_r", "sa_c", "sa_r", "verify", "verify_words", "lv", "reads", "bases", "loci",
-             "t_load", "t_gather", "t_locate", "t_sort", "t_dedup", "t_verify", "t_scan", "t_gap", "t_tail", "heavy_reads", "x0", "x1", "x2", "x3"]
+             "t_load", "t_gather", "t_locate", "t_sort", "t_dedup", "t_verify", "t_scan", "t_gap", "t_tail", "heavy_reads", "x0", "x1", "x2", "x3",
+             "lt_seeds", "lt_locate", "lt_sort", "lt_verify", "lt_out", "lt_samples"]
 
 
 class SaltError(RuntimeError):
@@ -267,6 +268,9 @@ class Index:
         return buf.raw[:n]
 
 
+KERNELS = ("k_seed", "k_light", "k_heavy", "k_gap", "k_gapfin")
+
+
 class GpuAligner:
     """Device copy of the index + one batch workspace on one GPU."""
 
@@ -302,10 +306,10 @@ class GpuAligner:
 
     def kernel_ms(self):
         """({kernel: ms summed since the last read}, calls)."""
-        ms = (ctypes.c_double * 3)()
+        ms = (ctypes.c_double * 5)()
         n = ctypes.c_uint32()
         _gpu_check(gpu_lib().salt_gpu_ws_kernel_ms(self._ws, ms, ctypes.byref(n)))
-        return {"k_seed": ms[0], "k_light": ms[1], "k_heavy": ms[2]}, n.value
+        return dict(zip(KERNELS, list(ms))), n.value
 
     def heavy_reads(self):
         """Indices (in the last batch) of the reads k_light queued for k_heavy."""

@@ -438,6 +438,31 @@ __device__ __forceinline__ void mismatch_batch(const IndexView &ix, const uint32
 // Needs (L+7)/8 + 1 <= 16 words, i.e. L <= 120.  Writes min(count, INF) for candidates [0, n) to out[].
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
+// mismatches of one candidate, computed by its 4 lanes (sub = 0..3 holds words 4*sub..4*sub+3 of the window)
+__device__ __forceinline__ uint32_t quad_mismatch(const u32x4_a4 x, const uint32_t pos, const uint32_t (&pmw)[4], const uint32_t sub,
+                                                  const uint32_t nw, const uint32_t L)
+{
+    const uint32_t sh = (pos & 7u) * 4u;
+    const uint32_t nxt = (uint32_t)__shfl_down((int)x.x, 1);             // first word of the next lane of the quad
+    const uint32_t xs[5] = { x.x, x.y, x.z, x.w, nxt };
+    uint32_t mism = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t j = 4 * sub + t;
+        if (j < nw) {
+            const uint32_t w = sh ? ((xs[t] >> sh) | (xs[t + 1] << (32 - sh))) : xs[t];
+            const uint32_t y = w & pmw[t];
+            const uint32_t nz = (y | (y >> 1) | (y >> 2) | (y >> 3)) & 0x11111111u;
+            const uint32_t rem = L - j * 8;
+            const uint32_t vm = rem >= 8 ? 0x11111111u : (0x11111111u >> (4 * (8 - rem)));
+            mism += (uint32_t)__popc(vm) - (uint32_t)__popc(nz & vm);
+        }
+    }
+    mism += (uint32_t)__shfl_xor((int)mism, 1);
+    mism += (uint32_t)__shfl_xor((int)mism, 2);
+    return mism;
+}
+
 __device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, const uint32_t *pm, uint32_t L,
                                              const uint32_t *cand, uint32_t n, uint8_t *out)
 {
@@ -446,10 +471,11 @@ __device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, c
     uint32_t pmw[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) pmw[t] = (4 * sub + t) < nw ? pm[4 * sub + t] : 0u;
-    for (uint32_t c0 = 0; c0 < n; c0 += 64) {                           // 4 groups of 16 candidates per trip
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {                           // up to 4 groups of 16 candidates per trip
         uint32_t pos[4]; u32x4_a4 x[4]; bool act[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            if (c0 + 16u * g >= n) break;                                // (uniform) nothing left for this group
             const uint32_t c = c0 + 16u * g + q;
             act[g] = c < n;
             pos[g] = act[g] ? cand[c] : 0u;
@@ -457,25 +483,42 @@ __device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, c
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const uint32_t sh = (pos[g] & 7u) * 4u;
-            const uint32_t nxt = (uint32_t)__shfl_down((int)x[g].x, 1);       // first word of the next lane of the quad
-            const uint32_t xs[5] = { x[g].x, x[g].y, x[g].z, x[g].w, nxt };
-            uint32_t mism = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint32_t j = 4 * sub + t;
-                if (j < nw) {
-                    const uint32_t w = sh ? ((xs[t] >> sh) | (xs[t + 1] << (32 - sh))) : xs[t];
-                    const uint32_t y = w & pmw[t];
-                    const uint32_t nz = (y | (y >> 1) | (y >> 2) | (y >> 3)) & 0x11111111u;
-                    const uint32_t rem = L - j * 8;
-                    const uint32_t vm = rem >= 8 ? 0x11111111u : (0x11111111u >> (4 * (8 - rem)));
-                    mism += (uint32_t)__popc(vm) - (uint32_t)__popc(nz & vm);
-                }
-            }
-            mism += (uint32_t)__shfl_xor((int)mism, 1);
-            mism += (uint32_t)__shfl_xor((int)mism, 2);
+            if (c0 + 16u * g >= n) break;
+            const uint32_t mism = quad_mismatch(x[g], pos[g], pmw, sub, nw, L);
             if (act[g] && sub == 0) out[c0 + 16u * g + q] = (uint8_t)(mism > 3 ? INF : mism);
+        }
+    }
+}
+
+// Both strands of one read in the same trips (k_light): candidates c0[0..n0) use pm0, c1[0..n1) use pm1.
+__device__ __forceinline__ void verify_quads_2(const uint32_t *__restrict__ ref, const uint32_t *pm0, const uint32_t *pm1, uint32_t L,
+                                               const uint32_t *c0, uint32_t n0, const uint32_t *c1, uint32_t n1, uint8_t *o0, uint8_t *o1)
+{
+    const uint32_t lane = lane_id(), sub = lane & 3u, q = lane >> 2;
+    const uint32_t nw = (L + 7) >> 3, n = n0 + n1;
+    uint32_t pa[4], pb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const bool in = (4 * sub + t) < nw; pa[t] = in ? pm0[4 * sub + t] : 0u; pb[t] = in ? pm1[4 * sub + t] : 0u; }
+    for (uint32_t b = 0; b < n; b += 64) {
+        uint32_t pos[4]; u32x4_a4 x[4]; bool act[4], rev[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (b + 16u * g >= n) break;
+            const uint32_t c = b + 16u * g + q;
+            act[g] = c < n; rev[g] = c >= n0;
+            pos[g] = act[g] ? (rev[g] ? c1[c - n0] : c0[c]) : 0u;
+            x[g] = *reinterpret_cast<const u32x4_a4 *>(ref + (pos[g] >> 3) + 4 * sub);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (b + 16u * g >= n) break;
+            const uint32_t pw[4] = { rev[g] ? pb[0] : pa[0], rev[g] ? pb[1] : pa[1], rev[g] ? pb[2] : pa[2], rev[g] ? pb[3] : pa[3] };
+            const uint32_t mism = quad_mismatch(x[g], pos[g], pw, sub, nw, L);
+            if (act[g] && sub == 0) {
+                const uint32_t c = b + 16u * g + q;
+                const uint8_t v = (uint8_t)(mism > 3 ? INF : mism);
+                if (rev[g]) o1[c - n0] = v; else o0[c] = v;
+            }
         }
     }
 }
@@ -1008,18 +1051,29 @@ struct LightLds {
     uint8_t  val[2][64];
 };
 
-__global__ void __launch_bounds__(64)
+static constexpr int LT_WAVES = 1;       // independent reads (waves) per block: 4x fewer workgroups to dispatch
+__global__ void __launch_bounds__(64 * LT_WAVES)
 k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
         const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
         uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl, unsigned long long *__restrict__ ctr)
 {
-    __shared__ LightLds w;
+    __shared__ LightLds w_all[LT_WAVES];
+    LightLds &w = w_all[threadIdx.x >> 6];
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull;
-    const uint32_t r = blockIdx.x;
+    const uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.x * LT_WAVES + (threadIdx.x >> 6));
+    if (r >= ap.n_reads) return;
     const uint32_t off = offs[r], L = offs[r + 1] - off;
     bool heavy = L > LT_MAXL || L < (uint32_t)ap.l_seed || ap.spr > LT_SLOTS || ap.max_locate < 2 * 64;
     uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_loci = 0;
+    const bool prof = ctr && (r & 127u) == 0;                                // phase clock of every 128th read
+    uint64_t tp = prof ? __builtin_amdgcn_s_memtime() : 0;
+    auto stamp = [&](int slot) {
+        if (!prof) return;
+        const uint64_t n = __builtin_amdgcn_s_memtime();
+        if (lane == 0) atomicAdd(ctr + slot, (unsigned long long)(n - tp));
+        tp = n;
+    };
 
     if (!heavy) {
         // ---- round trip 1: the read (as one-hot nibble words, both strands) and its seeds ----
@@ -1066,8 +1120,10 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
             if (slot == 0) w.pre[l][0] = 0;
         }
         WSYNC();
+        stamp(SALT_CTR_LT_SEEDS);
         uint32_t tot[4];
         for (int l = 0; l < 4; ++l) { tot[l] = w.pre[l][16]; heavy |= tot[l] > 64; }
+        if (ap.dbg_stop == 1) { if (lane == 0) results[r].pos = tot[0] + tot[1] + tot[2] + tot[3] + w.pm[0][0] + w.pm[1][1]; return; }
         if (!heavy) {
             // ---- round trip 2: every suffix-array row of the four lists at once ----
             uint32_t pos4[4]; bool keep4[4];
@@ -1082,6 +1138,8 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
                     keep4[l] = (l & 1) ? !(p > ix.ref_len || p + L > ix.ref_len) : !(p + L > ix.ref_len);   // alnse.c:672-673,715-717
                 }
             }
+            stamp(SALT_CTR_LT_LOCATE);
+            if (ap.dbg_stop == 2) { const uint32_t x = pos4[0] + pos4[1] + pos4[2] + pos4[3]; if (__ballot(x == 12345u) == 1) results[r].pos = x; return; }
             uint32_t n_s[2];
             for (int s = 0; s < 2; ++s) {
                 const uint64_t mc = __ballot(keep4[2 * s]), mr = __ballot(keep4[2 * s + 1]);
@@ -1120,6 +1178,8 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
                 n_c[s] = c0 + (uint32_t)__popcll(m1);
             }
             WSYNC();
+            stamp(SALT_CTR_LT_SORT);
+            if (ap.dbg_stop == 3) { if (lane == 0) results[r].pos = w.loci[0][0] + w.loci[1][0] + n_c[0] + n_c[1]; return; }
             // ---- round trip 3: masked Hamming distance of every candidate of both strands ----
             if (n_c[0] > 64 || n_c[1] > 64) heavy = true;                   // rare: leave multi-chunk scans to k_heavy
             uint32_t bound = 3, q_pos = 0xFFFFFFFFu, q_strand = 3, q_ndiff = 255;
@@ -1131,11 +1191,12 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
                 const bool a2[2] = { lane < n_c[0], lane < n_c[1] };
                 const uint32_t p2[2] = { a2[0] ? w.loci[0][lane] : 0u, a2[1] ? w.loci[1][lane] : 0u };
                 if (L <= 120) {
-                    verify_quads(ix.ref, w.pm[0], L, w.loci[0], n_c[0], w.val[0]);
-                    verify_quads(ix.ref, w.pm[1], L, w.loci[1], n_c[1], w.val[1]);
+                    verify_quads_2(ix.ref, w.pm[0], w.pm[1], L, w.loci[0], n_c[0], w.loci[1], n_c[1], w.val[0], w.val[1]);
                     WSYNC();
                     v2[0] = a2[0] ? w.val[0][lane] : INF; v2[1] = a2[1] ? w.val[1][lane] : INF;
                 } else mismatch_batch<20, 2>(ix, pm2, L, p2, a2, v2);
+                stamp(SALT_CTR_LT_VERIFY);
+                if (ap.dbg_stop == 4) { if (__ballot(v2[0] + v2[1] == 12345u) == 1) results[r].pos = v2[0]; return; }
                 c_verify += n_c[0] + n_c[1];
                 if (a2[0]) c_vwords += ((p2[0] & 7u) + L + 7) >> 3;
                 if (a2[1]) c_vwords += ((p2[1] & 7u) + L + 7) >> 3;
@@ -1209,6 +1270,8 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
         if (lane == 0) queue[atomicAdd(&qctl[0], 1u)] = r;
         return;                                                             // k_heavy does (and counts) all of it
     }
+    stamp(SALT_CTR_LT_OUT);
+    if (prof && lane == 0) atomicAdd(ctr + SALT_CTR_LT_SAMPLES, 1ull);
     if (ctr) {
         for (int o = 32; o > 0; o >>= 1) c_vwords += __shfl_down(c_vwords, o);
         if (lane == 0) {
@@ -1301,7 +1364,7 @@ void launch_light(const IndexView &ix, const AlignParams &ap, const uint8_t *seq
                   const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, unsigned long long *ctr, hipStream_t st)
 {
     if (!ap.n_reads) return;
-    hipLaunchKernelGGL(k_light, dim3(ap.n_reads), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr);
+    hipLaunchKernelGGL(k_light, dim3((ap.n_reads + LT_WAVES - 1) / LT_WAVES), dim3(64 * LT_WAVES), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1386,16 +1449,18 @@ uint32_t heavy_blocks_per_cu()
 
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, uint32_t *qctl, unsigned long long *ctr,
-                  uint32_t n_blocks, void *lvtab, uint32_t *gq, uint8_t *ge, uint32_t gcap, uint8_t *pe_scr, hipStream_t st)
+                  uint32_t n_blocks, void *lvtab, uint32_t *gq, uint8_t *ge, uint32_t gcap, uint8_t *pe_scr, hipEvent_t *ev2, hipStream_t st)
 {
-    if (!ap.n_reads) return;
+    if (!ap.n_reads) { if (ev2) { hipEventRecord(ev2[0], st); hipEventRecord(ev2[1], st); } return; }
     uint32_t blocks = n_blocks < ap.n_reads ? n_blocks : ap.n_reads;
     LvTables *tab = static_cast<LvTables *>(lvtab);
-    if (ap.pe) { hipLaunchKernelGGL(k_heavy_pe, dim3(blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, 0u, pe_scr); return; }
+    if (ap.pe) { hipLaunchKernelGGL(k_heavy_pe, dim3(blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, 0u, pe_scr); if (ev2) { hipEventRecord(ev2[0], st); hipEventRecord(ev2[1], st); } return; }
     hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
-    if (!gcap || ap.pe) return;
+    if (ev2) hipEventRecord(ev2[0], st);
+    if (!gcap) { if (ev2) hipEventRecord(ev2[1], st); return; }
     // the deferred gapped passes: distances by (read, strand, 32 candidates), then one finishing wave per read
     hipLaunchKernelGGL(k_gap, dim3(n_blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
+    if (ev2) hipEventRecord(ev2[1], st);
     hipLaunchKernelGGL(k_gapfin, dim3(n_blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
 }
 

@@ -45,7 +45,7 @@ struct salt_gpu_ws {
     int all_heavy = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
-    std::vector<hipEvent_t> ev;        // 4 per call: before k_seed, before k_light, before k_heavy, after
+    std::vector<hipEvent_t> ev;        // 6 per call: before k_seed, k_light, k_heavy, k_gap, k_gapfin, after
     uint32_t n_timed = 0;
 };
 static const uint32_t MAX_TIMED = 256;
@@ -309,11 +309,11 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     sp.max_seed = o->max_seed; sp.seed_only_ref = o->seed_only_ref;
     if (n_reads > ws->max_reads) return fail(SALT_E_CAPACITY, "more reads than the workspace holds");
     AlignParams ap; ap.n_reads = n_reads; ap.spr = spr; ap.l_seed = o->l_seed; ap.max_locate = o->max_locate; ap.max_hits = o->max_hits;
-    ap.all_heavy = ws->all_heavy; ap.pe = pe; ap.max_amb = pe ? 5u : 200u;
+    ap.all_heavy = ws->all_heavy; ap.pe = pe; { const char *e = getenv("SALT_GPU_LIGHT_STOP"); ap.dbg_stop = e ? atoi(e) : 0; } ap.max_amb = pe ? 5u : 200u;
     if (pe && !ws->d_pe_scr) HIPCHK(hipMalloc((void **)&ws->d_pe_scr, (uint64_t)ws->heavy_blocks * PE_LOCI_CAP * 5));
     unsigned long long *ctr = o->collect_counters ? ws->d_ctr : nullptr;
     const bool timed = ws->timing && ws->n_timed < MAX_TIMED;
-    hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * 4] : nullptr;
+    hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * 6] : nullptr;
     HIPCHK(hipMemsetAsync(ws->d_qctl, 0, 32, st));
     if (timed) HIPCHK(hipEventRecord(ev[0], st));
     launch_seed(ws->ix->view, sp, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r, ctr, st);
@@ -323,8 +323,8 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
                      static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, st);
     if (timed) HIPCHK(hipEventRecord(ev[2], st));
     launch_heavy(ws->ix->view, ap, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
-                 static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, ws->heavy_blocks, ws->d_lvtab, ws->d_gq, ws->d_ge, ws->gcap, pe ? ws->d_pe_scr : nullptr, st);
-    if (timed) { HIPCHK(hipEventRecord(ev[3], st)); ++ws->n_timed; }
+                 static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, ws->heavy_blocks, ws->d_lvtab, ws->d_gq, ws->d_ge, ws->gcap, pe ? ws->d_pe_scr : nullptr, timed ? ev + 3 : nullptr, st);
+    if (timed) { HIPCHK(hipEventRecord(ev[5], st)); ++ws->n_timed; }
     HIPCHK(hipGetLastError());
     return SALT_OK;
 }
@@ -397,26 +397,27 @@ extern "C" int salt_gpu_ws_timing(salt_gpu_ws_t *ws, int enable)
     if (!ws) return fail(SALT_E_INVAL, "null argument");
     HIPCHK(hipSetDevice(ws->ix->device));
     if (enable && ws->ev.empty()) {
-        ws->ev.resize((size_t)MAX_TIMED * 4);
+        ws->ev.resize((size_t)MAX_TIMED * 6);
         for (auto &e : ws->ev) HIPCHK(hipEventCreate(&e));
     }
     ws->timing = enable != 0; ws->n_timed = 0;
     return SALT_OK;
 }
 
-extern "C" int salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[3], uint32_t *n_calls)
+extern "C" int salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[SALT_N_KERNELS], uint32_t *n_calls)
 {
     if (!ws || !ms || !n_calls) return fail(SALT_E_INVAL, "null argument");
     HIPCHK(hipSetDevice(ws->ix->device));
-    ms[0] = ms[1] = ms[2] = 0; *n_calls = ws->n_timed;
+    for (int k = 0; k < SALT_N_KERNELS; ++k) ms[k] = 0;
+    *n_calls = ws->n_timed;
     for (uint32_t i = 0; i < ws->n_timed; ++i) {
-        hipEvent_t *ev = &ws->ev[(size_t)i * 4];
-        HIPCHK(hipEventSynchronize(ev[3]));
-        float a = 0, b = 0, c = 0;
-        HIPCHK(hipEventElapsedTime(&a, ev[0], ev[1]));
-        HIPCHK(hipEventElapsedTime(&b, ev[1], ev[2]));
-        HIPCHK(hipEventElapsedTime(&c, ev[2], ev[3]));
-        ms[0] += a; ms[1] += b; ms[2] += c;
+        hipEvent_t *ev = &ws->ev[(size_t)i * 6];
+        HIPCHK(hipEventSynchronize(ev[5]));
+        for (int k = 0; k < SALT_N_KERNELS; ++k) {
+            float a = 0;
+            HIPCHK(hipEventElapsedTime(&a, ev[k], ev[k + 1]));
+            ms[k] += a;
+        }
     }
     ws->n_timed = 0;
     return SALT_OK;

@@ -18,6 +18,7 @@ struct AlignParams {
     int32_t  l_seed;
     uint32_t max_locate;
     int32_t  max_hits;
+    int32_t  dbg_stop;              // debug/A-B: k_light leaves after phase dbg_stop (1..4); results are then garbage
     int32_t  all_heavy;             // debug/A-B: skip k_light, k_heavy walks reads 0..n_reads-1
     int32_t  pe;                    // 1: mates of a paired-end batch -- alnse_overlap semantics (alnse.c:985-1044, 501-629):
                                     //    per-interval locate cap, gapped bound stays 3, > 5 N skips the mate
@@ -31,7 +32,7 @@ void launch_light(const IndexView &ix, const AlignParams &ap, const uint8_t *seq
                   const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, unsigned long long *ctr, hipStream_t st);
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, uint32_t *qctl, unsigned long long *ctr,
-                  uint32_t n_blocks, void *lvtab, uint32_t *gq, uint8_t *ge, uint32_t gcap, uint8_t *pe_scr, hipStream_t st);
+                  uint32_t n_blocks, void *lvtab, uint32_t *gq, uint8_t *ge, uint32_t gcap, uint8_t *pe_scr, hipEvent_t *ev2, hipStream_t st);
 size_t gap_e_bytes_per_read();
 size_t lv_table_bytes();                // per-block LV traceback table (global memory)
 

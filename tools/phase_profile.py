@@ -18,3 +18,7 @@ tot = sum(v for k, v in c.items() if k.startswith("t_"))
 for k, v in c.items():
     if k.startswith("t_"):
         print("%-10s %6.1f %%   %8.1f kcycles/heavy read" % (k, 100.0 * v / tot, v / max(c["heavy_reads"], 1) / 1e3))
+lt = {k: v for k, v in c.items() if k.startswith("lt_") and k != "lt_samples"}
+tot = sum(lt.values())
+for k, v in lt.items():
+    print("%-10s %6.1f %%   %8.0f ticks/light read (s_memtime, every 128th read)" % (k, 100.0 * v / max(tot, 1), v / max(c["lt_samples"], 1)))
