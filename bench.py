@@ -196,22 +196,23 @@ def main():
             # k_heavy, k_gap and k_gapfin share one byte figure: the oracle counts per read, and a read that k_light queues
             # is finished by those three kernels together ("heavy stage")
             HEAVY = ("k_heavy", "k_gap", "k_gapfin")
-            per_launch = {"k_seed": b_seed * n_reads,
+            SEED = ("k_pack", "k_seed")
+            per_launch = {"seed_stage": b_seed * n_reads,
                           "k_light": (algorithmic_bytes(ctr_l, L)[1] if ctr_l else 0.0) * (n_reads - n_heavy),
                           "heavy_stage": (algorithmic_bytes(ctr_h, L)[1] if ctr_h else 0.0) * n_heavy}
-            stage_ms = {"k_seed": kms["k_seed"], "k_light": kms["k_light"], "heavy_stage": sum(kms[k] for k in HEAVY)}
+            stage_ms = {"seed_stage": sum(kms[k] for k in SEED), "k_light": kms["k_light"], "heavy_stage": sum(kms[k] for k in HEAVY)}
             dom = max(kms, key=lambda k: kms[k])                      # the single kernel with the longest launch
-            grp = "heavy_stage" if dom in HEAVY else dom
+            grp = "heavy_stage" if dom in HEAVY else "seed_stage" if dom in SEED else dom
             ach = per_launch[grp] / (stage_ms[grp] / 1e3) / 1e9
             traffic = None
             tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tf):
                 try:
                     tj = json.load(open(tf)).get(args.workload, {})
-                    traffic = sum(tj[k] for k in HEAVY) if grp == "heavy_stage" else tj.get(dom)
+                    traffic = sum(tj[k] for k in HEAVY) if grp == "heavy_stage" else sum(tj[k] for k in SEED) if grp == "seed_stage" else tj.get(dom)
                 except Exception:
                     traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": dom if grp == dom else "k_heavy+k_gap+k_gapfin", "achieved": round(ach, 2),
+            out["roofline"] = {"bound": "hbm", "kernel": dom if grp == dom else "+".join(HEAVY if grp == "heavy_stage" else SEED), "achieved": round(ach, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "algorithmic_bytes_per_read": {"seed_stage": round(b_seed, 1), "align_stage": round(b_align, 1)},
                                "bytes_per_launch": {k: round(v, 0) for k, v in per_launch.items()},

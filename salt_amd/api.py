@@ -268,7 +268,7 @@ class Index:
         return buf.raw[:n]
 
 
-KERNELS = ("k_seed", "k_light", "k_heavy", "k_gap", "k_gapfin")
+KERNELS = ("k_pack", "k_seed", "k_light", "k_heavy", "k_gap", "k_gapfin")
 
 
 class GpuAligner:
@@ -306,7 +306,7 @@ class GpuAligner:
 
     def kernel_ms(self):
         """({kernel: ms summed since the last read}, calls)."""
-        ms = (ctypes.c_double * 5)()
+        ms = (ctypes.c_double * len(KERNELS))()
         n = ctypes.c_uint32()
         _gpu_check(gpu_lib().salt_gpu_ws_kernel_ms(self._ws, ms, ctypes.byref(n)))
         return dict(zip(KERNELS, list(ms))), n.value

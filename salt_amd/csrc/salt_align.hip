@@ -61,10 +61,90 @@ __device__ __forceinline__ uint32_t read_base(const uint8_t *seq, uint32_t L, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_pack: the batch's reads in the two packed, fixed-stride forms the other kernels gather from (PackGeom,
+// salt_kernels.h).  A block of 256 threads takes 256 / (2*nw32) consecutive reads: their bytes are staged in LDS
+// as both strands (coalesced loads; query_seq_reverse / nst_nt4_table semantics, codes > 4 read as N,
+// query.c:46-71,177-183), then one thread per (read, strand, 32 bases) packs with shift-and-mask steps only.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pk_nibbles(uint32_t x)        // 4 bytes (low nibbles) -> 16 bits, byte 0 lowest
+{
+    uint32_t t = x & 0x0F0F0F0Fu;
+    t = (t | (t >> 4)) & 0x00FF00FFu;
+    return (t | (t >> 8)) & 0xFFFFu;
+}
+
+__global__ void __launch_bounds__(256)
+k_pack(PackGeom pg, uint32_t n_reads, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+       uint32_t *__restrict__ pm, uint32_t *__restrict__ tb)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sb[8192];              // [read][strand][32 * nw32], 8 = no base
+    __shared__ uint32_t so[65];
+    const uint32_t tpr = 2 * pg.nw32, rpb = 256 / tpr < 64 ? 256 / tpr : 64, slot = 32 * pg.nw32;   // threads per read, reads per block, bytes per strand
+    const uint32_t r0 = blockIdx.x * rpb, nr = n_reads - r0 < rpb ? n_reads - r0 : rpb;
+    if (threadIdx.x <= nr) so[threadIdx.x] = offs[r0 + threadIdx.x];
+    reinterpret_cast<uint4 *>(sb)[threadIdx.x] = make_uint4(0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u);
+    reinterpret_cast<uint4 *>(sb)[threadIdx.x + 256] = make_uint4(0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u);
+    __syncthreads();
+    const uint32_t cap = 8 * pg.nw8;                                        // bases the records hold per strand
+    for (uint32_t rr = threadIdx.x >> 6; rr < nr; rr += 4) {                // one wave per read
+        const uint32_t o = so[rr];
+        uint32_t L = so[rr + 1] - o;
+        if (L > cap) L = cap;                                               // longer than max_read_len says: truncated, never out of bounds
+        uint8_t *f = sb + (size_t)rr * 2 * slot, *v = f + slot;
+        for (uint32_t i = threadIdx.x & 63u; i < L; i += 64) {
+            uint32_t c = seqs[o + i];
+            if (c > 4) c = 4;
+            f[i] = (uint8_t)c;
+            v[L - 1 - i] = (uint8_t)(c < 4 ? 3 - c : c);
+        }
+    }
+    __syncthreads();
+    const uint32_t rr = threadIdx.x / tpr, sub = threadIdx.x - rr * tpr;
+    if (rr >= nr) return;
+    const uint32_t strand = sub >= pg.nw32, j = sub - strand * pg.nw32;
+    uint32_t L = so[rr + 1] - so[rr];
+    if (L > cap) L = cap;
+    const uint4 *src = reinterpret_cast<const uint4 *>(sb + ((size_t)rr * 2 + strand) * slot + 32 * j);
+    const uint4 q0 = src[0], q1 = src[1];
+    const uint32_t d[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+    uint32_t *pmr = pm + (uint64_t)(r0 + rr) * pg.pm_stride, *tbr = tb + (uint64_t)(r0 + rr) * pg.tb_stride;
+    uint32_t p16[4], nb = 0;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const uint32_t n8 = pk_nibbles(d[2 * h]) | (pk_nibbles(d[2 * h + 1]) << 16);     // base q of the chunk in nibble q
+        const uint32_t one = 0x11111111u;
+        const uint32_t a = n8 & one, b = (n8 >> 1) & one, isn = (n8 >> 2) & one, valid = ~(n8 >> 3) & one;
+        const uint32_t na = a ^ one, nb_ = b ^ one;
+        uint32_t oh = (na & nb_) | ((a & nb_) << 1) | ((na & b) << 2) | ((a & b) << 3);  // 1 << code
+        oh = (oh | isn * 15u) & (valid * 15u);                                          // N -> 15, no base -> 0 (nt2bit, editdistance.c:40)
+        if (4 * j + h < pg.nw8) pmr[strand * pg.nw8 + 4 * j + h] = oh;
+        uint32_t t = n8 & 0x33333333u;                                                  // 2-bit codes (N and 'no base' read 0)
+        t = (t | (t >> 2)) & 0x0F0F0F0Fu; t = (t | (t >> 4)) & 0x00FF00FFu; p16[h] = (t | (t >> 8)) & 0xFFFFu;
+        uint32_t u = isn;
+        u = (u | (u >> 3)) & 0x03030303u; u = (u | (u >> 6)) & 0x000F000Fu; u = (u | (u >> 12)) & 0xFFu;
+        nb |= u << (8 * h);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint32_t r = __brev(p16[2 * g] | (p16[2 * g + 1] << 16));                 // first base highest; then put each pair back in order
+        if (2 * j + g < pg.nw16) tbr[strand * pg.nw16 + 2 * j + g] = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+    }
+    tbr[2 * pg.nw16 + strand * pg.nw32 + j] = __brev(nb);
+    if (sub == 0) { pmr[2 * pg.nw8] = L; tbr[2 * pg.nw16 + 2 * pg.nw32] = L; }
+}
+
+void launch_pack(const PackGeom &pg, uint32_t n_reads, const uint8_t *seqs, const uint32_t *offs, uint32_t *pm, uint32_t *tb, hipStream_t st)
+{
+    if (!n_reads) return;
+    const uint32_t rpb = 256 / (2 * pg.nw32) < 64 ? 256 / (2 * pg.nw32) : 64;
+    hipLaunchKernelGGL(k_pack, dim3((n_reads + rpb - 1) / rpb), dim3(256), 0, st, pg, n_reads, seqs, offs, pm, tb);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_seed
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_seed(IndexView ix, SeedParams sp, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
        uint4 *__restrict__ sai_c, uint4 *__restrict__ sai_r, unsigned long long *__restrict__ ctr)
 {
     const uint64_t item = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,43 +154,68 @@ k_seed(IndexView ix, SeedParams sp, const uint8_t *__restrict__ seqs, const uint
         const uint32_t rs = (uint32_t)(item / sp.spr);
         const int strand = (int)(rs & 1u);
         const uint32_t r = rs >> 1;
-        const uint32_t off = offs[r], L = offs[r + 1] - off;
-        const uint8_t *seq = seqs + off;
+        // the read as k_pack left it: 2-bit codes (first base in the high bits) and 'is N' bits of this strand
+        const uint32_t *rec = tb + (uint64_t)r * sp.pg.tb_stride;
+        const uint32_t *t2 = rec + (uint32_t)strand * sp.pg.nw16, *tn = rec + 2 * sp.pg.nw16 + (uint32_t)strand * sp.pg.nw32;
+        const uint32_t L = rec[2 * sp.pg.nw16 + 2 * sp.pg.nw32];
         const uint32_t k = (uint32_t)sp.l_seed, s = slot * (uint32_t)sp.l_overlap;
         uint4 oc = make_uint4(1, 0, 0, 0), orr = make_uint4(1, 0, 0, 0);
         if (L >= k && s + k <= L) {
             const uint32_t e = s + k - 1, W = ix.r_lkt_len;
+            // seeds of up to 33 bases sit in 3 + 2 registers (bases wb*16 .. wb*16+47); longer ones read the record
+            const bool inreg = k <= 33;
+            const uint32_t wb = s >> 4, nb = s >> 5;
+            const uint32_t w0 = t2[wb], w1 = t2[wb + 1], w2 = t2[wb + 2];       // stays inside the record (PackGeom)
+            const uint32_t n0 = tn[nb], n1 = tn[nb + 1];
+            auto base2 = [&](uint32_t i) -> uint32_t {
+                if (inreg && i >= s) { const uint32_t rel = i - (wb << 4); const uint32_t ws = rel < 16 ? w0 : rel < 32 ? w1 : w2; return (ws >> (30 - 2 * (rel & 15u))) & 3u; }
+                return (t2[i >> 4] >> (30 - 2 * (i & 15u))) & 3u;
+            };
+            auto is_n = [&](uint32_t i) -> bool {
+                if (inreg && i >= s) { const uint32_t rel = i - (nb << 5); const uint32_t ns = rel < 32 ? n0 : n1; return (ns >> (31 - (rel & 31u))) & 1u; }
+                return (tn[i >> 5] >> (31 - (i & 31u))) & 1u;
+            };
             // W-mer at the seed tail: both searches start from their tabulated interval
             // (LKT_seq2LktItem / LKT_lookup_sa lookup.c:163-177 + the first steps of bwt.c:281-309, rbwt.c:619-648)
             uint32_t x = 0; bool has_n = false;
-            for (uint32_t t = 0; t < W; ++t) {
-                uint32_t c = read_base(seq, L, strand, e - W + 1 + t);
-                has_n |= c > 3; x = (x << 2) | (c & 3u);
+            const uint32_t a0 = e - W + 1;
+            if (inreg) {
+                const uint32_t rel = a0 - (wb << 4), rr = rel & 15u;
+                const uint64_t v = rel < 16 ? (((uint64_t)w0 << 32) | w1) : rel < 32 ? (((uint64_t)w1 << 32) | w2) : ((uint64_t)w2 << 32);
+                x = (uint32_t)((v >> (64 - 2 * rr - 2 * W)) & ((1ull << (2 * W)) - 1ull));
+                const uint32_t reln = a0 - (nb << 5);
+                const uint64_t vn = ((uint64_t)n0 << 32) | n1;
+                has_n = ((vn >> (64 - reln - W)) & ((1ull << W) - 1ull)) != 0;
+            } else {
+                for (uint32_t t = 0; t < W; ++t) { has_n |= is_n(a0 + t); x = (x << 2) | base2(a0 + t); }
             }
             uint32_t kc = 1, lc = 0, kr = 1, lr = 0;
             bool alive_c = !has_n, alive_r = !has_n && !sp.seed_only_ref;
-            if (alive_c) { uint2 v = ix.c_wlkt[x]; kc = v.x; lc = v.y; alive_c = kc <= lc; ++n_lkt; n_occ_c += 2 * (W - ix.lkt_len); }
-            if (alive_r) { uint2 v = ix.r_lkt[x]; kr = v.x; lr = v.y; alive_r = kr <= lr; n_occ_r += 2 * W; }
+            if (alive_c) {
+                const uint4 v = ix.wlkt[x];                  // one 16-byte gather: C interval in .x/.y, R interval in .z/.w
+                kc = v.x; lc = v.y; alive_c = kc <= lc; ++n_lkt; n_occ_c += 2 * (W - ix.lkt_len);
+                if (alive_r) { kr = v.z; lr = v.w; alive_r = kr <= lr; n_occ_r += 2 * W; }
+            }
             const int i_r_start = (int)(k - W) - 1;         // first head index still to consume
             // joint backward search over the seed head, newest base last (bwt.c:281-309, rbwt.c:619-648)
             for (int i = i_r_start; i >= 0 && (alive_c || alive_r); --i) {
-                uint32_t c = read_base(seq, L, strand, s + (uint32_t)i);
-                if (c > 3) { alive_c = false; alive_r = false; break; }
+                if (is_n(s + (uint32_t)i)) { alive_c = false; alive_r = false; break; }
+                const uint32_t c = base2(s + (uint32_t)i);
                 if (alive_c) {
-                    uint32_t ok = c_occ(ix, kc - 1, c), ol = c_occ(ix, lc, c);
+                    uint32_t ok, ol; c_occ2(ix, kc - 1, lc, c, ok, ol);
                     kc = ix.c_L2[c] + ok + 1; lc = ix.c_L2[c] + ol; alive_c = kc <= lc; n_occ_c += 2;
                 }
                 if (alive_r) {
-                    uint32_t ok = r_occ(ix, kr, c), ol = r_occ(ix, lr + 1, c);
+                    uint32_t ok, ol; r_occ2(ix, kr, lr + 1, c, ok, ol);
                     kr = ix.r_cum[c] + ok + 1; lr = ix.r_cum[c] + ol; alive_r = kr <= lr; n_occ_r += 2;
                 }
             }
             if (alive_c) {                                    // shrink big intervals leftwards (alnse.c:246-258)
                 uint32_t ext = 0;
                 while (lc - kc > sp.max_seed && ext < s) {
-                    uint32_t c = read_base(seq, L, strand, s - ext - 1);
-                    if (c > 3) break;
-                    uint32_t ok = c_occ(ix, kc - 1, c), ol = c_occ(ix, lc, c);
+                    if (is_n(s - ext - 1)) break;
+                    const uint32_t c = base2(s - ext - 1);
+                    uint32_t ok, ol; c_occ2(ix, kc - 1, lc, c, ok, ol);
                     n_occ_c += 2;
                     if (ok + 1 > ol) break;
                     kc = ix.c_L2[c] + ok + 1; lc = ix.c_L2[c] + ol; ++ext;
@@ -121,8 +226,8 @@ k_seed(IndexView ix, SeedParams sp, const uint8_t *__restrict__ seqs, const uint
             if (alive_r) {                                    // same, without the N guard (alnse.c:279-291)
                 uint32_t ext = 0;
                 while (lr - kr > sp.max_seed && ext < s) {
-                    uint32_t c = read_base(seq, L, strand, s - ext - 1);
-                    uint32_t ok = r_occ(ix, kr, c), ol = r_occ(ix, lr + 1, c);
+                    const uint32_t c = is_n(s - ext - 1) ? 4u : base2(s - ext - 1);       // an N walks the '#' column
+                    uint32_t ok, ol; r_occ2(ix, kr, lr + 1, c, ok, ol);
                     n_occ_r += 2;
                     if (ok + 1 > ol) break;
                     kr = ix.r_cum[c] + ok + 1; lr = ix.r_cum[c] + ol; ++ext;
@@ -1053,7 +1158,7 @@ struct LightLds {
 
 static constexpr int LT_WAVES = 1;       // independent reads (waves) per block: 4x fewer workgroups to dispatch
 __global__ void __launch_bounds__(64 * LT_WAVES)
-k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
         const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
         uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl, unsigned long long *__restrict__ ctr)
 {
@@ -1063,7 +1168,8 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.x * LT_WAVES + (threadIdx.x >> 6));
     if (r >= ap.n_reads) return;
-    const uint32_t off = offs[r], L = offs[r + 1] - off;
+    const uint32_t *rec = pm + (uint64_t)r * ap.pg.pm_stride;               // k_pack's one-hot words of this read, both strands
+    const uint32_t L = rec[2 * ap.pg.nw8];
     bool heavy = L > LT_MAXL || L < (uint32_t)ap.l_seed || ap.spr > LT_SLOTS || ap.max_locate < 2 * 64;
     uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_loci = 0;
     const bool prof = ctr && (r & 127u) == 0;                                // phase clock of every 128th read
@@ -1081,20 +1187,12 @@ k_light(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const ui
         uint32_t n_amb = 0;
         if (lane < 2 * nw) {
             const uint32_t s = lane >= nw, j = s ? lane - nw : lane;
-            uint32_t word = 0;
-            for (uint32_t q = 0; q < 8; ++q) {
-                uint32_t i = j * 8 + q, msk = 0;
-                if (i < L) {
-                    uint32_t c = s ? seqs[off + (L - 1 - i)] : seqs[off + i];
-                    if (s && c < 4) c = 3 - c;
-                    msk = c < 4 ? (1u << c) : 15u;                         // nt2bit (editdistance.c:40)
-                    n_amb += (!s && c > 3);
-                }
-                word |= msk << (4 * q);
-            }
+            const uint32_t word = rec[s * ap.pg.nw8 + j];
             w.pm[s][j] = word;
+            if (!s) n_amb = (uint32_t)__popc(word & (word >> 1) & (word >> 2) & (word >> 3) & 0x11111111u);   // N = all four bits
         }
-        for (int o = 32; o > 0; o >>= 1) n_amb += (uint32_t)__shfl_xor((int)n_amb, o);
+        if (ap.max_amb < L)                                                 // (uniform) otherwise the limit cannot be passed
+            for (int o = 32; o > 0; o >>= 1) n_amb += (uint32_t)__shfl_xor((int)n_amb, o);
         if (n_amb > ap.max_amb) {                                           // alnse.c:1328 / alnpe.c:495: record left untouched
             if (lane == 0) {
                 salt_result_t *out = results + r;
@@ -1351,20 +1449,20 @@ void launch_pe_final(const IndexView &ix, uint32_t n_pairs, const uint8_t *seqs,
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (called from salt_gpu.hip)
 // ---------------------------------------------------------------------------------------------
-void launch_seed(const IndexView &ix, const SeedParams &sp, const uint8_t *seqs, const uint32_t *offs, uint4 *sai_c,
+void launch_seed(const IndexView &ix, const SeedParams &sp, const uint32_t *tb, const uint8_t *, const uint32_t *, uint4 *sai_c,
                  uint4 *sai_r, unsigned long long *ctr, hipStream_t st)
 {
     uint64_t items = (uint64_t)sp.n_reads * 2u * sp.spr;
     if (!items) return;
     uint32_t blocks = (uint32_t)((items + 255) / 256);
-    hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(256), 0, st, ix, sp, seqs, offs, sai_c, sai_r, ctr);
+    hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(256), 0, st, ix, sp, tb, sai_c, sai_r, ctr);
 }
 
-void launch_light(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
+void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint8_t *, const uint32_t *, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, unsigned long long *ctr, hipStream_t st)
 {
     if (!ap.n_reads) return;
-    hipLaunchKernelGGL(k_light, dim3((ap.n_reads + LT_WAVES - 1) / LT_WAVES), dim3(64 * LT_WAVES), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr);
+    hipLaunchKernelGGL(k_light, dim3((ap.n_reads + LT_WAVES - 1) / LT_WAVES), dim3(64 * LT_WAVES), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr);
 }
 
 // ---------------------------------------------------------------------------------------------

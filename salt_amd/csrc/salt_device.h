@@ -13,8 +13,8 @@
 //          1-in-8 samples by the reference's own LF walk (bwt.c:89-102) -- locate is then one load.
 //   r_pos  for every R suffix-array row the value Rbwt_back_bwt_sa() (rbwt.c:316-333) returns,
 //          again expanded once at attach time.
-//   c_wlkt / r_lkt  W-mer tables (W = 12..16, default 14, never above the seed length): for every W-mer
-//          the SA interval both searches hold after consuming it -- C: LKT_lookup_sa on its last 12 bases
+//   wlkt   W-mer table, 16 B per W-mer (W = 12..16, default 14, never above the seed length): for every W-mer
+//          the SA intervals both searches hold after consuming it (.x/.y = C, .z/.w = R; one gather serves both) -- C: LKT_lookup_sa on its last 12 bases
 //          (lookup.h:39-53, with that table's A-padded tail quirk) followed by W-12 steps of
 //          bwt_match_exact_alt (bwt.c:281-309); R: the first W iterations of Rbwt_exact_match_backward
 //          from (0, textLength) (rbwt.c:619-648).  Tabulated once at attach time; (1,0) = dead.
@@ -37,7 +37,7 @@ struct ImageHeader {
     uint32_t lkt_len, lkt_n;
     uint32_t r_text_len, r_inv_sa0, r_cum[6];
     uint32_t ref_len, r_lkt_len;
-    uint64_t off_c_occ, off_c_sa, off_lkt, off_r_occ, off_r_pos, off_r_lkt, off_ref, off_c_wlkt;
+    uint64_t off_c_occ, off_c_sa, off_lkt, off_r_occ, off_r_pos, off_wlkt, off_ref, off_unused;
     uint64_t n_c_blocks, n_r_blocks;
     uint64_t reserved[7];
 };
@@ -46,7 +46,7 @@ static const uint64_t IMAGE_MAGIC = 0x53414c5447465839ull;          // "SALTGFX9
 // What kernels receive (by value): resolved pointers + scalars.
 struct IndexView {
     const COcc *c_occ; const uint32_t *c_sa; const uint32_t *lkt;
-    const ROcc *r_occ; const uint32_t *r_pos; const uint2 *r_lkt; const uint32_t *ref; const uint2 *c_wlkt;
+    const ROcc *r_occ; const uint32_t *r_pos; const uint4 *wlkt; const uint32_t *ref;
     uint32_t c_primary, c_L2[5], c_seq_len;
     uint32_t r_text_len, r_inv_sa0, r_cum[6];
     uint32_t ref_len, lkt_len, r_lkt_len;
@@ -71,6 +71,29 @@ __device__ __forceinline__ uint32_t c_occ(const IndexView &ix, uint32_t k, uint3
     uint64_t mask = m == 64 ? ~0ull : ((1ull << m) - 1ull);
     uint64_t eq = ((c & 1) ? lo : ~lo) & ((c & 2) ? hi : ~hi) & mask;
     return sel4(cnt, c) + (uint32_t)__popcll(eq);
+}
+
+// Occ(k, c) and Occ(l, c) of one backward-search step (bwt_2occ, bwt.c:140-175).  Once an interval is narrow both
+// rows fall into the same checkpoint block, which is then fetched once: half the gather work of two c_occ calls.
+__device__ __forceinline__ uint32_t c_occ_eval(const uint4 cnt, const uint4 pl, const uint32_t k, const uint32_t c)
+{
+    const uint64_t lo = (uint64_t)pl.x | ((uint64_t)pl.y << 32), hi = (uint64_t)pl.z | ((uint64_t)pl.w << 32);
+    const uint32_t m = (k & 63u) + 1u;
+    const uint64_t mask = m == 64 ? ~0ull : ((1ull << m) - 1ull);
+    const uint64_t eq = ((c & 1) ? lo : ~lo) & ((c & 2) ? hi : ~hi) & mask;
+    return sel4(cnt, c) + (uint32_t)__popcll(eq);
+}
+__device__ __forceinline__ void c_occ2(const IndexView &ix, const uint32_t k, const uint32_t l, const uint32_t c, uint32_t &ok, uint32_t &ol)
+{
+    const uint32_t full = ix.c_L2[c + 1] - ix.c_L2[c];
+    const bool ks = k == ix.c_seq_len || k == 0xFFFFFFFFu, ls = l == ix.c_seq_len || l == 0xFFFFFFFFu;
+    const uint32_t kk = k - (k >= ix.c_primary), ll = l - (l >= ix.c_primary);
+    uint4 cnt = make_uint4(0, 0, 0, 0), pl = make_uint4(0, 0, 0, 0);
+    if (!ks) { const uint4 *p = reinterpret_cast<const uint4 *>(ix.c_occ + (kk >> 6)); cnt = p[0]; pl = p[1]; }
+    ok = ks ? (k == ix.c_seq_len ? full : 0u) : c_occ_eval(cnt, pl, kk, c);
+    if (ls) { ol = l == ix.c_seq_len ? full : 0u; return; }
+    if (ks || (ll >> 6) != (kk >> 6)) { const uint4 *p = reinterpret_cast<const uint4 *>(ix.c_occ + (ll >> 6)); cnt = p[0]; pl = p[1]; }
+    ol = c_occ_eval(cnt, pl, ll, c);
 }
 
 // symbol k of the $-removed C BWT (bwt_B0, bwt.h:64) -- used only by the attach-time SA expansion
@@ -98,6 +121,35 @@ __device__ __forceinline__ uint32_t r_occ(const IndexView &ix, uint32_t index, u
     uint64_t eh = ((c & 1) ? b0h : ~b0h) & ((c & 2) ? b1h : ~b1h) & ((c & 4) ? b2h : ~b2h) & mh;
     uint32_t base = c < 4 ? sel4(cnt, c) : (blk << 7) - (cnt.x + cnt.y + cnt.z + cnt.w);
     return base + (uint32_t)__popcll(el) + (uint32_t)__popcll(eh);
+}
+
+// Occ(a, c) and Occ(b, c) of one R backward-search step; one block fetch when both indices share it
+struct ROccBlk { uint4 cnt, q0, q1, q2; };
+__device__ __forceinline__ ROccBlk r_occ_load(const IndexView &ix, const uint32_t blk)
+{
+    const uint4 *p = reinterpret_cast<const uint4 *>(ix.r_occ + blk);
+    return ROccBlk{ p[0], p[1], p[2], p[3] };
+}
+__device__ __forceinline__ uint32_t r_occ_eval(const ROccBlk &r, const uint32_t index, const uint32_t c)
+{
+    const uint32_t blk = index >> 7, m = index & 127u;
+    const uint64_t b0l = (uint64_t)r.q0.x | ((uint64_t)r.q0.y << 32), b0h = (uint64_t)r.q0.z | ((uint64_t)r.q0.w << 32);
+    const uint64_t b1l = (uint64_t)r.q1.x | ((uint64_t)r.q1.y << 32), b1h = (uint64_t)r.q1.z | ((uint64_t)r.q1.w << 32);
+    const uint64_t b2l = (uint64_t)r.q2.x | ((uint64_t)r.q2.y << 32), b2h = (uint64_t)r.q2.z | ((uint64_t)r.q2.w << 32);
+    const uint64_t ml = m >= 64 ? ~0ull : ((1ull << m) - 1ull);
+    const uint64_t mh = m > 64 ? ((1ull << (m - 64)) - 1ull) : 0ull;
+    const uint64_t el = ((c & 1) ? b0l : ~b0l) & ((c & 2) ? b1l : ~b1l) & ((c & 4) ? b2l : ~b2l) & ml;
+    const uint64_t eh = ((c & 1) ? b0h : ~b0h) & ((c & 2) ? b1h : ~b1h) & ((c & 4) ? b2h : ~b2h) & mh;
+    const uint32_t base = c < 4 ? sel4(r.cnt, c) : (blk << 7) - (r.cnt.x + r.cnt.y + r.cnt.z + r.cnt.w);
+    return base + (uint32_t)__popcll(el) + (uint32_t)__popcll(eh);
+}
+__device__ __forceinline__ void r_occ2(const IndexView &ix, uint32_t a, uint32_t b, const uint32_t c, uint32_t &oa, uint32_t &ob)
+{
+    a -= (a > ix.r_inv_sa0); b -= (b > ix.r_inv_sa0);              // '$' is not stored (rbwt.c:165)
+    ROccBlk r = r_occ_load(ix, a >> 7);
+    oa = r_occ_eval(r, a, c);
+    if ((b >> 7) != (a >> 7)) r = r_occ_load(ix, b >> 7);
+    ob = r_occ_eval(r, b, c);
 }
 
 // Rbwt_bwt2nt (rbwt.h:103-122): BWT symbol of row pos; the '$' row reads as '#'

@@ -33,6 +33,7 @@ struct salt_gpu_ws {
     uint32_t max_reads = 0; uint64_t max_bases = 0;
     uint8_t *d_seqs = nullptr; uint32_t *d_offs = nullptr; salt_result_t *d_results = nullptr;
     uint4 *d_sai_c = nullptr, *d_sai_r = nullptr; uint64_t sai_cap = 0;
+    uint32_t *d_pm = nullptr, *d_tb = nullptr; uint64_t pm_cap = 0, tb_cap = 0;     // k_pack's records (words)
     unsigned long long *d_ctr = nullptr;
     uint32_t *d_queue = nullptr, *d_qctl = nullptr;   // reads k_light hands to k_heavy; {count, head}
     void *d_lvtab = nullptr;                          // one LV traceback table per persistent k_heavy block
@@ -45,7 +46,7 @@ struct salt_gpu_ws {
     int all_heavy = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
-    std::vector<hipEvent_t> ev;        // 6 per call: before k_seed, k_light, k_heavy, k_gap, k_gapfin, after
+    std::vector<hipEvent_t> ev;        // 7 per call: before k_pack, k_seed, k_light, k_heavy, k_gap, k_gapfin, after
     uint32_t n_timed = 0;
 };
 static const uint32_t MAX_TIMED = 256;
@@ -62,9 +63,8 @@ static void make_view(salt_gpu_index *ix)
     v.lkt = reinterpret_cast<const uint32_t *>(b + h.off_lkt);
     v.r_occ = reinterpret_cast<const ROcc *>(b + h.off_r_occ);
     v.r_pos = reinterpret_cast<const uint32_t *>(b + h.off_r_pos);
-    v.r_lkt = reinterpret_cast<const uint2 *>(b + h.off_r_lkt);
+    v.wlkt = reinterpret_cast<const uint4 *>(b + h.off_wlkt);
     v.ref = reinterpret_cast<const uint32_t *>(b + h.off_ref);
-    v.c_wlkt = reinterpret_cast<const uint2 *>(b + h.off_c_wlkt);
     v.c_primary = h.c_primary; memcpy(v.c_L2, h.c_L2, sizeof v.c_L2); v.c_seq_len = h.c_seq_len;
     v.r_text_len = h.r_text_len; v.r_inv_sa0 = h.r_inv_sa0; memcpy(v.r_cum, h.r_cum, sizeof v.r_cum);
     v.ref_len = h.ref_len; v.lkt_len = h.lkt_len; v.r_lkt_len = h.r_lkt_len;
@@ -95,7 +95,7 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     hd.lkt_len = h->lkt_len; hd.lkt_n = h->lkt_n;
     hd.r_text_len = h->r_text_len; hd.r_inv_sa0 = h->r_inv_sa0; memcpy(hd.r_cum, h->r_cum, sizeof hd.r_cum);
     hd.ref_len = h->ref_len;
-    {   // width of the device k-mer tables: 8 B x 4^W per table (W=14: 2 GiB each, W=16: 32 GiB each)
+    {   // width of the device k-mer tables: 16 B x 4^W (W=14: 4 GiB, W=16: 64 GiB)
         uint32_t w = 14;
         if (const char *e = getenv("SALT_GPU_LKT_LEN")) w = (uint32_t)atoi(e);
         if (h->l_seed > 0 && w > (uint32_t)h->l_seed) w = (uint32_t)h->l_seed;
@@ -113,8 +113,8 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     hd.off_lkt = off;   off = align_up(off + (uint64_t)h->lkt_n * 4, 256);
     hd.off_r_occ = off; off = align_up(off + hd.n_r_blocks * sizeof(ROcc), 256);
     hd.off_r_pos = off; off = align_up(off + ((uint64_t)h->r_text_len + 1) * 4, 256);
-    hd.off_r_lkt = off; off = align_up(off + (1ull << (2 * hd.r_lkt_len)) * 8, 256);
-    hd.off_c_wlkt = off; off = align_up(off + (1ull << (2 * hd.r_lkt_len)) * 8, 256);
+    hd.off_wlkt = off; off = align_up(off + (1ull << (2 * hd.r_lkt_len)) * 16, 256);
+    hd.off_unused = 0;
     hd.off_ref = off;   off = align_up(off + (ref_words + 4) * 4, 256);
     hd.bytes = off;
     ix->bytes = off;
@@ -161,7 +161,7 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     uint32_t *d_sa_s = nullptr, *d_r_sa = nullptr;
 #define CHK2(x) do { hipError_t e2 = (x); if (e2 != hipSuccess) { hipFree(ix->image); hipFree(d_sa_s); hipFree(d_r_sa); delete ix; \
     return fail(SALT_E_HIP, std::string(#x) + ": " + hipGetErrorString(e2)); } } while (0)
-    CHK2(hipMemset(ix->image, 0, hd.off_r_lkt));     // the two W-mer tables are fully written by their kernels
+    CHK2(hipMemset(ix->image, 0, hd.off_wlkt));      // the W-mer table is fully written by its kernel
     CHK2(hipMemcpy(ix->image, &hd, sizeof hd, hipMemcpyHostToDevice));
     CHK2(hipMemcpy(ix->image + hd.off_c_occ, cocc.data(), cocc.size() * sizeof(COcc), hipMemcpyHostToDevice));
     CHK2(hipMemcpy(ix->image + hd.off_lkt, h->lkt, (uint64_t)h->lkt_n * 4, hipMemcpyHostToDevice));
@@ -175,8 +175,7 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     CHK2(hipMemcpy(d_r_sa, h->r_sa, (uint64_t)h->r_n_sa * 4, hipMemcpyHostToDevice));
     launch_build_c_sa(ix->view, d_sa_s, h->c_sa_intv, reinterpret_cast<uint32_t *>(ix->image + hd.off_c_sa), nullptr);
     launch_build_r_pos(ix->view, d_r_sa, reinterpret_cast<uint32_t *>(ix->image + hd.off_r_pos), nullptr);
-    launch_build_r_lkt(ix->view, hd.r_lkt_len, reinterpret_cast<uint2 *>(ix->image + hd.off_r_lkt), nullptr);
-    launch_build_c_wlkt(ix->view, hd.r_lkt_len, reinterpret_cast<uint2 *>(ix->image + hd.off_c_wlkt), nullptr);
+    launch_build_wlkt(ix->view, hd.r_lkt_len, reinterpret_cast<uint4 *>(ix->image + hd.off_wlkt), nullptr);
     CHK2(hipGetLastError());
     CHK2(hipDeviceSynchronize());
     hipFree(d_sa_s); hipFree(d_r_sa);
@@ -257,7 +256,7 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
 {
     if (!ws) return;
     hipSetDevice(ws->ix->device);
-    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gq); hipFree(ws->d_ge);
+    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gq); hipFree(ws->d_ge);
     hipFree(ws->d_pe_scr); hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres); hipFree(ws->d_pctl); hipFree(ws->d_sw_scr);
     if (ws->stream) hipStreamDestroy(ws->stream);
     for (auto &e : ws->ev) if (e) hipEventDestroy(e);
@@ -305,26 +304,37 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
         HIPCHK(hipMalloc((void **)&ws->d_sai_r, items * sizeof(uint4)));
         ws->sai_cap = items;
     }
-    SeedParams sp; sp.n_reads = n_reads; sp.spr = spr; sp.l_seed = o->l_seed; sp.l_overlap = o->l_overlap;
+    const PackGeom pg = PackGeom::make(max_read_len);
+    if ((uint64_t)n_reads * pg.pm_stride > ws->pm_cap || (uint64_t)n_reads * pg.tb_stride > ws->tb_cap) {
+        HIPCHK(hipStreamSynchronize(st));
+        hipFree(ws->d_pm); hipFree(ws->d_tb); ws->d_pm = ws->d_tb = nullptr; ws->pm_cap = ws->tb_cap = 0;
+        const uint64_t nr = n_reads > ws->max_reads ? n_reads : ws->max_reads;
+        HIPCHK(hipMalloc((void **)&ws->d_pm, nr * pg.pm_stride * 4));
+        HIPCHK(hipMalloc((void **)&ws->d_tb, nr * pg.tb_stride * 4));
+        ws->pm_cap = nr * pg.pm_stride; ws->tb_cap = nr * pg.tb_stride;
+    }
+    SeedParams sp; sp.pg = pg; sp.n_reads = n_reads; sp.spr = spr; sp.l_seed = o->l_seed; sp.l_overlap = o->l_overlap;
     sp.max_seed = o->max_seed; sp.seed_only_ref = o->seed_only_ref;
     if (n_reads > ws->max_reads) return fail(SALT_E_CAPACITY, "more reads than the workspace holds");
-    AlignParams ap; ap.n_reads = n_reads; ap.spr = spr; ap.l_seed = o->l_seed; ap.max_locate = o->max_locate; ap.max_hits = o->max_hits;
+    AlignParams ap; ap.pg = pg; ap.n_reads = n_reads; ap.spr = spr; ap.l_seed = o->l_seed; ap.max_locate = o->max_locate; ap.max_hits = o->max_hits;
     ap.all_heavy = ws->all_heavy; ap.pe = pe; { const char *e = getenv("SALT_GPU_LIGHT_STOP"); ap.dbg_stop = e ? atoi(e) : 0; } ap.max_amb = pe ? 5u : 200u;
     if (pe && !ws->d_pe_scr) HIPCHK(hipMalloc((void **)&ws->d_pe_scr, (uint64_t)ws->heavy_blocks * PE_LOCI_CAP * 5));
     unsigned long long *ctr = o->collect_counters ? ws->d_ctr : nullptr;
     const bool timed = ws->timing && ws->n_timed < MAX_TIMED;
-    hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * 6] : nullptr;
+    hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * 7] : nullptr;
     HIPCHK(hipMemsetAsync(ws->d_qctl, 0, 32, st));
     if (timed) HIPCHK(hipEventRecord(ev[0], st));
-    launch_seed(ws->ix->view, sp, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r, ctr, st);
+    launch_pack(pg, n_reads, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_pm, ws->d_tb, st);
     if (timed) HIPCHK(hipEventRecord(ev[1], st));
-    if (!ap.all_heavy)
-        launch_light(ws->ix->view, ap, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
-                     static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, st);
+    launch_seed(ws->ix->view, sp, ws->d_tb, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r, ctr, st);
     if (timed) HIPCHK(hipEventRecord(ev[2], st));
+    if (!ap.all_heavy)
+        launch_light(ws->ix->view, ap, ws->d_pm, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
+                     static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, st);
+    if (timed) HIPCHK(hipEventRecord(ev[3], st));
     launch_heavy(ws->ix->view, ap, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
-                 static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, ws->heavy_blocks, ws->d_lvtab, ws->d_gq, ws->d_ge, ws->gcap, pe ? ws->d_pe_scr : nullptr, timed ? ev + 3 : nullptr, st);
-    if (timed) { HIPCHK(hipEventRecord(ev[5], st)); ++ws->n_timed; }
+                 static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, ws->heavy_blocks, ws->d_lvtab, ws->d_gq, ws->d_ge, ws->gcap, pe ? ws->d_pe_scr : nullptr, timed ? ev + 4 : nullptr, st);
+    if (timed) { HIPCHK(hipEventRecord(ev[6], st)); ++ws->n_timed; }
     HIPCHK(hipGetLastError());
     return SALT_OK;
 }
@@ -397,7 +407,7 @@ extern "C" int salt_gpu_ws_timing(salt_gpu_ws_t *ws, int enable)
     if (!ws) return fail(SALT_E_INVAL, "null argument");
     HIPCHK(hipSetDevice(ws->ix->device));
     if (enable && ws->ev.empty()) {
-        ws->ev.resize((size_t)MAX_TIMED * 6);
+        ws->ev.resize((size_t)MAX_TIMED * 7);
         for (auto &e : ws->ev) HIPCHK(hipEventCreate(&e));
     }
     ws->timing = enable != 0; ws->n_timed = 0;
@@ -411,8 +421,8 @@ extern "C" int salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[SALT_N_KERNELS
     for (int k = 0; k < SALT_N_KERNELS; ++k) ms[k] = 0;
     *n_calls = ws->n_timed;
     for (uint32_t i = 0; i < ws->n_timed; ++i) {
-        hipEvent_t *ev = &ws->ev[(size_t)i * 6];
-        HIPCHK(hipEventSynchronize(ev[5]));
+        hipEvent_t *ev = &ws->ev[(size_t)i * 7];
+        HIPCHK(hipEventSynchronize(ev[6]));
         for (int k = 0; k < SALT_N_KERNELS; ++k) {
             float a = 0;
             HIPCHK(hipEventElapsedTime(&a, ev[k], ev[k + 1]));

@@ -4,7 +4,7 @@
 // kernels replace a data-dependent walk by one load:
 //   k_build_c_sa   bwt_sa / bwt_invPsi                 (Align_src/bwt.c:89-102, bwt.h:67-71)
 //   k_build_r_pos  Rbwt_back_bwt_sa                    (Align_src/rbwt.c:316-333)
-//   k_build_r_lkt  first lkt_len steps of Rbwt_exact_match_backward from (0, textLength)
+//   k_build_wlkt   both searches' interval after the last W bases of a seed
 //                                                      (Align_src/rbwt.c:619-648, alnse.c:273-275)
 #include "salt_device.h"
 #include "salt_kernels.h"
@@ -44,43 +44,41 @@ k_build_r_pos(IndexView ix, const uint32_t *__restrict__ r_sa, uint32_t *__restr
     out[j] = sa_index > n_acgt ? r_sa[sa_index - n_acgt - 1] + step - 1 : 0xFFFFFFFFu;
 }
 
+// One entry per W-mer x (first base in the high bits): the C interval after LKT_lookup_sa on the last lkt_len bases
+// + bwt_match_exact_alt on the W - lkt_len bases before them (lookup.h:39-53, bwt.c:281-309) in .x/.y, and the R
+// interval after the first W steps of Rbwt_exact_match_backward from (0, textLength) (rbwt.c:619-648) in .z/.w;
+// (1, 0) = empty.  One 16-byte gather serves both searches of a seed.
 __global__ void __launch_bounds__(256)
-k_build_r_lkt(IndexView ix, uint32_t len, uint2 *__restrict__ out)
+k_build_wlkt(IndexView ix, uint32_t len, uint4 *__restrict__ out)
 {
     const uint64_t n = 1ull << (2 * len), stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t lk = ix.lkt_len;
     for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += stride) {
+        const uint32_t tail = (uint32_t)(x & ((1ull << (2 * lk)) - 1ull));
+        uint32_t k = ix.lkt[tail], l = ix.lkt[tail + 1] - 1;
+        for (uint32_t t = 0; t < len - lk && k <= l; ++t) {
+            uint32_t c = (uint32_t)(x >> (2 * (lk + t))) & 3u;
+            uint32_t ok = c_occ(ix, k - 1, c), ol = c_occ(ix, l, c);
+            k = ix.c_L2[c] + ok + 1; l = ix.c_L2[c] + ol;
+        }
         uint32_t k0 = 0, l0 = ix.r_text_len;
         for (uint32_t step = 0; step < len && k0 <= l0; ++step) {
             uint32_t c = (uint32_t)(x >> (2 * step)) & 3u;     // last base of the W-mer first
             k0 = ix.r_cum[c] + r_occ(ix, k0, c) + 1;
             l0 = ix.r_cum[c] + r_occ(ix, l0 + 1, c);
         }
-        out[x] = k0 <= l0 ? make_uint2(k0, l0) : make_uint2(1u, 0u);
+        uint4 e = make_uint4(1u, 0u, 1u, 0u);
+        if (k <= l) { e.x = k; e.y = l; }
+        if (k0 <= l0) { e.z = k0; e.w = l0; }
+        out[x] = e;
     }
 }
 
-__global__ void __launch_bounds__(256)
-k_build_c_wlkt(IndexView ix, uint32_t len, uint2 *__restrict__ out)
-{
-    const uint64_t n = 1ull << (2 * len), stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t lk = ix.lkt_len;
-    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += stride) {
-        const uint32_t tail = (uint32_t)(x & ((1ull << (2 * lk)) - 1ull));
-        uint32_t k = ix.lkt[tail], l = ix.lkt[tail + 1] - 1;       // LKT_lookup_sa (lookup.h:39-53)
-        for (uint32_t t = 0; t < len - lk && k <= l; ++t) {          // bwt_match_exact_alt on the bases before the tail
-            uint32_t c = (uint32_t)(x >> (2 * (lk + t))) & 3u;
-            uint32_t ok = c_occ(ix, k - 1, c), ol = c_occ(ix, l, c);
-            k = ix.c_L2[c] + ok + 1; l = ix.c_L2[c] + ol;
-        }
-        out[x] = k <= l ? make_uint2(k, l) : make_uint2(1u, 0u);
-    }
-}
-
-void launch_build_c_wlkt(const IndexView &ix, uint32_t len, uint2 *out, hipStream_t st)
+void launch_build_wlkt(const IndexView &ix, uint32_t len, uint4 *out, hipStream_t st)
 {
     uint64_t n = 1ull << (2 * len), blocks = (n + 255) / 256;
     if (blocks > (1u << 20)) blocks = 1u << 20;
-    hipLaunchKernelGGL(k_build_c_wlkt, dim3((uint32_t)blocks), dim3(256), 0, st, ix, len, out);
+    hipLaunchKernelGGL(k_build_wlkt, dim3((uint32_t)blocks), dim3(256), 0, st, ix, len, out);
 }
 
 void launch_build_c_sa(const IndexView &ix, const uint32_t *sa_sampled, uint32_t sa_intv, uint32_t *out, hipStream_t st)
@@ -93,13 +91,6 @@ void launch_build_r_pos(const IndexView &ix, const uint32_t *r_sa, uint32_t *out
 {
     uint64_t n = (uint64_t)ix.r_text_len + 1;
     hipLaunchKernelGGL(k_build_r_pos, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, ix, r_sa, out);
-}
-
-void launch_build_r_lkt(const IndexView &ix, uint32_t len, uint2 *out, hipStream_t st)
-{
-    uint64_t n = 1ull << (2 * len), blocks = (n + 255) / 256;
-    if (blocks > (1u << 20)) blocks = 1u << 20;
-    hipLaunchKernelGGL(k_build_r_lkt, dim3((uint32_t)blocks), dim3(256), 0, st, ix, len, out);
 }
 
 } // namespace salt

@@ -6,11 +6,29 @@
 
 namespace salt {
 
+// Per-batch packed copies of the reads (k_pack), fixed stride per read so that no kernel waits for offs[]:
+//   pm record (pm_stride words): one-hot nibble words (nt2bit, editdistance.c:40), 8 bases per word, base i in bits
+//       4*(i%8)..+3 (the mixRef layout): words [0, nw8) forward strand, [nw8, 2*nw8) reverse complement, [2*nw8] = L
+//   tb record (tb_stride words): 2-bit codes, 16 bases per word, base i in bits 30-2*(i%16) (first base highest, so a
+//       k-mer is a funnel shift): [0, nw16) forward, [nw16, 2*nw16) reverse complement; then 'is N' bits, 32 bases
+//       per word, base i in bit 31-(i%32): [2*nw16, +nw32) forward, [.., +nw32) reverse; then L
+struct PackGeom {
+    uint32_t nw8, nw16, nw32, pm_stride, tb_stride;
+    __host__ __device__ static PackGeom make(uint32_t max_len)
+    {
+        if (max_len < 1) max_len = 1;
+        PackGeom g; g.nw8 = (max_len + 7) / 8; g.nw16 = (max_len + 15) / 16; g.nw32 = (max_len + 31) / 32;
+        g.pm_stride = (2 * g.nw8 + 1 + 3) & ~3u; g.tb_stride = (2 * g.nw16 + 2 * g.nw32 + 1 + 3) & ~3u;
+        return g;
+    }
+};
+
 struct SeedParams {
     uint32_t n_reads, spr;          // spr: seed slots per (read, strand) = ceil((Lmax-k+1)/overlap)
     int32_t  l_seed, l_overlap;
     uint32_t max_seed;
     int32_t  seed_only_ref;
+    PackGeom pg;
 };
 
 struct AlignParams {
@@ -18,6 +36,7 @@ struct AlignParams {
     int32_t  l_seed;
     uint32_t max_locate;
     int32_t  max_hits;
+    PackGeom pg;
     int32_t  dbg_stop;              // debug/A-B: k_light leaves after phase dbg_stop (1..4); results are then garbage
     int32_t  all_heavy;             // debug/A-B: skip k_light, k_heavy walks reads 0..n_reads-1
     int32_t  pe;                    // 1: mates of a paired-end batch -- alnse_overlap semantics (alnse.c:985-1044, 501-629):
@@ -26,9 +45,10 @@ struct AlignParams {
 };
 static const uint32_t PE_LOCI_CAP = 32768;      // loci per strand a PE mate may enumerate (global scratch)
 
-void launch_seed(const IndexView &ix, const SeedParams &sp, const uint8_t *seqs, const uint32_t *offs, uint4 *sai_c,
+void launch_pack(const PackGeom &pg, uint32_t n_reads, const uint8_t *seqs, const uint32_t *offs, uint32_t *pm, uint32_t *tb, hipStream_t st);
+void launch_seed(const IndexView &ix, const SeedParams &sp, const uint32_t *tb, const uint8_t *seqs, const uint32_t *offs, uint4 *sai_c,
                  uint4 *sai_r, unsigned long long *ctr, hipStream_t st);
-void launch_light(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
+void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, unsigned long long *ctr, hipStream_t st);
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, uint32_t *qctl, unsigned long long *ctr,
@@ -58,7 +78,6 @@ void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const 
 // attach-time expansion kernels (salt_index.hip)
 void launch_build_c_sa(const IndexView &ix, const uint32_t *sa_sampled, uint32_t sa_intv, uint32_t *out, hipStream_t st);
 void launch_build_r_pos(const IndexView &ix, const uint32_t *r_sa, uint32_t *out, hipStream_t st);
-void launch_build_r_lkt(const IndexView &ix, uint32_t len, uint2 *out, hipStream_t st);
-void launch_build_c_wlkt(const IndexView &ix, uint32_t len, uint2 *out, hipStream_t st);
+void launch_build_wlkt(const IndexView &ix, uint32_t len, uint4 *out, hipStream_t st);
 
 } // namespace salt
