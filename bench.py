@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("SALT_BENCH_WORKLOAD", "chr21"))
     ap.add_argument("--cpu-sample", type=int, default=200000, help="reads given to the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (experiments; default: the workload's own batch)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -73,7 +74,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     cfg = workload.CONFIGS[args.workload]
-    L, n_reads = cfg["read_len"], cfg["n_reads"]
+    L, n_reads = cfg["read_len"], (args.reads or cfg["n_reads"])
     cache = os.environ.get("SALT_BENCH_CACHE", "/tmp/salt_bench_cache")
 
     # ---- index files (rank 0 builds them with the product's own salt-idx equivalent) ----

@@ -105,6 +105,7 @@ enum { SALT_CTR_LKT, SALT_CTR_OCC_C, SALT_CTR_OCC_R, SALT_CTR_SA_C, SALT_CTR_SA_
        SALT_CTR_T_LOAD, SALT_CTR_T_GATHER, SALT_CTR_T_LOCATE, SALT_CTR_T_SORT, SALT_CTR_T_DEDUP, SALT_CTR_T_VERIFY,
        SALT_CTR_T_SCAN, SALT_CTR_T_GAP, SALT_CTR_T_TAIL, SALT_CTR_HEAVY_READS, SALT_CTR_X0, SALT_CTR_X1, SALT_CTR_X2, SALT_CTR_X3,
        SALT_CTR_LT_SEEDS, SALT_CTR_LT_LOCATE, SALT_CTR_LT_SORT, SALT_CTR_LT_VERIFY, SALT_CTR_LT_OUT, SALT_CTR_LT_SAMPLES,   /* k_light: s_memtime ticks of every 128th read */
+       SALT_CTR_MAX_HEAVY, SALT_CTR_MAX_GAPFIN,   /* slowest read of k_heavy / k_gapfin: (s_memrealtime ticks << 32) | read index */
        SALT_CTR_N };
 
 typedef struct salt_gpu_index salt_gpu_index_t;

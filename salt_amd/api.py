@@ -22,7 +22,7 @@ MAX_HITS = 5
 MAX_CIGAR_OPS = 64
 CTR_NAMES = ["lkt", "occ_c", "occ_r", "sa_c", "sa_r", "verify", "verify_words", "lv", "reads", "bases", "loci",
              "t_load", "t_gather", "t_locate", "t_sort", "t_dedup", "t_verify", "t_scan", "t_gap", "t_tail", "heavy_reads", "x0", "x1", "x2", "x3",
-             "lt_seeds", "lt_locate", "lt_sort", "lt_verify", "lt_out", "lt_samples"]
+             "lt_seeds", "lt_locate", "lt_sort", "lt_verify", "lt_out", "lt_samples", "max_heavy", "max_gapfin"]
 
 
 class SaltError(RuntimeError):

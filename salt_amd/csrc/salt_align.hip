@@ -263,8 +263,7 @@ static constexpr int LLV_N = 32;                 // candidates per round (lanes 
 struct LaneLv { uint32_t T[LLV_N * LLV_TW]; uint8_t rows[2][LLV_W][LLV_N]; };
 struct LvBytes { uint8_t T[MAXL + 4 + 64]; uint8_t P[MAXL + 64]; };
 struct WaveLds {                                 // ~10.7 KB: 14-15 one-wave blocks per CU
-    uint8_t  seq[2][MAXL];
-    uint32_t pm[2][MAXL / 8];
+    uint32_t pm[2][MAXL / 8];                               // one-hot nibble words of the read, both strands (k_pack)
     union { SaiLists sai; LaneLv llv; LvBytes lvb; } u;     // seeds | lane-LV scratch | wave-LV byte strings
     uint8_t  cand_e[MAXLOC];
     uint32_t loci[MAXLOC];
@@ -382,29 +381,44 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
     PhaseClock pc(a.phase);
     const uint64_t base_item = ((uint64_t)r * 2u + (uint32_t)strand) * ap.spr;
     uint32_t n_list[2] = { 0, 0 };
+    const uint32_t cap_total = PE ? a.loci_cap : ap.max_locate;
+    uint32_t rows = 0;                                        // suffix-array rows the locate loops would enumerate (saturating)
     // gather valid seeds in seed order (n_C / n_back_R grow in seed_start order, alnse.c:265-300)
-    for (int which = 0; which < 2; ++which) {
-        const gp_u32x4 src = which == 0 ? sai_c : sai_r;
-        uint32_t n = 0;
-        for (uint32_t b = 0; b < ap.spr; b += 64) {
-            uint32_t slot = b + lane;
-            uint4 v = make_uint4(1, 0, 0, 0);
-            if (slot < ap.spr) { const u32x4_t t = src[base_item + slot]; v = make_uint4(t.x, t.y, t.z, t.w); }
-            uint64_t m = __ballot(v.w != 0);
-            if (v.w) { uint32_t at = n + (uint32_t)__popcll(m & lt); w.u.sai.sp[which][at] = v.x; w.u.sai.ep[which][at] = v.y; w.u.sai.off[which][at] = v.z; }
-            n += (uint32_t)__popcll(m);
+    for (uint32_t b = 0; b < ap.spr; b += 64) {
+        const uint32_t slot = b + lane;
+        uint4 v2[2] = { make_uint4(1, 0, 0, 0), make_uint4(1, 0, 0, 0) };
+        if (slot < ap.spr) {                                  // both lists' loads are in flight together
+            const u32x4_t tc = sai_c[base_item + slot], tr = sai_r[base_item + slot];
+            v2[0] = make_uint4(tc.x, tc.y, tc.z, tc.w); v2[1] = make_uint4(tr.x, tr.y, tr.z, tr.w);
         }
-        n_list[which] = n;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const uint4 v = v2[which];
+            const uint32_t n = n_list[which];
+            uint64_t m = __ballot(v.w != 0);
+            uint32_t sz = 0;
+            if (v.w) {
+                uint32_t at = n + (uint32_t)__popcll(m & lt); w.u.sai.sp[which][at] = v.x; w.u.sai.ep[which][at] = v.y; w.u.sai.off[which][at] = v.z;
+                sz = v.y - v.x + 1u;
+                if (which == 1 && !PE) { uint32_t skip = sz / 0x40000u; if (skip > 1) sz = (sz + skip - 1) / skip; }
+                if (sz > cap_total) sz = cap_total + 1u;
+            }
+            for (int o = 32; o > 0; o >>= 1) sz += (uint32_t)__shfl_xor((int)sz, o);
+            rows = rows + sz > cap_total ? cap_total + 1u : rows + sz;
+            n_list[which] = n + (uint32_t)__popcll(m);
+        }
     }
     WSYNC();
-    if (lane < 2) sai_introsort(w.u.sai, (int)lane, (int)n_list[lane]);      // alnse.c:307-308
+    // The reference orders both lists by interval size (alnse.c:307-308, klib introsort).  The order only decides WHICH
+    // rows are located before a cap stops the loops; when every row is located the loci are the same set, and they
+    // are sorted right after -- so the (serial) replica of the sort runs only when the cap can bite.
+    if (rows > cap_total && lane < 2) sai_introsort(w.u.sai, (int)lane, (int)n_list[lane]);
     WSYNC();
     pc.stamp(SALT_CTR_T_GATHER);
     // locate: SE under the global max_locate cap (alnse_locate_alt, alnse.c:633-731); PE with the per-interval cap
     // and the 0x40000 global cap of alnse_locate (alnse.c:501-629; here bounded by the scratch capacity)
     uint32_t n = 0;
     bool full = false;
-    const uint32_t cap_total = PE ? a.loci_cap : ap.max_locate;
     for (uint32_t i = 0; i < n_list[0] && !full; ++i) {
         const uint32_t sp = w.u.sai.sp[0][i], off = w.u.sai.off[0][i];
         uint32_t ep = w.u.sai.ep[0][i];
@@ -543,43 +557,42 @@ __device__ __forceinline__ void mismatch_batch(const IndexView &ix, const uint32
 // Needs (L+7)/8 + 1 <= 16 words, i.e. L <= 120.  Writes min(count, INF) for candidates [0, n) to out[].
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
-// mismatches of one candidate, computed by its 4 lanes (sub = 0..3 holds words 4*sub..4*sub+3 of the window)
-__device__ __forceinline__ uint32_t quad_mismatch(const u32x4_a4 x, const uint32_t pos, const uint32_t (&pmw)[4], const uint32_t sub,
-                                                  const uint32_t nw, const uint32_t L)
+// mismatches of one candidate, computed by its 4 lanes (sub = 0..3 holds words 4*sub..4*sub+3 of the window).
+// pmw: the read's one-hot words of this lane (zero past the read's end), nvalid: bases of the read inside them.
+// A base matches when (reference mask & one-hot) != 0 (ed_mismatch, editdistance.c:88-163); matches are counted
+// per nibble with one add (bit 3 of (n & 7) + 7 | n is set iff the nibble n is non-zero) and subtracted from nvalid.
+__device__ __forceinline__ uint32_t quad_mismatch(const u32x4_a4 x, const uint32_t pos, const uint32_t (&pmw)[4], const uint32_t nvalid)
 {
     const uint32_t sh = (pos & 7u) * 4u;
     const uint32_t nxt = (uint32_t)__shfl_down((int)x.x, 1);             // first word of the next lane of the quad
     const uint32_t xs[5] = { x.x, x.y, x.z, x.w, nxt };
-    uint32_t mism = 0;
+    uint32_t match = 0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const uint32_t j = 4 * sub + t;
-        if (j < nw) {
-            const uint32_t w = sh ? ((xs[t] >> sh) | (xs[t + 1] << (32 - sh))) : xs[t];
-            const uint32_t y = w & pmw[t];
-            const uint32_t nz = (y | (y >> 1) | (y >> 2) | (y >> 3)) & 0x11111111u;
-            const uint32_t rem = L - j * 8;
-            const uint32_t vm = rem >= 8 ? 0x11111111u : (0x11111111u >> (4 * (8 - rem)));
-            mism += (uint32_t)__popc(vm) - (uint32_t)__popc(nz & vm);
-        }
+        const uint32_t w = __funnelshift_r(xs[t], xs[t + 1], sh);        // window word: reference nibbles pos+8j .. pos+8j+7
+        const uint32_t y = w & pmw[t];
+        match += (uint32_t)__popc((((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u);
     }
+    uint32_t mism = nvalid - match;
     mism += (uint32_t)__shfl_xor((int)mism, 1);
     mism += (uint32_t)__shfl_xor((int)mism, 2);
     return mism;
 }
 
+template <int G>                                                         // groups of 16 candidates whose loads are in flight together
 __device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, const uint32_t *pm, uint32_t L,
                                              const uint32_t *cand, uint32_t n, uint8_t *out)
 {
     const uint32_t lane = lane_id(), sub = lane & 3u, q = lane >> 2;
     const uint32_t nw = (L + 7) >> 3;
+    const uint32_t nvalid = L > 32u * sub ? (L - 32u * sub < 32u ? L - 32u * sub : 32u) : 0u;
     uint32_t pmw[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) pmw[t] = (4 * sub + t) < nw ? pm[4 * sub + t] : 0u;
-    for (uint32_t c0 = 0; c0 < n; c0 += 64) {                           // up to 4 groups of 16 candidates per trip
-        uint32_t pos[4]; u32x4_a4 x[4]; bool act[4];
+    for (uint32_t c0 = 0; c0 < n; c0 += 16u * G) {                      // up to G groups of 16 candidates per trip
+        uint32_t pos[G]; u32x4_a4 x[G]; bool act[G];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < G; ++g) {
             if (c0 + 16u * g >= n) break;                                // (uniform) nothing left for this group
             const uint32_t c = c0 + 16u * g + q;
             act[g] = c < n;
@@ -587,9 +600,9 @@ __device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, c
             x[g] = *reinterpret_cast<const u32x4_a4 *>(ref + (pos[g] >> 3) + 4 * sub);
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < G; ++g) {
             if (c0 + 16u * g >= n) break;
-            const uint32_t mism = quad_mismatch(x[g], pos[g], pmw, sub, nw, L);
+            const uint32_t mism = quad_mismatch(x[g], pos[g], pmw, nvalid);
             if (act[g] && sub == 0) out[c0 + 16u * g + q] = (uint8_t)(mism > 3 ? INF : mism);
         }
     }
@@ -601,6 +614,7 @@ __device__ __forceinline__ void verify_quads_2(const uint32_t *__restrict__ ref,
 {
     const uint32_t lane = lane_id(), sub = lane & 3u, q = lane >> 2;
     const uint32_t nw = (L + 7) >> 3, n = n0 + n1;
+    const uint32_t nvalid = L > 32u * sub ? (L - 32u * sub < 32u ? L - 32u * sub : 32u) : 0u;
     uint32_t pa[4], pb[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { const bool in = (4 * sub + t) < nw; pa[t] = in ? pm0[4 * sub + t] : 0u; pb[t] = in ? pm1[4 * sub + t] : 0u; }
@@ -618,7 +632,7 @@ __device__ __forceinline__ void verify_quads_2(const uint32_t *__restrict__ ref,
         for (int g = 0; g < 4; ++g) {
             if (b + 16u * g >= n) break;
             const uint32_t pw[4] = { rev[g] ? pb[0] : pa[0], rev[g] ? pb[1] : pa[1], rev[g] ? pb[2] : pa[2], rev[g] ? pb[3] : pa[3] };
-            const uint32_t mism = quad_mismatch(x[g], pos[g], pw, sub, nw, L);
+            const uint32_t mism = quad_mismatch(x[g], pos[g], pw, nvalid);
             if (act[g] && sub == 0) {
                 const uint32_t c = b + 16u * g + q;
                 const uint8_t v = (uint8_t)(mism > 3 ? INF : mism);
@@ -689,8 +703,30 @@ __device__ __attribute__((noinline)) uint32_t lv_lanes(LaneLv &s, const uint32_t
 {
     const int lane = (int)lane_id() & (LLV_N - 1);      // callers pass active = false for lanes >= LLV_N
     const uint32_t *T = s.T + lane * LLV_TW;
-    auto nT = [&](int i) -> uint32_t { return (i >= 0 && i < tlen) ? (T[i >> 3] >> (4 * (i & 7))) & 15u : 0u; };
-    auto nP = [&](int i) -> uint32_t { return i < plen ? (pm[i >> 3] >> (4 * (i & 7))) & 15u : 0u; };
+    const int nwp = (plen + 7) >> 3;
+    // 8 nibbles starting at base i: pattern (zeros past plen) / text (zeros outside [0, tlen); i may be negative)
+    auto wP = [&](int i) -> uint32_t {
+        const int j = i >> 3;
+        const uint32_t lo = j < nwp ? pm[j] : 0u, hi = j + 1 < nwp ? pm[j + 1] : 0u;
+        return __funnelshift_r(lo, hi, 4u * (uint32_t)(i & 7));
+    };
+    auto wT = [&](int i) -> uint32_t {
+        if (i < 0) return i <= -8 ? 0u : T[0] << (4 * -i);
+        const int j = i >> 3;
+        const uint32_t lo = j < LLV_TW ? T[j] : 0u, hi = j + 1 < LLV_TW ? T[j + 1] : 0u;
+        return __funnelshift_r(lo, hi, 4u * (uint32_t)(i & 7));
+    };
+    // bases matching from i on diagonal d, 8 per step: a base matches when mask & one-hot != 0 (LandauVishkin.c:42-53,85-96)
+    auto extend = [&](int d, int i, int end) -> int {
+        while (i < end) {
+            const uint32_t y = wP(i) & wT(d + i);
+            const uint32_t z = ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;     // bit 3 of a nibble: no match there
+            const int run = z ? (__ffs((int)z) - 1) >> 2 : 8;
+            i += run;
+            if (run < 8) break;
+        }
+        return i < end ? i : end;
+    };
     auto RD = [&](int row, int d) -> int { return (int)s.rows[row][d + LLV_K + 1][lane] - 2; };
     auto WR = [&](int row, int d, int v) { s.rows[row][d + LLV_K + 1][lane] = (uint8_t)(v + 2); };
     for (int row = 0; row < 2; ++row) for (int d = 0; d < LLV_W; ++d) s.rows[row][d][lane] = 0;      // -2 everywhere
@@ -698,8 +734,7 @@ __device__ __attribute__((noinline)) uint32_t lv_lanes(LaneLv &s, const uint32_t
     uint32_t result = 255;
     bool done = !active;
     if (active) {
-        int i = 0;
-        while (i < end0 && (nP(i) & nT(i)) != 0) ++i;
+        const int i = extend(0, 0, end0);
         WR(0, 0, i);
         if (i == end0) { result = (uint32_t)(plen > end0 ? plen - end0 : 0); done = true; }
     }
@@ -712,10 +747,9 @@ __device__ __attribute__((noinline)) uint32_t lv_lanes(LaneLv &s, const uint32_t
             const int left = RD(prev, d - 1), right = RD(prev, d + 1) + 1;
             if (left > best) best = left;
             if (right > best) best = right;
-            if (nP(best) == nT(d + best)) {                               // equality gate (LandauVishkin.c:79)
+            if ((wP(best) & 15u) == (wT(d + best) & 15u)) {               // equality gate (LandauVishkin.c:79)
                 const int end = plen < tlen - d ? plen : tlen - d;
-                if (best >= end) best = end;
-                else { int i = best; while (i < end && (nP(i) & nT(d + i)) != 0) ++i; best = i; }
+                best = best >= end ? end : extend(d, best, end);
             }
             if (best == plen) { result = (uint32_t)e; done = true; }
             else WR(cur, d, best);
@@ -734,8 +768,7 @@ __device__ void lv_unpack(const uint32_t *ref_generic, WaveLds &w, int strand, u
         w.u.lvb.T[i] = i < tlen ? (uint8_t)((ref[p >> 3] >> (4 * (p & 7u))) & 15u) : (uint8_t)0;
     }
     for (uint32_t i = lane_id(); i < L + 48; i += 64) {
-        uint8_t c = i < L ? w.seq[strand][i] : (uint8_t)5;
-        w.u.lvb.P[i] = c > 4 ? (uint8_t)0 : (c > 3 ? (uint8_t)15 : (uint8_t)(1u << c));
+        w.u.lvb.P[i] = i < L ? (uint8_t)((w.pm[strand][i >> 3] >> (4 * (i & 7u))) & 15u) : (uint8_t)0;
     }
     WSYNC();
 }
@@ -803,14 +836,15 @@ static constexpr uint32_t GAP_DEFER_MIN = 128;    // candidates (both strands) f
 
 template <int MODE, bool PE>
 __device__ __forceinline__ void align_general(const IndexView ix, const AlignParams ap, WaveLds &w, const uint32_t r,
-                              const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+                              const uint32_t *__restrict__ pm,
                               const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r,
                               salt_result_t *__restrict__ results, unsigned long long *__restrict__ ctr,
                               unsigned long long *phase, LvTables *lvtab, const GapCtx g, uint32_t *pe_loci, uint8_t *pe_cand)
 {
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull;
-    const uint32_t off = offs[r], L = offs[r + 1] - off;
+    const uint32_t *rec = pm + (uint64_t)r * ap.pg.pm_stride;               // k_pack's record of this read
+    const uint32_t L = rec[2 * ap.pg.nw8];
     salt_result_t *out = results + r;
     uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_lv = 0, c_loci = 0;
     PhaseClock pc(phase);
@@ -819,18 +853,17 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     uint8_t *const cand_e = PE ? pe_cand : w.cand_e;
     const uint32_t loci_cap = PE ? PE_LOCI_CAP : (uint32_t)MAXLOC;
 
-    // ---- load the read, both strands (query.c:177-183, 46-71) ----
+    // ---- the read: one-hot masks of both strands, 8 bases per word, LSB first like the mixRef (editdistance.c:40) ----
+    const uint32_t nw = (L + 7) >> 3;
     uint32_t n_amb = 0;
-    for (uint32_t b = 0; b < L; b += 64) {
-        uint32_t i = b + lane; bool isn = false;
-        if (i < L) {
-            uint8_t c = seqs[off + i];
-            if (c > 4) c = 4;
-            w.seq[0][i] = c; w.seq[1][L - 1 - i] = c < 4 ? (uint8_t)(3 - c) : c;
-            isn = c > 3;
-        }
-        n_amb += (uint32_t)__popcll(__ballot(isn));
+    for (uint32_t t = lane; t < 2 * nw; t += 64) {
+        const uint32_t s = t >= nw, j = s ? t - nw : t;
+        const uint32_t word = rec[s * ap.pg.nw8 + j];
+        w.pm[s][j] = word;
+        if (!s) n_amb += (uint32_t)__popc(word & (word >> 1) & (word >> 2) & (word >> 3) & 0x11111111u);     // N = all four bits
     }
+    if (ap.max_amb < L) { for (int o = 32; o > 0; o >>= 1) n_amb += (uint32_t)__shfl_xor((int)n_amb, o); }
+    else n_amb = 0;                                           // (uniform) the limit cannot be passed
     WSYNC();
     // result defaults (query_read_seq, query.c:199-206)
     uint32_t q_pos = 0xFFFFFFFFu; uint32_t q_strand = 3, q_ndiff = 255, q_gap = 255;
@@ -843,20 +876,6 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         }
         return;
     }
-    // one-hot masks, 8 bases per word, LSB first like the mixRef (editdistance.c:40)
-    const uint32_t nw = (L + 7) >> 3;
-    for (uint32_t t = lane; t < 2 * nw; t += 64) {
-        uint32_t s = t >= nw, j = s ? t - nw : t, word = 0;
-        for (uint32_t q = 0; q < 8; ++q) {
-            uint32_t i = j * 8 + q;
-            uint32_t c = i < L ? w.seq[s][i] : 5u;
-            uint32_t msk = c < 4 ? (1u << c) : (c == 4 ? 15u : 0u);
-            word |= msk << (4 * q);
-        }
-        w.pm[s][j] = word;
-    }
-    WSYNC();
-
     pc.stamp(SALT_CTR_T_LOAD);
     // ---- gap-free pass over both strands (alnse.c:1077-1084) ----
     uint32_t bound = 3;
@@ -872,7 +891,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
         uint32_t call_best_n = INF, call_best_pos = 0;
         // phase A: every candidate's distance, 4 per lane with all loads in flight
-        if (L <= 120) verify_quads(ix.ref, w.pm[strand], L, loci, n_cand, cand_e);
+        if (L <= 120) verify_quads<8>(ix.ref, w.pm[strand], L, loci, n_cand, cand_e);
         else if (L <= 8 * 13) {
             for (uint32_t b = 0; b < n_cand; b += 256) {
                 uint32_t pp[4], vv[4]; bool aa[4];
@@ -1061,7 +1080,11 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         }
 
     pc.stamp(SALT_CTR_T_TAIL);
-    if (phase) pc.add(SALT_CTR_X3, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - rt0));
+    if (phase) {
+        const unsigned long long dt = (unsigned long long)(__builtin_amdgcn_s_memrealtime() - rt0);
+        pc.add(SALT_CTR_X3, dt);
+        if (ctr && lane == 0 && MODE != 1) atomicMax(ctr + (MODE == 0 ? SALT_CTR_MAX_HEAVY : SALT_CTR_MAX_GAPFIN), (dt << 32) | r);
+    }
     if (ctr) {
         for (int o = 32; o > 0; o >>= 1) c_vwords += __shfl_down(c_vwords, o);
         if (lane == 0) {
@@ -1079,8 +1102,8 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
 //   qctl[2] reads queued for k_gap       qctl[3] k_gap head      qctl[4] k_gapfin head
 // ---------------------------------------------------------------------------------------------
 template <int MODE, bool PE>
-__device__ __forceinline__ void persistent_body(const IndexView &ix, const AlignParams &ap, const uint8_t *__restrict__ seqs,
-                                                const uint32_t *__restrict__ offs, const uint4 *__restrict__ sai_c,
+__device__ __forceinline__ void persistent_body(const IndexView &ix, const AlignParams &ap, const uint32_t *__restrict__ pm,
+                                                const uint4 *__restrict__ sai_c,
                                                 const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
                                                 const uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl,
                                                 unsigned long long *__restrict__ ctr, LvTables *__restrict__ lvtab,
@@ -1107,7 +1130,7 @@ __device__ __forceinline__ void persistent_body(const IndexView &ix, const Align
         if (MODE == 0) r = ap.all_heavy ? it : queue[it];
         else if (MODE == 1) { const uint32_t per = 2u * (MAXLOC / LLV_N); g.slot = it / per; g.strand = (it % per) / (MAXLOC / LLV_N); g.chunk = it % (MAXLOC / LLV_N); r = gq[g.slot]; }
         else { g.slot = it; r = gq[it]; }
-        align_general<MODE, PE>(ix, ap, w, r, seqs, offs, sai_c, sai_r, results, MODE == 1 ? nullptr : ctr, MODE == 1 ? nullptr : phase, lvtab + blockIdx.x, g,
+        align_general<MODE, PE>(ix, ap, w, r, pm, sai_c, sai_r, results, MODE == 1 ? nullptr : ctr, MODE == 1 ? nullptr : phase, lvtab + blockIdx.x, g,
                             pe_scr ? reinterpret_cast<uint32_t *>(pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5) : nullptr,
                             pe_scr ? pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5 + (size_t)PE_LOCI_CAP * 4 : nullptr);
         if (MODE == 0 && phase && threadIdx.x == 0) s_phase[SALT_CTR_HEAVY_READS] += 1;
@@ -1121,12 +1144,12 @@ __device__ __forceinline__ void persistent_body(const IndexView &ix, const Align
 
 #define PERSISTENT_KERNEL(NAME, MODE, PE)                                                                                 \
 __global__ void __launch_bounds__(64)                                                                                   \
-NAME(IndexView ix, AlignParams ap, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,                  \
+NAME(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,                                                     \
      const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,             \
      const uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl, unsigned long long *__restrict__ ctr,             \
      LvTables *__restrict__ lvtab, uint32_t *__restrict__ gq, uint8_t *__restrict__ ge, uint32_t gcap,                  \
      uint8_t *__restrict__ pe_scr)                                                                                      \
-{ persistent_body<MODE, PE>(ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, lvtab, gq, ge, gcap, pe_scr); }
+{ persistent_body<MODE, PE>(ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr, lvtab, gq, ge, gcap, pe_scr); }
 PERSISTENT_KERNEL(k_heavy, 0, false)
 PERSISTENT_KERNEL(k_gap, 1, false)
 PERSISTENT_KERNEL(k_gapfin, 2, false)
@@ -1386,7 +1409,7 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
 // seed-and-verify mapping (query.c:282-296)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
-k_pe_final(IndexView ix, uint32_t n_pairs, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+k_pe_final(IndexView ix, PackGeom pg, uint32_t n_pairs, const uint32_t *__restrict__ pm,
            salt_result_t *__restrict__ res, const PePair *__restrict__ pairs, const PeSwRes *__restrict__ sw, LvTables *__restrict__ lvtab,
            uint32_t *__restrict__ head)
 {
@@ -1420,13 +1443,14 @@ k_pe_final(IndexView ix, uint32_t n_pairs, const uint8_t *__restrict__ seqs, con
     for (int m = 0; m < 2; ++m) {
         if (m == rescued) continue;
         salt_result_t *q = res + 2 * p + m;
-        const uint32_t off = offs[2 * p + m], L = offs[2 * p + m + 1] - off;
+        const uint32_t *rec = pm + (uint64_t)(2 * p + m) * pg.pm_stride;
+        const uint32_t L = rec[2 * pg.nw8];
         if (lane == 0) { q->seq_start = 0; q->seq_end = (uint16_t)(L - 1); }
         const uint32_t pos = q->pos;
         if (pos == 0xFFFFFFFFu) { if (lane == 0) q->n_cigar = 0; continue; }
         if (q->is_gap) {
             const int strand = q->strand;
-            for (uint32_t i = lane; i < L; i += 64) { uint8_t c = seqs[off + i]; if (c > 4) c = 4; w.seq[0][i] = c; w.seq[1][L - 1 - i] = c < 4 ? (uint8_t)(3 - c) : c; }
+            for (uint32_t t = lane; t < (L + 7) >> 3; t += 64) w.pm[strand][t] = rec[(uint32_t)strand * pg.nw8 + t];
             WSYNC();
             lv_cigar(ix.ref, w, lvtab + blockIdx.x, strand, L, pos, (int)q->n_diff);
             if (lane < (uint32_t)w.n_cig) q->cigar[lane] = w.cig[lane];
@@ -1438,12 +1462,12 @@ k_pe_final(IndexView ix, uint32_t n_pairs, const uint8_t *__restrict__ seqs, con
   }
 }
 
-void launch_pe_final(const IndexView &ix, uint32_t n_pairs, const uint8_t *seqs, const uint32_t *offs, salt_result_t *res, const PePair *pairs,
+void launch_pe_final(const IndexView &ix, const PackGeom &pg, uint32_t n_pairs, const uint32_t *pm, salt_result_t *res, const PePair *pairs,
                      const PeSwRes *sw, void *lvtab, uint32_t *head, uint32_t n_blocks, hipStream_t st)
 {
     if (!n_pairs) return;
     const uint32_t blocks = n_blocks < n_pairs ? n_blocks : n_pairs;
-    hipLaunchKernelGGL(k_pe_final, dim3(blocks), dim3(64), 0, st, ix, n_pairs, seqs, offs, res, pairs, sw, static_cast<LvTables *>(lvtab), head);
+    hipLaunchKernelGGL(k_pe_final, dim3(blocks), dim3(64), 0, st, ix, pg, n_pairs, pm, res, pairs, sw, static_cast<LvTables *>(lvtab), head);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1477,13 +1501,11 @@ k_diag_lv(IndexView ix, uint32_t n_cases, const uint32_t *__restrict__ pos, cons
     const uint32_t c = blockIdx.x, lane = lane_id();
     if (c >= n_cases) return;
     const uint32_t off = offs[c], L = offs[c + 1] - off, p = pos[c];
-    for (uint32_t i = lane; i < L; i += 64) w.seq[0][i] = seqs[off + i];
-    WSYNC();
     const uint32_t nw = (L + 7) >> 3;
     for (uint32_t j = lane; j < nw; j += 64) {
         uint32_t word = 0;
         for (uint32_t q = 0; q < 8; ++q) {
-            uint32_t i = j * 8 + q, cc = i < L ? w.seq[0][i] : 5u;
+            uint32_t i = j * 8 + q, cc = i < L ? seqs[off + i] : 5u;
             word |= (cc < 4 ? (1u << cc) : (cc == 4 ? 15u : 0u)) << (4 * q);
         }
         w.pm[0][j] = word;
@@ -1545,21 +1567,21 @@ uint32_t heavy_blocks_per_cu()
     return (uint32_t)cached;
 }
 
-void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
+void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, uint32_t *qctl, unsigned long long *ctr,
                   uint32_t n_blocks, void *lvtab, uint32_t *gq, uint8_t *ge, uint32_t gcap, uint8_t *pe_scr, hipEvent_t *ev2, hipStream_t st)
 {
     if (!ap.n_reads) { if (ev2) { hipEventRecord(ev2[0], st); hipEventRecord(ev2[1], st); } return; }
     uint32_t blocks = n_blocks < ap.n_reads ? n_blocks : ap.n_reads;
     LvTables *tab = static_cast<LvTables *>(lvtab);
-    if (ap.pe) { hipLaunchKernelGGL(k_heavy_pe, dim3(blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, 0u, pe_scr); if (ev2) { hipEventRecord(ev2[0], st); hipEventRecord(ev2[1], st); } return; }
-    hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
+    if (ap.pe) { hipLaunchKernelGGL(k_heavy_pe, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, 0u, pe_scr); if (ev2) { hipEventRecord(ev2[0], st); hipEventRecord(ev2[1], st); } return; }
+    hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
     if (ev2) hipEventRecord(ev2[0], st);
     if (!gcap) { if (ev2) hipEventRecord(ev2[1], st); return; }
     // the deferred gapped passes: distances by (read, strand, 32 candidates), then one finishing wave per read
-    hipLaunchKernelGGL(k_gap, dim3(n_blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
+    hipLaunchKernelGGL(k_gap, dim3(n_blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
     if (ev2) hipEventRecord(ev2[1], st);
-    hipLaunchKernelGGL(k_gapfin, dim3(n_blocks), dim3(64), 0, st, ix, ap, seqs, offs, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
+    hipLaunchKernelGGL(k_gapfin, dim3(n_blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
 }
 
 size_t gap_e_bytes_per_read() { return 2u * MAXLOC; }

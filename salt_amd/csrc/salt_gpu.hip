@@ -332,7 +332,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
         launch_light(ws->ix->view, ap, ws->d_pm, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
                      static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, st);
     if (timed) HIPCHK(hipEventRecord(ev[3], st));
-    launch_heavy(ws->ix->view, ap, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
+    launch_heavy(ws->ix->view, ap, ws->d_pm, ws->d_sai_c, ws->d_sai_r,
                  static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, ws->heavy_blocks, ws->d_lvtab, ws->d_gq, ws->d_ge, ws->gcap, pe ? ws->d_pe_scr : nullptr, timed ? ev + 4 : nullptr, st);
     if (timed) { HIPCHK(hipEventRecord(ev[6], st)); ++ws->n_timed; }
     HIPCHK(hipGetLastError());
@@ -583,7 +583,7 @@ extern "C" int salt_gpu_align_pe(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, con
     HIPCHK(hipMemsetAsync(ws->d_pctl, 0, 32, st));
     launch_pair(n_pairs, pe->min_tlen, pe->max_tlen, (uint32_t)ws->ix->l_pac, ws->d_offs, ws->d_results, ws->d_pairs, ws->d_req, ws->d_pctl, st);
     launch_sw(ws->ix->view, ws->ix->d_pac, ws->d_seqs, ws->d_offs, ws->d_req, ws->d_pctl, ws->d_swres, ws->d_pctl + 1, ws->d_sw_scr, ws->sw_blocks, st);
-    launch_pe_final(ws->ix->view, n_pairs, ws->d_seqs, ws->d_offs, ws->d_results, ws->d_pairs, ws->d_swres, ws->d_lvtab, ws->d_pctl + 2, ws->heavy_blocks, st);
+    launch_pe_final(ws->ix->view, PackGeom::make(max_len), n_pairs, ws->d_pm, ws->d_results, ws->d_pairs, ws->d_swres, ws->d_lvtab, ws->d_pctl + 2, ws->heavy_blocks, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(results, ws->d_results, (uint64_t)n_reads * sizeof(salt_result_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

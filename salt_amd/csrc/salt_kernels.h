@@ -50,7 +50,7 @@ void launch_seed(const IndexView &ix, const SeedParams &sp, const uint32_t *tb, 
                  uint4 *sai_r, unsigned long long *ctr, hipStream_t st);
 void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, unsigned long long *ctr, hipStream_t st);
-void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
+void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, uint32_t *qctl, unsigned long long *ctr,
                   uint32_t n_blocks, void *lvtab, uint32_t *gq, uint8_t *ge, uint32_t gcap, uint8_t *pe_scr, hipEvent_t *ev2, hipStream_t st);
 size_t gap_e_bytes_per_read();
@@ -68,7 +68,7 @@ void launch_pair(uint32_t n_pairs, uint32_t min_tlen, uint32_t max_tlen, uint32_
                  PePair *pairs, PeSwReq *req, uint32_t *pctl, hipStream_t st);
 void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, const uint32_t *offs, const PeSwReq *req, const uint32_t *pctl,
                PeSwRes *res, uint32_t *head, uint8_t *scratch, uint32_t n_blocks, hipStream_t st);
-void launch_pe_final(const IndexView &ix, uint32_t n_pairs, const uint8_t *seqs, const uint32_t *offs, salt_result_t *res, const PePair *pairs,
+void launch_pe_final(const IndexView &ix, const PackGeom &pg, uint32_t n_pairs, const uint32_t *pm, salt_result_t *res, const PePair *pairs,
                      const PeSwRes *sw, void *lvtab, uint32_t *head, uint32_t n_blocks, hipStream_t st);
 
 uint32_t heavy_blocks_per_cu();
