@@ -196,7 +196,7 @@ def main():
             n_heavy = len(heavy_ids)
             # k_heavy, k_gap and k_gapfin share one byte figure: the oracle counts per read, and a read that k_light queues
             # is finished by those three kernels together ("heavy stage")
-            HEAVY = ("k_heavy", "k_gap", "k_gapfin")
+            HEAVY = ("k_heavy", "k_gap", "k_gapfin", "k_cigar")
             SEED = ("k_pack", "k_seed")
             per_launch = {"seed_stage": b_seed * n_reads,
                           "k_light": (algorithmic_bytes(ctr_l, L)[1] if ctr_l else 0.0) * (n_reads - n_heavy),

@@ -268,7 +268,7 @@ class Index:
         return buf.raw[:n]
 
 
-KERNELS = ("k_pack", "k_seed", "k_light", "k_heavy", "k_gap", "k_gapfin")
+KERNELS = ("k_pack", "k_seed", "k_light", "k_heavy", "k_gap", "k_gapfin", "k_cigar")
 
 
 class GpuAligner:

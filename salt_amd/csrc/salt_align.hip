@@ -822,24 +822,51 @@ __device__ __attribute__((noinline)) void lv_cigar(const uint32_t *ref, WaveLds 
 // ---------------------------------------------------------------------------------------------
 // k_align
 // ---------------------------------------------------------------------------------------------
-// Reads whose gapped pass would run Landau-Vishkin over hundreds of candidates are the kernel's tail: one
-// wave would spend milliseconds on them.  k_heavy (MODE 0) therefore only queues such a read; k_gap
-// (MODE 1) computes the candidates' distances with one wave per (read, strand, 32 candidates), and
-// k_gapfin (MODE 2) replays the sequential rule over the stored distances and writes the result.
-struct GapCtx {
-    uint32_t *gq;        // queued read indices
-    uint32_t *gctl;      // [2] = number queued
-    uint8_t  *ge;        // [slot][strand][MAXLOC] distances (255 = more than L/10)
-    uint32_t cap, slot, strand, chunk;
-};
-static constexpr uint32_t GAP_DEFER_MIN = 128;    // candidates (both strands) from which the gapped pass is deferred
+// the text window of one candidate for lv_lanes: tl reference masks from pos, nibble-packed, zero past the end
+__device__ __forceinline__ void lane_text(const uint32_t *__restrict__ ref, uint32_t *T, uint32_t pos, uint32_t tl)
+{
+    const uint32_t w0 = pos >> 3, sh = (pos & 7u) * 4u, nwt = (tl + 7) >> 3;
+    uint32_t lo = ref[w0];
+    for (uint32_t j = 0; j < (uint32_t)LLV_TW; ++j) {
+        uint32_t word = 0;
+        if (j < nwt) {
+            const uint32_t hi = ref[w0 + j + 1];
+            word = __funnelshift_r(lo, hi, sh);
+            const uint32_t rem = tl - j * 8;
+            if (rem < 8) word &= (1u << (4 * rem)) - 1u;
+            lo = hi;
+        }
+        T[j] = word;
+    }
+}
 
-template <int MODE, bool PE>
+// A read without a gap-free hit needs Landau-Vishkin over all its candidates plus LV tracebacks for its CIGARs:
+// hundreds of microseconds on one wave, i.e. the tail of a persistent kernel.  k_heavy therefore only stores such a
+// read's candidate lists; k_gap computes the distances with one wave per (read, strand, 32 candidates), k_gapfin
+// replays the reference's sequential rule over the stored distances and writes the result, and k_cigar runs one
+// traceback per wave.  (GapBufs is declared in salt_kernels.h; a read that finds no free slot is finished inline.)
+__device__ __forceinline__ uint32_t store_gap_list(const uint32_t *loci, uint32_t n, uint32_t L, uint32_t ref_len, uint32_t *__restrict__ dst)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t n_out = 0;
+    for (uint32_t b = 0; b < n; b += 64) {                    // the gap-free list minus alnse_check_withgap's range filter (alnse.c:894)
+        const uint32_t i = b + lane;
+        const uint32_t pos = i < n ? loci[i] : 0u;
+        const bool keep = i < n && !(pos + L + 4 >= ref_len);
+        const uint64_t m = __ballot(keep);
+        if (keep) dst[n_out + (uint32_t)__popcll(m & lt)] = pos;
+        n_out += (uint32_t)__popcll(m);
+    }
+    return n_out;
+}
+
+template <bool PE>
 __device__ __forceinline__ void align_general(const IndexView ix, const AlignParams ap, WaveLds &w, const uint32_t r,
                               const uint32_t *__restrict__ pm,
                               const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r,
                               salt_result_t *__restrict__ results, unsigned long long *__restrict__ ctr,
-                              unsigned long long *phase, LvTables *lvtab, const GapCtx g, uint32_t *pe_loci, uint8_t *pe_cand)
+                              unsigned long long *phase, LvTables *lvtab, const GapBufs g, uint32_t *pe_loci, uint8_t *pe_cand)
 {
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -882,8 +909,9 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     bool found[2] = { false, false };
     uint32_t n_hits_s[2] = { 0, 0 };            // hits recorded (<= NHIT) per strand
     uint32_t a0[2] = { 0, 0 };                  // n_diff of the first hit of each list
-    uint32_t n_cand_nogap = 0;
-    if (MODE == 0 && !too_short)
+    uint32_t n_cand_nogap = 0, n_cand_s[2] = { 0, 0 };
+    CandStats cs_s[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+    if (!too_short)
     for (int strand = 0; strand < 2; ++strand) {
         pc.stamp(SALT_CTR_T_SCAN);
         const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, loci, loci_cap, ap.pe }, w);
@@ -933,7 +961,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             }
             (void)m3;
         }
-        c_verify += n_cand; n_cand_nogap += n_cand;
+        c_verify += n_cand; n_cand_nogap += n_cand; n_cand_s[strand] = n_cand; cs_s[strand] = cs;
         for (uint32_t b = lane; b < n_cand; b += 64) c_vwords += ((loci[b] & 7u) + L + 7) >> 3;
         if (found[strand]) { q_pos = call_best_pos; q_ndiff = call_best_n; q_gap = 0; q_strand = (uint32_t)strand; }
         WSYNC();
@@ -945,14 +973,39 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         int maxd = PE ? 3 : (int)(L / 10);                    // alnse.c:1090 (SE) / alnse.c:1016-1028 (PE keeps 3)
         const int gap_k0 = maxd;
         const bool lanes_fit = gap_k0 <= LLV_K && L + 4 <= 8u * (LLV_TW - 1);
-        if (MODE == 0 && !PE && lanes_fit && g.cap && n_cand_nogap >= GAP_DEFER_MIN) {
+        if (!PE && lanes_fit && g.cap && n_cand_nogap > 0) {
             uint32_t slot = 0;
             if (lane == 0) slot = atomicAdd(&g.gctl[2], 1u);
             slot = (uint32_t)__shfl((int)slot, 0);
-            if (slot < g.cap) { if (lane == 0) g.gq[slot] = r; return; }      // k_gap / k_gapfin take it from here
+            if (slot < g.cap) {                                           // k_gap / k_gapfin / k_cigar take it from here
+                // strand 1's gap-free list is still in LDS; strand 0's is located again
+                uint32_t ns[2];
+                ns[1] = store_gap_list(loci, n_cand_s[1], L, ix.ref_len, g.gloci + ((size_t)slot * 2 + 1) * MAXLOC);
+                c_sa_c += cs_s[1].n_sa_c; c_sa_r += cs_s[1].n_sa_r; c_loci += cs_s[1].n_loci;
+                WSYNC();
+                const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, 0, true, phase, loci, loci_cap, ap.pe }, w);
+                c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
+                uint32_t *dst0 = g.gloci + (size_t)slot * 2 * MAXLOC;
+                for (uint32_t i = lane; i < cs.n_cand; i += 64) dst0[i] = loci[i];
+                ns[0] = cs.n_cand;
+                const uint32_t ch0 = (ns[0] + LLV_N - 1) / LLV_N, ch1 = (ns[1] + LLV_N - 1) / LLV_N;
+                uint32_t base = 0;
+                if (lane == 0) { base = atomicAdd(&g.gctl[5], ch0 + ch1); g.gq[slot] = r; g.gn[2 * slot] = ns[0]; g.gn[2 * slot + 1] = ns[1]; }
+                base = (uint32_t)__shfl((int)base, 0);
+                for (uint32_t c = lane; c < ch0 + ch1; c += 64) g.gitems[base + c] = (slot << 8) | (c >= ch0 ? (0x80u | (c - ch0)) : c);
+                if (ctr) {
+                    for (int o = 32; o > 0; o >>= 1) c_vwords += __shfl_down(c_vwords, o);
+                    if (lane == 0) {
+                        atomicAdd(ctr + SALT_CTR_SA_C, c_sa_c); atomicAdd(ctr + SALT_CTR_SA_R, c_sa_r);
+                        atomicAdd(ctr + SALT_CTR_VERIFY, c_verify); atomicAdd(ctr + SALT_CTR_VERIFY_WORDS, c_vwords);
+                        atomicAdd(ctr + SALT_CTR_LV, ns[0] + ns[1]); atomicAdd(ctr + SALT_CTR_READS, 1ull);
+                        atomicAdd(ctr + SALT_CTR_BASES, L); atomicAdd(ctr + SALT_CTR_LOCI, c_loci);
+                    }
+                }
+                return;
+            }
         }
         for (int strand = 0; strand < 2; ++strand) {
-            if (MODE == 1 && strand != (int)g.strand) continue;
             pc.stamp(SALT_CTR_T_GAP);
             const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, loci, loci_cap, ap.pe }, w);
             pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
@@ -961,41 +1014,22 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             // all candidates' distances at the call's initial bound, 64 at a time (one per lane); the
             // sequential rule below then only compares numbers
             const bool lanes_ok = lanes_fit;
-            uint8_t *ge = (MODE != 0) ? g.ge + ((size_t)g.slot * 2 + (uint32_t)strand) * MAXLOC : nullptr;
-            if (MODE == 2) {                                          // distances were computed by k_gap
-                for (uint32_t i = lane; i < n_cand; i += 64) cand_e[i] = ge[i];
-                WSYNC();
-            } else if (lanes_ok) {
+            if (lanes_ok) {
                 const int k0 = gap_k0;
-                for (uint32_t b = (MODE == 1 ? g.chunk * LLV_N : 0u); b < (MODE == 1 ? (g.chunk + 1) * LLV_N : n_cand) && b < n_cand; b += LLV_N) {
+                for (uint32_t b = 0; b < n_cand; b += LLV_N) {
                     WSYNC();
                     const uint32_t i = b + lane;
                     bool act = false;
                     if (lane < LLV_N && i < n_cand) {
                         const uint32_t pos = loci[i];
                         act = !(pos > ix.ref_len || pos + L + 4 > ix.ref_len);           // ed_diff guard (editdistance.c:178)
-                        if (act) {
-                            const uint32_t tl = L + 4, w0 = pos >> 3, sh = (pos & 7u) * 4u, nwt = (tl + 7) >> 3;
-                            uint32_t lo = ix.ref[w0];
-                            for (uint32_t j = 0; j < LLV_TW; ++j) {
-                                uint32_t word = 0;
-                                if (j < nwt) {
-                                    const uint32_t hi = ix.ref[w0 + j + 1];
-                                    word = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
-                                    const uint32_t rem = tl - j * 8;
-                                    if (rem < 8) word &= (1u << (4 * rem)) - 1u;
-                                    lo = hi;
-                                }
-                                w.u.llv.T[lane * LLV_TW + j] = word;
-                            }
-                        }
+                        if (act) lane_text(ix.ref, w.u.llv.T + lane * LLV_TW, pos, L + 4);
                     }
                     const uint32_t e = lv_lanes(w.u.llv, w.pm[strand], (int)L, (int)L + 4, k0, act);
-                    if (lane < LLV_N && i < n_cand) { if (MODE == 1) ge[i] = (uint8_t)e; else cand_e[i] = (uint8_t)e; }
+                    if (lane < LLV_N && i < n_cand) cand_e[i] = (uint8_t)e;
                 }
                 WSYNC();
             }
-            if (MODE == 1) return;                                    // this item's 32 distances are stored
             for (uint32_t i = 0; i < n_cand; ++i) {
                 uint32_t pos = loci[i];
                 int e = -1;
@@ -1083,7 +1117,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     if (phase) {
         const unsigned long long dt = (unsigned long long)(__builtin_amdgcn_s_memrealtime() - rt0);
         pc.add(SALT_CTR_X3, dt);
-        if (ctr && lane == 0 && MODE != 1) atomicMax(ctr + (MODE == 0 ? SALT_CTR_MAX_HEAVY : SALT_CTR_MAX_GAPFIN), (dt << 32) | r);
+        if (ctr && lane == 0) atomicMax(ctr + SALT_CTR_MAX_HEAVY, (dt << 32) | r);
     }
     if (ctr) {
         for (int o = 32; o > 0; o >>= 1) c_vwords += __shfl_down(c_vwords, o);
@@ -1097,17 +1131,17 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_heavy / k_gap / k_gapfin: persistent waves pull work items from counters in qctl[]
-//   qctl[0] reads queued by k_light      qctl[1] k_heavy head
-//   qctl[2] reads queued for k_gap       qctl[3] k_gap head      qctl[4] k_gapfin head
+// Persistent kernels: one-wave blocks pull work items through counters in qctl[] until the head passes the count
+//   qctl[0] reads queued by k_light    qctl[1] k_heavy head
+//   qctl[2] gapped reads (slots)       qctl[3] k_gap head        qctl[4] k_gapfin head
+//   qctl[5] k_gap items                qctl[6] CIGAR items       qctl[7] k_cigar head
 // ---------------------------------------------------------------------------------------------
-template <int MODE, bool PE>
-__device__ __forceinline__ void persistent_body(const IndexView &ix, const AlignParams &ap, const uint32_t *__restrict__ pm,
-                                                const uint4 *__restrict__ sai_c,
-                                                const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
-                                                const uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl,
-                                                unsigned long long *__restrict__ ctr, LvTables *__restrict__ lvtab,
-                                                uint32_t *__restrict__ gq, uint8_t *__restrict__ ge, uint32_t gcap, uint8_t *__restrict__ pe_scr)
+template <bool PE>
+__device__ __forceinline__ void heavy_body(const IndexView &ix, const AlignParams &ap, const uint32_t *__restrict__ pm,
+                                           const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r,
+                                           salt_result_t *__restrict__ results, const uint32_t *__restrict__ queue,
+                                           unsigned long long *__restrict__ ctr, LvTables *__restrict__ lvtab, const GapBufs g,
+                                           uint8_t *__restrict__ pe_scr)
 {
     __shared__ WaveLds w;
     __shared__ uint32_t s_item;
@@ -1115,25 +1149,18 @@ __device__ __forceinline__ void persistent_body(const IndexView &ix, const Align
     unsigned long long *phase = ctr ? s_phase : nullptr;
     if (ctr) { for (int i = threadIdx.x; i < SALT_CTR_N; i += 64) s_phase[i] = 0; }
     WSYNC();
-    uint32_t n_items;
-    if (MODE == 0) n_items = ap.all_heavy ? ap.n_reads : qctl[0];
-    else { uint32_t ng = qctl[2] < gcap ? qctl[2] : gcap; n_items = MODE == 1 ? ng * 2u * (MAXLOC / LLV_N) : ng; }
-    uint32_t *head = qctl + (MODE == 0 ? 1 : MODE == 1 ? 3 : 4);
-    for (;;) {                                                           // every wave leaves once the head passes n_items
-        if (threadIdx.x == 0) s_item = atomicAdd(head, 1u);
+    const uint32_t n_items = ap.all_heavy ? ap.n_reads : g.gctl[0];
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&g.gctl[1], 1u);
         WSYNC();
         const uint32_t it = s_item;
         WSYNC();
         if (it >= n_items) break;
-        GapCtx g{ gq, qctl, ge, gcap, 0, 0, 0 };
-        uint32_t r;
-        if (MODE == 0) r = ap.all_heavy ? it : queue[it];
-        else if (MODE == 1) { const uint32_t per = 2u * (MAXLOC / LLV_N); g.slot = it / per; g.strand = (it % per) / (MAXLOC / LLV_N); g.chunk = it % (MAXLOC / LLV_N); r = gq[g.slot]; }
-        else { g.slot = it; r = gq[it]; }
-        align_general<MODE, PE>(ix, ap, w, r, pm, sai_c, sai_r, results, MODE == 1 ? nullptr : ctr, MODE == 1 ? nullptr : phase, lvtab + blockIdx.x, g,
-                            pe_scr ? reinterpret_cast<uint32_t *>(pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5) : nullptr,
-                            pe_scr ? pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5 + (size_t)PE_LOCI_CAP * 4 : nullptr);
-        if (MODE == 0 && phase && threadIdx.x == 0) s_phase[SALT_CTR_HEAVY_READS] += 1;
+        const uint32_t r = ap.all_heavy ? it : queue[it];
+        align_general<PE>(ix, ap, w, r, pm, sai_c, sai_r, results, ctr, phase, lvtab + blockIdx.x, g,
+                          pe_scr ? reinterpret_cast<uint32_t *>(pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5) : nullptr,
+                          pe_scr ? pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5 + (size_t)PE_LOCI_CAP * 4 : nullptr);
+        if (phase && threadIdx.x == 0) s_phase[SALT_CTR_HEAVY_READS] += 1;
         WSYNC();
     }
     if (phase) {                                                         // one flush per wave
@@ -1142,18 +1169,197 @@ __device__ __forceinline__ void persistent_body(const IndexView &ix, const Align
     }
 }
 
-#define PERSISTENT_KERNEL(NAME, MODE, PE)                                                                                 \
+#define HEAVY_KERNEL(NAME, PE)                                                                                          \
 __global__ void __launch_bounds__(64)                                                                                   \
 NAME(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,                                                     \
      const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,             \
-     const uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl, unsigned long long *__restrict__ ctr,             \
-     LvTables *__restrict__ lvtab, uint32_t *__restrict__ gq, uint8_t *__restrict__ ge, uint32_t gcap,                  \
-     uint8_t *__restrict__ pe_scr)                                                                                      \
-{ persistent_body<MODE, PE>(ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr, lvtab, gq, ge, gcap, pe_scr); }
-PERSISTENT_KERNEL(k_heavy, 0, false)
-PERSISTENT_KERNEL(k_gap, 1, false)
-PERSISTENT_KERNEL(k_gapfin, 2, false)
-PERSISTENT_KERNEL(k_heavy_pe, 0, true)          // paired-end mates: PE locate rule, loci in global scratch, gap bound 3, no deferral
+     const uint32_t *__restrict__ queue, unsigned long long *__restrict__ ctr,                                          \
+     LvTables *__restrict__ lvtab, GapBufs g, uint8_t *__restrict__ pe_scr)                                             \
+{ heavy_body<PE>(ix, ap, pm, sai_c, sai_r, results, queue, ctr, lvtab, g, pe_scr); }
+HEAVY_KERNEL(k_heavy, false)
+HEAVY_KERNEL(k_heavy_pe, true)                  // paired-end mates: PE locate rule, loci in global scratch, gap bound 3, no deferral
+
+// k_gap: one item = 32 candidates of one strand of one queued read: their Landau-Vishkin distances at the bound L/10
+// (ed_diff -> computeEditDistance, editdistance.c:174-232, LandauVishkin.c:19-122), one candidate per lane
+struct GapLds { LaneLv llv; uint32_t pm[MAXL / 8]; };
+__global__ void __launch_bounds__(64)
+k_gap(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, GapBufs g)
+{
+    __shared__ GapLds s;
+    __shared__ uint32_t s_item;
+    const uint32_t lane = lane_id();
+    const uint32_t cap_items = g.cap * 2u * (MAXLOC / LLV_N);
+    const uint32_t n_items = g.gctl[5] < cap_items ? g.gctl[5] : cap_items;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&g.gctl[3], 1u);
+        WSYNC();
+        const uint32_t it = s_item;
+        WSYNC();
+        if (it >= n_items) break;
+        const uint32_t item = g.gitems[it], slot = item >> 8, strand = (item >> 7) & 1u, chunk = item & 127u;
+        const uint32_t r = g.gq[slot];
+        const uint32_t *rec = pm + (uint64_t)r * ap.pg.pm_stride;
+        const uint32_t L = rec[2 * ap.pg.nw8], nw = (L + 7) >> 3;
+        for (uint32_t t = lane; t < nw; t += 64) s.pm[t] = rec[strand * ap.pg.nw8 + t];
+        const uint32_t n = g.gn[2 * slot + strand], i = chunk * LLV_N + lane;
+        const size_t row = ((size_t)slot * 2 + strand) * MAXLOC;
+        bool act = false;
+        if (lane < LLV_N && i < n) {
+            const uint32_t pos = g.gloci[row + i];
+            act = !(pos > ix.ref_len || pos + L + 4 > ix.ref_len);               // ed_diff guard (editdistance.c:178)
+            if (act) lane_text(ix.ref, s.llv.T + lane * LLV_TW, pos, L + 4);
+        }
+        WSYNC();
+        const uint32_t e = lv_lanes(s.llv, s.pm, (int)L, (int)L + 4, (int)(L / 10), act);
+        if (lane < LLV_N && i < n) g.ge[row + i] = (uint8_t)e;
+        WSYNC();
+    }
+}
+
+// k_gapfin: one queued read per wave: alnse_check_withgap's sequential rule (alnse.c:871-901, code_kdiff 371-393)
+// replayed by ballots over the stored distances, strand 0 then 1 with the bound carried over; then
+// query_set_hits / gen_mapq (query.c:270-333) and the result row; every LV traceback becomes a k_cigar item.
+struct FinLds { uint32_t hit_pos[2][NHIT]; uint8_t hit_nd[2][NHIT]; };
+__global__ void __launch_bounds__(64)
+k_gapfin(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, salt_result_t *__restrict__ results, GapBufs g,
+         unsigned long long *__restrict__ ctr)
+{
+    __shared__ FinLds w;
+    __shared__ uint32_t s_item;
+    const uint32_t lane = lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t n_items = g.gctl[2] < g.cap ? g.gctl[2] : g.cap;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&g.gctl[4], 1u);
+        WSYNC();
+        const uint32_t slot = s_item;
+        WSYNC();
+        if (slot >= n_items) break;
+        const uint64_t rt0 = ctr ? __builtin_amdgcn_s_memrealtime() : 0;
+        const uint32_t r = g.gq[slot];
+        const uint32_t L = pm[(uint64_t)r * ap.pg.pm_stride + 2 * ap.pg.nw8];
+        salt_result_t *out = results + r;
+        uint32_t q_pos = 0xFFFFFFFFu, q_strand = 3, q_ndiff = 255, q_gap = 255;
+        uint32_t bound = L / 10;                                          // alnse.c:1090
+        uint32_t n_hits_s[2] = { 0, 0 }, a0[2] = { 0, 0 };
+        for (int strand = 0; strand < 2; ++strand) {
+            const uint32_t n = g.gn[2 * slot + strand];
+            const size_t row = ((size_t)slot * 2 + (uint32_t)strand) * MAXLOC;
+            uint32_t call_best_n = INF, call_best_pos = 0;
+            bool any = false;
+            for (uint32_t b = 0; b < n; b += 64) {
+                const uint32_t i = b + lane;
+                uint32_t v = INF, pos = 0;
+                if (i < n) { pos = g.gloci[row + i]; v = g.ge[row + i]; if (v > (uint32_t)LLV_K) v = INF; }
+                // m[t] = lanes with v <= t; a candidate passes iff v <= bound and no earlier candidate is smaller
+                uint64_t smaller = 0, m_prev = 0;
+                uint64_t pmask_by_t[LLV_K + 1];
+#pragma unroll
+                for (int t = 0; t <= LLV_K; ++t) {
+                    const uint64_t m = __ballot(v <= (uint32_t)t);
+                    if (v == (uint32_t)t) smaller = m_prev;
+                    m_prev = m; pmask_by_t[t] = m;
+                }
+                const bool pass = v <= bound && (smaller & lt) == 0;
+                const uint64_t pmk = __ballot(pass);
+                if (pmk) {
+                    uint32_t vmin = 0;
+#pragma unroll
+                    for (int t = LLV_K; t >= 0; --t) if (pmask_by_t[t] & pmk) vmin = (uint32_t)t;
+                    const uint32_t rank = n_hits_s[strand] + (uint32_t)__popcll(pmk & lt);
+                    if (pass && rank < NHIT) { w.hit_pos[strand][rank] = pos; w.hit_nd[strand][rank] = (uint8_t)v; }
+                    if (n_hits_s[strand] == 0) a0[strand] = (uint32_t)__shfl((int)v, __ffsll((long long)pmk) - 1);
+                    const uint32_t add = (uint32_t)__popcll(pmk);
+                    n_hits_s[strand] = n_hits_s[strand] + add > NHIT ? NHIT : n_hits_s[strand] + add;
+                    if (vmin < call_best_n) {
+                        const uint64_t at = __ballot(pass && v == vmin);
+                        call_best_n = vmin;
+                        call_best_pos = (uint32_t)__shfl((int)pos, __ffsll((long long)at) - 1);
+                    }
+                    any = true;
+                    bound = vmin < bound ? vmin : bound;
+                }
+            }
+            if (any) { q_pos = call_best_pos; q_ndiff = call_best_n; q_gap = 1; q_strand = (uint32_t)strand; }
+        }
+        WSYNC();
+        int b0 = (int)q_ndiff, b1 = 100000, tot = 0;
+        uint32_t nh[2] = { 0, 0 };
+        uint32_t sel_idx[2][SALT_MAX_HITS];
+        for (int s = 0; s < 2 && tot < ap.max_hits; ++s)
+            for (uint32_t j = 0; j < n_hits_s[s]; ++j) {
+                const uint32_t p = w.hit_pos[s][j];
+                if (p == 0xFFFFFFFFu || p == q_pos) continue;
+                if (a0[s] <= q_ndiff) {
+                    if ((int)a0[s] <= b1) b1 = (int)a0[s];
+                    if (nh[s] < SALT_MAX_HITS) sel_idx[s][nh[s]] = j;
+                    ++nh[s]; ++tot;
+                }
+                if (tot == ap.max_hits) break;
+            }
+        uint32_t mapq = 0;
+        if (b0 != 0) {
+            const uint32_t x = (uint32_t)(b0 > b1 ? b0 - b1 : b1 - b0);
+            const uint64_t q = (uint64_t)255 * x / (uint32_t)b0;
+            mapq = q < 254 ? (uint32_t)q : 254u;
+        }
+        const uint32_t n_cig_items = q_pos != 0xFFFFFFFFu ? 1u + nh[0] + nh[1] : 0u;
+        if (lane == 0) {
+            out->pos = q_pos; out->strand = (uint8_t)q_strand; out->n_diff = (uint8_t)q_ndiff; out->is_gap = (uint8_t)q_gap;
+            out->mapq = (uint8_t)mapq; out->b0 = b0; out->b1 = b1; out->seq_start = 0; out->seq_end = (uint16_t)(L - 1);
+            out->n_hits[0] = (uint8_t)nh[0]; out->n_hits[1] = (uint8_t)nh[1]; out->skipped = 0; out->n_cigar = 0;
+            for (int s = 0; s < 2; ++s)
+                for (uint32_t j = 0; j < nh[s]; ++j) {
+                    const uint32_t h = sel_idx[s][j];
+                    out->hits[s][j].pos = w.hit_pos[s][h]; out->hits[s][j].n_diff = w.hit_nd[s][h];
+                    out->hits[s][j].is_gap = 1; out->hits[s][j].strand = (uint16_t)s;
+                }
+            if (n_cig_items) {                                            // main hit (which = 0) and every alternative hit (1 + index)
+                const uint32_t base = atomicAdd(&g.gctl[6], n_cig_items);
+                for (uint32_t c = 0; c < n_cig_items; ++c) g.cq[base + c] = (slot << 3) | c;
+            }
+            if (ctr) atomicMax(ctr + SALT_CTR_MAX_GAPFIN, ((unsigned long long)(__builtin_amdgcn_s_memrealtime() - rt0) << 32) | r);
+        }
+        WSYNC();
+    }
+}
+
+// k_cigar: one LV traceback per wave (query_gen_cigar query.c:282-296; XA CIGARs sam.c:216-225)
+__global__ void __launch_bounds__(64)
+k_cigar(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, salt_result_t *__restrict__ results, GapBufs g,
+        LvTables *__restrict__ lvtab)
+{
+    __shared__ WaveLds w;
+    __shared__ uint32_t s_item;
+    const uint32_t lane = lane_id();
+    const uint32_t cap_items = g.cap * (1u + SALT_MAX_HITS);
+    const uint32_t n_items = g.gctl[6] < cap_items ? g.gctl[6] : cap_items;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&g.gctl[7], 1u);
+        WSYNC();
+        const uint32_t it = s_item;
+        WSYNC();
+        if (it >= n_items) break;
+        const uint32_t item = g.cq[it], which = item & 7u, r = g.gq[item >> 3];
+        salt_result_t *out = results + r;
+        const uint32_t *rec = pm + (uint64_t)r * ap.pg.pm_stride;
+        const uint32_t L = rec[2 * ap.pg.nw8];
+        uint32_t strand, pos, k;
+        if (which == 0) { strand = out->strand; pos = out->pos; k = out->n_diff; }
+        else {
+            const uint32_t h = which - 1, n0 = out->n_hits[0];
+            strand = h >= n0; const uint32_t j = strand ? h - n0 : h;
+            pos = out->hits[strand][j].pos; k = out->hits[strand][j].n_diff;
+        }
+        for (uint32_t t = lane; t < (L + 7) >> 3; t += 64) w.pm[strand][t] = rec[strand * ap.pg.nw8 + t];
+        WSYNC();
+        lv_cigar(ix.ref, w, lvtab + blockIdx.x, (int)strand, L, pos, (int)k);
+        uint16_t *dst = which == 0 ? out->cigar : out->hit_cigar[which - 1];
+        if (lane < (uint32_t)w.n_cig) dst[lane] = w.cig[lane];
+        if (lane == 0) { if (which == 0) out->n_cigar = (uint8_t)w.n_cig; else out->hit_n_cigar[which - 1] = (uint8_t)w.n_cig; }
+        WSYNC();
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_light: one wave per read, the common case in three memory round trips.
@@ -1568,22 +1774,43 @@ uint32_t heavy_blocks_per_cu()
 }
 
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint4 *sai_c,
-                  const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, uint32_t *qctl, unsigned long long *ctr,
-                  uint32_t n_blocks, void *lvtab, uint32_t *gq, uint8_t *ge, uint32_t gcap, uint8_t *pe_scr, hipEvent_t *ev2, hipStream_t st)
+                  const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, unsigned long long *ctr,
+                  uint32_t n_blocks, void *lvtab, const GapBufs &g, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st)
 {
-    if (!ap.n_reads) { if (ev2) { hipEventRecord(ev2[0], st); hipEventRecord(ev2[1], st); } return; }
+    if (!ap.n_reads) { if (ev3) for (int i = 0; i < 3; ++i) hipEventRecord(ev3[i], st); return; }
     uint32_t blocks = n_blocks < ap.n_reads ? n_blocks : ap.n_reads;
     LvTables *tab = static_cast<LvTables *>(lvtab);
-    if (ap.pe) { hipLaunchKernelGGL(k_heavy_pe, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, 0u, pe_scr); if (ev2) { hipEventRecord(ev2[0], st); hipEventRecord(ev2[1], st); } return; }
-    hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
-    if (ev2) hipEventRecord(ev2[0], st);
-    if (!gcap) { if (ev2) hipEventRecord(ev2[1], st); return; }
-    // the deferred gapped passes: distances by (read, strand, 32 candidates), then one finishing wave per read
-    hipLaunchKernelGGL(k_gap, dim3(n_blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
-    if (ev2) hipEventRecord(ev2[1], st);
-    hipLaunchKernelGGL(k_gapfin, dim3(n_blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr, tab, gq, ge, gcap, pe_scr);
+    if (ap.pe) {
+        GapBufs none = g; none.cap = 0;
+        hipLaunchKernelGGL(k_heavy_pe, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, none, pe_scr);
+        if (ev3) for (int i = 0; i < 3; ++i) hipEventRecord(ev3[i], st);
+        return;
+    }
+    hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr);
+    if (ev3) hipEventRecord(ev3[0], st);
+    if (!g.cap) { if (ev3) { hipEventRecord(ev3[1], st); hipEventRecord(ev3[2], st); } return; }
+    // the deferred gapped passes: distances by (read, strand, 32 candidates), one finishing wave per read, one traceback per wave
+    hipLaunchKernelGGL(k_gap, dim3(n_blocks), dim3(64), 0, st, ix, ap, pm, g);
+    if (ev3) hipEventRecord(ev3[1], st);
+    hipLaunchKernelGGL(k_gapfin, dim3(n_blocks), dim3(64), 0, st, ix, ap, pm, results, g, ctr);
+    if (ev3) hipEventRecord(ev3[2], st);
+    hipLaunchKernelGGL(k_cigar, dim3(n_blocks), dim3(64), 0, st, ix, ap, pm, results, g, tab);
 }
 
-size_t gap_e_bytes_per_read() { return 2u * MAXLOC; }
+GapBufs gap_bufs_layout(uint8_t *base, uint32_t cap, uint32_t *gctl, size_t *bytes)
+{
+    GapBufs g; size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off = (off + n + 255) & ~(size_t)255; return base ? base + o : nullptr; };
+    g.gq = reinterpret_cast<uint32_t *>(take((size_t)cap * 4));
+    g.gn = reinterpret_cast<uint32_t *>(take((size_t)cap * 2 * 4));
+    g.gloci = reinterpret_cast<uint32_t *>(take((size_t)cap * 2 * MAXLOC * 4));
+    g.ge = take((size_t)cap * 2 * MAXLOC);
+    g.gitems = reinterpret_cast<uint32_t *>(take((size_t)cap * 2 * (MAXLOC / LLV_N) * 4));
+    g.cq = reinterpret_cast<uint32_t *>(take((size_t)cap * (1 + SALT_MAX_HITS) * 4));
+    g.gctl = gctl; g.cap = cap;
+    if (bytes) *bytes = off;
+    return g;
+}
+
 
 } // namespace salt

@@ -37,7 +37,7 @@ struct salt_gpu_ws {
     unsigned long long *d_ctr = nullptr;
     uint32_t *d_queue = nullptr, *d_qctl = nullptr;   // reads k_light hands to k_heavy; {count, head}
     void *d_lvtab = nullptr;                          // one LV traceback table per persistent k_heavy block
-    uint32_t *d_gq = nullptr; uint8_t *d_ge = nullptr; uint32_t gcap = 0;   // deferred gapped passes
+    uint8_t *d_gap = nullptr; uint32_t gcap = 0; GapBufs gap{};             // deferred gapped passes
     // paired end (allocated on first use)
     uint8_t *d_pe_scr = nullptr;                       // per persistent block: PE_LOCI_CAP loci + distances
     PePair *d_pairs = nullptr; PeSwReq *d_req = nullptr; PeSwRes *d_swres = nullptr; uint32_t *d_pctl = nullptr;
@@ -46,7 +46,7 @@ struct salt_gpu_ws {
     int all_heavy = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
-    std::vector<hipEvent_t> ev;        // 7 per call: before k_pack, k_seed, k_light, k_heavy, k_gap, k_gapfin, after
+    std::vector<hipEvent_t> ev;        // 8 per call: before k_pack, k_seed, k_light, k_heavy, k_gap, k_gapfin, k_cigar, after
     uint32_t n_timed = 0;
 };
 static const uint32_t MAX_TIMED = 256;
@@ -231,8 +231,9 @@ extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint
     ws->gcap = max_reads < 8192 ? max_reads : 8192;
     if (const char *e3 = getenv("SALT_GPU_NO_GAP_DEFER")) if (atoi(e3)) ws->gcap = 0;
     if (ws->gcap) {
-        CHKW(hipMalloc((void **)&ws->d_gq, (uint64_t)ws->gcap * 4));
-        CHKW(hipMalloc((void **)&ws->d_ge, (uint64_t)ws->gcap * gap_e_bytes_per_read()));
+        size_t gbytes = 0;
+        gap_bufs_layout(nullptr, ws->gcap, nullptr, &gbytes);
+        CHKW(hipMalloc((void **)&ws->d_gap, gbytes));
     }
     {
         hipDeviceProp_t prop;
@@ -256,7 +257,7 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
 {
     if (!ws) return;
     hipSetDevice(ws->ix->device);
-    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gq); hipFree(ws->d_ge);
+    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gap);
     hipFree(ws->d_pe_scr); hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres); hipFree(ws->d_pctl); hipFree(ws->d_sw_scr);
     if (ws->stream) hipStreamDestroy(ws->stream);
     for (auto &e : ws->ev) if (e) hipEventDestroy(e);
@@ -321,7 +322,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     if (pe && !ws->d_pe_scr) HIPCHK(hipMalloc((void **)&ws->d_pe_scr, (uint64_t)ws->heavy_blocks * PE_LOCI_CAP * 5));
     unsigned long long *ctr = o->collect_counters ? ws->d_ctr : nullptr;
     const bool timed = ws->timing && ws->n_timed < MAX_TIMED;
-    hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * 7] : nullptr;
+    hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * 8] : nullptr;
     HIPCHK(hipMemsetAsync(ws->d_qctl, 0, 32, st));
     if (timed) HIPCHK(hipEventRecord(ev[0], st));
     launch_pack(pg, n_reads, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_pm, ws->d_tb, st);
@@ -333,8 +334,9 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
                      static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, st);
     if (timed) HIPCHK(hipEventRecord(ev[3], st));
     launch_heavy(ws->ix->view, ap, ws->d_pm, ws->d_sai_c, ws->d_sai_r,
-                 static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, ws->heavy_blocks, ws->d_lvtab, ws->d_gq, ws->d_ge, ws->gcap, pe ? ws->d_pe_scr : nullptr, timed ? ev + 4 : nullptr, st);
-    if (timed) { HIPCHK(hipEventRecord(ev[6], st)); ++ws->n_timed; }
+                 static_cast<salt_result_t *>(d_results), ws->d_queue, ctr, ws->heavy_blocks, ws->d_lvtab,
+                 gap_bufs_layout(ws->d_gap, ws->gcap, ws->d_qctl, nullptr), pe ? ws->d_pe_scr : nullptr, timed ? ev + 4 : nullptr, st);
+    if (timed) { HIPCHK(hipEventRecord(ev[7], st)); ++ws->n_timed; }
     HIPCHK(hipGetLastError());
     return SALT_OK;
 }
@@ -407,7 +409,7 @@ extern "C" int salt_gpu_ws_timing(salt_gpu_ws_t *ws, int enable)
     if (!ws) return fail(SALT_E_INVAL, "null argument");
     HIPCHK(hipSetDevice(ws->ix->device));
     if (enable && ws->ev.empty()) {
-        ws->ev.resize((size_t)MAX_TIMED * 7);
+        ws->ev.resize((size_t)MAX_TIMED * 8);
         for (auto &e : ws->ev) HIPCHK(hipEventCreate(&e));
     }
     ws->timing = enable != 0; ws->n_timed = 0;
@@ -421,8 +423,8 @@ extern "C" int salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[SALT_N_KERNELS
     for (int k = 0; k < SALT_N_KERNELS; ++k) ms[k] = 0;
     *n_calls = ws->n_timed;
     for (uint32_t i = 0; i < ws->n_timed; ++i) {
-        hipEvent_t *ev = &ws->ev[(size_t)i * 7];
-        HIPCHK(hipEventSynchronize(ev[6]));
+        hipEvent_t *ev = &ws->ev[(size_t)i * 8];
+        HIPCHK(hipEventSynchronize(ev[7]));
         for (int k = 0; k < SALT_N_KERNELS; ++k) {
             float a = 0;
             HIPCHK(hipEventElapsedTime(&a, ev[k], ev[k + 1]));

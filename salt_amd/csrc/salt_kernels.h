@@ -50,10 +50,21 @@ void launch_seed(const IndexView &ix, const SeedParams &sp, const uint32_t *tb, 
                  uint4 *sai_r, unsigned long long *ctr, hipStream_t st);
 void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, unsigned long long *ctr, hipStream_t st);
+// Deferred gapped passes (k_heavy -> k_gap -> k_gapfin -> k_cigar), `cap` slots; gctl = the workspace's qctl[8]
+struct GapBufs {
+    uint32_t *gq;        // [cap] read index of the slot
+    uint32_t *gn;        // [cap][2] candidates per strand
+    uint32_t *gloci;     // [cap][2][1024] candidate lists of the gapped pass
+    uint8_t  *ge;        // [cap][2][1024] Landau-Vishkin distances (255 = more than L/10)
+    uint32_t *gitems;    // k_gap items: (slot << 8) | (strand << 7) | chunk of 32 candidates
+    uint32_t *cq;        // k_cigar items: (slot << 3) | which (0 = the alignment, 1 + i = alternative hit i)
+    uint32_t *gctl;
+    uint32_t cap;
+};
+GapBufs gap_bufs_layout(uint8_t *base, uint32_t cap, uint32_t *gctl, size_t *bytes);   // base = nullptr: size only
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint4 *sai_c,
-                  const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, uint32_t *qctl, unsigned long long *ctr,
-                  uint32_t n_blocks, void *lvtab, uint32_t *gq, uint8_t *ge, uint32_t gcap, uint8_t *pe_scr, hipEvent_t *ev2, hipStream_t st);
-size_t gap_e_bytes_per_read();
+                  const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, unsigned long long *ctr,
+                  uint32_t n_blocks, void *lvtab, const GapBufs &g, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st);
 size_t lv_table_bytes();                // per-block LV traceback table (global memory)
 
 // ---- paired end (salt_pe.hip) ----
