@@ -78,6 +78,7 @@ k_pack(PackGeom pg, uint32_t n_reads, const uint8_t *__restrict__ seqs, const ui
        uint32_t *__restrict__ pm, uint32_t *__restrict__ tb)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sb[8192];              // [read][strand][32 * nw32], 8 = no base
+    __shared__ uint8_t raw[4096 + 64];                                     // the block's reads as they lie in seqs[]
     __shared__ uint32_t so[65];
     const uint32_t tpr = 2 * pg.nw32, rpb = 256 / tpr < 64 ? 256 / tpr : 64, slot = 32 * pg.nw32;   // threads per read, reads per block, bytes per strand
     const uint32_t r0 = blockIdx.x * rpb, nr = n_reads - r0 < rpb ? n_reads - r0 : rpb;
@@ -85,14 +86,24 @@ k_pack(PackGeom pg, uint32_t n_reads, const uint8_t *__restrict__ seqs, const ui
     reinterpret_cast<uint4 *>(sb)[threadIdx.x] = make_uint4(0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u);
     reinterpret_cast<uint4 *>(sb)[threadIdx.x + 256] = make_uint4(0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u);
     __syncthreads();
+    const uint32_t base = so[0];
+    uint32_t total = so[nr] - base;
+    if (total > 4096u) total = 4096u;                                       // reads longer than max_read_len says: truncated, never out of bounds
+    {   // one contiguous copy, all loads independent of each other
+        const uint8_t *src = seqs + base;
+#pragma unroll 4
+        for (uint32_t i = threadIdx.x; i < total; i += 256) raw[i] = src[i];
+    }
+    __syncthreads();
     const uint32_t cap = 8 * pg.nw8;                                        // bases the records hold per strand
-    for (uint32_t rr = threadIdx.x >> 6; rr < nr; rr += 4) {                // one wave per read
-        const uint32_t o = so[rr];
-        uint32_t L = so[rr + 1] - o;
-        if (L > cap) L = cap;                                               // longer than max_read_len says: truncated, never out of bounds
+    for (uint32_t rr = threadIdx.x >> 6; rr < nr; rr += 4) {                // one wave per read: both strands at aligned slots
+        const uint32_t o = so[rr] - base;
+        uint32_t L = so[rr + 1] - so[rr];
+        if (L > cap) L = cap;
+        if (o >= total) L = 0; else if (L > total - o) L = total - o;
         uint8_t *f = sb + (size_t)rr * 2 * slot, *v = f + slot;
         for (uint32_t i = threadIdx.x & 63u; i < L; i += 64) {
-            uint32_t c = seqs[o + i];
+            uint32_t c = raw[o + i];
             if (c > 4) c = 4;
             f[i] = (uint8_t)c;
             v[L - 1 - i] = (uint8_t)(c < 4 ? 3 - c : c);
@@ -104,6 +115,7 @@ k_pack(PackGeom pg, uint32_t n_reads, const uint8_t *__restrict__ seqs, const ui
     const uint32_t strand = sub >= pg.nw32, j = sub - strand * pg.nw32;
     uint32_t L = so[rr + 1] - so[rr];
     if (L > cap) L = cap;
+    { const uint32_t o = so[rr] - base; if (o >= total) L = 0; else if (L > total - o) L = total - o; }
     const uint4 *src = reinterpret_cast<const uint4 *>(sb + ((size_t)rr * 2 + strand) * slot + 32 * j);
     const uint4 q0 = src[0], q1 = src[1];
     const uint32_t d[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
