@@ -147,6 +147,7 @@ def main():
     kms, n_calls = aln.kernel_ms()
     kms = {k: v / max(n_calls, 1) for k, v in kms.items()}
     heavy_ids = aln.heavy_reads()
+    qc = aln.queue_counts()
 
     out = None
     if rank == 0:
@@ -163,6 +164,7 @@ def main():
                        "parallelism": "reads sharded over %d GPU(s), index replicated (one RCCL broadcast)" % world},
             "kernel_ms": {k: round(v, 3) for k, v in kms.items()},
             "reads_to_k_heavy": int(len(heavy_ids)),
+            "queue_counts": dict(zip(("heavy_reads", "gapped_reads", "k_gap_items", "k_cigar_items"), [qc[0], qc[2], qc[5], qc[6]])),
         }
         # ---- CPU baseline + parity check on a bounded sample (oracle = checker, never the product) ----
         if not args.no_cpu and world == 1:

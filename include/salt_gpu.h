@@ -163,6 +163,10 @@ int  salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[SALT_N_KERNELS], uint32_
  * *n = how many; ids[0..min(*n,cap)) = their indices in the batch, in queue order. */
 int  salt_gpu_ws_heavy_reads(salt_gpu_ws_t *ws, uint32_t *ids, uint32_t cap, uint32_t *n);
 
+/* Work-queue counters of the LAST batch (diagnostics): [0] reads k_light handed to k_heavy, [2] reads whose gapped pass
+ * was deferred, [5] k_gap items (32 candidates each), [6] k_cigar items; the odd entries are the consumers' heads. */
+int  salt_gpu_ws_queue_counts(salt_gpu_ws_t *ws, uint32_t out[8]);
+
 /* counters of the last batch(es) since the previous call; resets them */
 int  salt_gpu_ws_counters(salt_gpu_ws_t *ws, uint64_t out[SALT_CTR_N]);
 

@@ -131,6 +131,7 @@ def gpu_lib():
         lib.salt_gpu_ws_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
         lib.salt_gpu_index_image_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
         lib.salt_gpu_ws_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.salt_gpu_ws_queue_counts.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         lib.salt_gpu_ws_heavy_reads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
         lib.salt_gpu_ws_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32)]
         assert lib.salt_gpu_result_size() == RESULT_DTYPE.itemsize
@@ -310,6 +311,11 @@ class GpuAligner:
         n = ctypes.c_uint32()
         _gpu_check(gpu_lib().salt_gpu_ws_kernel_ms(self._ws, ms, ctypes.byref(n)))
         return dict(zip(KERNELS, list(ms))), n.value
+
+    def queue_counts(self):
+        out = (ctypes.c_uint32 * 8)()
+        _gpu_check(gpu_lib().salt_gpu_ws_queue_counts(self._ws, out))
+        return list(out)
 
     def heavy_reads(self):
         """Indices (in the last batch) of the reads k_light queued for k_heavy."""

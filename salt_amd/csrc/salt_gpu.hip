@@ -519,6 +519,15 @@ extern "C" int salt_gpu_diag_ssw(uint32_t n_cases, const uint8_t *aware, const u
     return SALT_OK;
 }
 
+extern "C" int salt_gpu_ws_queue_counts(salt_gpu_ws_t *ws, uint32_t out[8])
+{
+    if (!ws || !out) return fail(SALT_E_INVAL, "null argument");
+    HIPCHK(hipSetDevice(ws->ix->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, ws->d_qctl, 32, hipMemcpyDeviceToHost));
+    return SALT_OK;
+}
+
 extern "C" int salt_gpu_ws_heavy_reads(salt_gpu_ws_t *ws, uint32_t *ids, uint32_t cap, uint32_t *n)
 {
     if (!ws || !n) return fail(SALT_E_INVAL, "null argument");

@@ -10,7 +10,7 @@ import json
 import sys
 from collections import defaultdict
 
-KERNELS = ("k_seed", "k_light", "k_heavy_pe", "k_heavy", "k_gapfin", "k_gap", "k_pair", "k_sw", "k_pe_final")
+KERNELS = ("k_pack", "k_seed", "k_light", "k_heavy_pe", "k_heavy", "k_gapfin", "k_gap", "k_cigar", "k_pair", "k_sw", "k_pe_final")
 
 
 def short(name):
