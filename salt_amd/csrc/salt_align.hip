@@ -1398,7 +1398,7 @@ struct LightLds {
 };
 
 static constexpr int LT_WAVES = 1;       // independent reads (waves) per block: 4x fewer workgroups to dispatch
-__global__ void __launch_bounds__(64 * LT_WAVES)
+__global__ void __launch_bounds__(64 * LT_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
         const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
         uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl, unsigned long long *__restrict__ ctr)
