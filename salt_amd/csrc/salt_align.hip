@@ -26,6 +26,11 @@ static constexpr int MAXL = SALT_MAX_READ_LEN;
 static constexpr int SLOTS = SALT_MAX_SEED_SLOTS;
 static constexpr int MAXLOC = SALT_MAX_LOCATE;
 static constexpr int LVK = 31;                  // MAX_K (LandauVishkin.c:13)
+// k_light writes the first 24 bytes of a result row as six dwords
+static_assert(offsetof(salt_result_t, strand) == 4 && offsetof(salt_result_t, mapq) == 7 && offsetof(salt_result_t, b0) == 8 &&
+              offsetof(salt_result_t, b1) == 12 && offsetof(salt_result_t, seq_start) == 16 && offsetof(salt_result_t, seq_end) == 18 &&
+              offsetof(salt_result_t, n_hits) == 20 && offsetof(salt_result_t, n_cigar) == 22 && offsetof(salt_result_t, skipped) == 23 &&
+              offsetof(salt_result_t, hits) == 24 && sizeof(salt_hit_t) == 8, "salt_result_t header layout");
 static constexpr int NHIT = 6;                  // first hits kept per strand (5 + the primary)
 static constexpr uint32_t INF = 255;
 
@@ -1566,42 +1571,45 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
             if (heavy) { }
             else {
                 WSYNC();
-                // ---- query_set_hits / gen_mapq (query.c:270-333) ----
-                int b0 = (int)q_ndiff, b1 = 100000, tot_h = 0;
-                uint32_t nh[2] = { 0, 0 };
-                uint32_t sel_idx[2][SALT_MAX_HITS];
-                for (int s = 0; s < 2 && tot_h < ap.max_hits; ++s)
-                    for (uint32_t j = 0; j < n_hits_s[s]; ++j) {
-                        const uint32_t hp = w.hit_pos[s][j];
-                        if (hp == 0xFFFFFFFFu || hp == q_pos) continue;
-                        if (a0[s] <= q_ndiff) {
-                            if ((int)a0[s] <= b1) b1 = (int)a0[s];
-                            if (nh[s] < SALT_MAX_HITS) sel_idx[s][nh[s]] = j;
-                            ++nh[s]; ++tot_h;
-                        }
-                        if (tot_h == ap.max_hits) break;
-                    }
+                // ---- query_set_hits / gen_mapq (query.c:270-333): lane t < 2*NHIT looks at recorded hit (t / NHIT, t % NHIT);
+                // the sequential loop keeps the first max_hits of them that are neither the primary nor worse than it ----
+                const uint32_t hs = lane >= (uint32_t)NHIT, hj = lane - hs * NHIT;
+                uint32_t hp = 0xFFFFFFFFu, hn = 0;
+                bool cand = false;
+                if (lane < 2u * NHIT && hj < (hs ? n_hits_s[1] : n_hits_s[0])) {
+                    hp = w.hit_pos[hs][hj]; hn = w.hit_nd[hs][hj];
+                    cand = hp != 0xFFFFFFFFu && hp != q_pos && (hs ? a0[1] : a0[0]) <= q_ndiff;
+                }
+                const uint64_t cm = __ballot(cand);
+                const bool sel = cand && (uint32_t)__popcll(cm & lt) < (uint32_t)ap.max_hits;
+                const uint64_t sm = __ballot(sel);
+                const uint32_t nh0 = (uint32_t)__popcll(sm & ((1ull << NHIT) - 1ull)), nh1 = (uint32_t)__popcll(sm >> NHIT);
+                const int b0 = (int)q_ndiff;
+                int b1 = 100000;
+                if (nh0) b1 = (int)a0[0];
+                if (nh1 && (int)a0[1] <= b1) b1 = (int)a0[1];
                 uint32_t mapq = 0;
                 if (b0 != 0) {
                     const uint32_t x = (uint32_t)(b0 > b1 ? b0 - b1 : b1 - b0);
                     const uint64_t q = (uint64_t)255 * x / (uint32_t)b0;
                     mapq = q < 254 ? (uint32_t)q : 254u;
                 }
-                if (lane == 0) {
-                    salt_result_t *out = results + r;
-                    out->pos = q_pos; out->strand = (uint8_t)q_strand; out->n_diff = (uint8_t)q_ndiff; out->is_gap = 0;
-                    out->mapq = (uint8_t)mapq; out->b0 = b0; out->b1 = b1; out->seq_start = 0; out->seq_end = (uint16_t)(L - 1);
-                    out->n_hits[0] = (uint8_t)nh[0]; out->n_hits[1] = (uint8_t)nh[1]; out->skipped = 0;
-                    out->cigar[0] = (uint16_t)((L << 4) | 0u); out->n_cigar = 1;
-                    uint32_t hidx = 0;
-                    for (int s = 0; s < 2; ++s)
-                        for (uint32_t j = 0; j < nh[s]; ++j, ++hidx) {
-                            const uint32_t h = sel_idx[s][j];
-                            out->hits[s][j].pos = w.hit_pos[s][h]; out->hits[s][j].n_diff = w.hit_nd[s][h];
-                            out->hits[s][j].is_gap = 0; out->hits[s][j].strand = (uint16_t)s;
-                            out->hit_n_cigar[hidx] = 0;
-                        }
+                salt_result_t *out = results + r;
+                if (sel) {                                                  // one 8-byte store per kept hit, all in one instruction
+                    const uint32_t hidx = (uint32_t)__popcll(sm & lt);
+                    salt_hit_t hv; hv.pos = hp; hv.n_diff = (uint8_t)hn; hv.is_gap = 0; hv.strand = (uint16_t)hs;
+                    out->hits[hs][hs ? hidx - nh0 : hidx] = hv;
+                    out->hit_n_cigar[hidx] = 0;
                 }
+                if (lane < 6) {                                             // the 24 header bytes as six dwords
+                    const uint32_t d = lane == 0 ? q_pos
+                                     : lane == 1 ? (q_strand | (q_ndiff << 8) | (mapq << 24))             // strand, n_diff, is_gap = 0, mapq
+                                     : lane == 2 ? (uint32_t)b0
+                                     : lane == 3 ? (uint32_t)b1
+                                     : lane == 4 ? ((L - 1) << 16)                                        // seq_start = 0, seq_end
+                                     : (nh0 | (nh1 << 8) | (1u << 16));                                   // n_hits[2], n_cigar = 1, skipped = 0
+                    reinterpret_cast<uint32_t *>(out)[lane] = d;
+                } else if (lane == 6) out->cigar[0] = (uint16_t)((L << 4) | 0u);
             }
         }
     }
