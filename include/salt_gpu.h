@@ -145,6 +145,9 @@ typedef struct { uint32_t min_tlen, max_tlen; } salt_pe_opt_t;      /* -a 250, -
 int  salt_gpu_index_set_pac(salt_gpu_index_t *ix, const uint8_t *pac, uint64_t l_pac);
 int  salt_gpu_align_pe(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, const salt_pe_opt_t *pe, uint32_t n_pairs,
                        const uint8_t *seqs, const uint32_t *offs, salt_result_t *results);
+/* Same on device-resident buffers (2 * n_pairs reads); only enqueues on `hip_stream`. */
+int  salt_gpu_align_pe_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, const salt_pe_opt_t *pe, uint32_t n_pairs,
+                                uint32_t max_read_len, const void *d_seqs, const void *d_offs, void *d_results, void *hip_stream);
 
 /* Same work on device-resident buffers; only enqueues on `hip_stream` (a hipStream_t, NULL = default). */
 int  salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, uint32_t n_reads,

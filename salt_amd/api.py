@@ -128,6 +128,8 @@ def gpu_lib():
         lib.salt_gpu_index_set_pac.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
         lib.salt_gpu_align_pe.argtypes = [ctypes.c_void_p, ctypes.POINTER(_AlnOpt), ctypes.POINTER(_PeOpt), ctypes.c_uint32,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.salt_gpu_align_pe_resident.argtypes = [ctypes.c_void_p, ctypes.POINTER(_AlnOpt), ctypes.POINTER(_PeOpt), ctypes.c_uint32, ctypes.c_uint32,
+                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.salt_gpu_ws_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
         lib.salt_gpu_index_image_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
         lib.salt_gpu_ws_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -369,6 +371,16 @@ class GpuAligner:
                                              o.ctypes.data, res[done:].ctypes.data))
             done += m
         return res
+
+    def align_pe_resident(self, opt, index, n_pairs, max_read_len, d_seqs, d_offs, d_results, stream=0):
+        lib = gpu_lib()
+        if not getattr(self, "_pac_set", False):
+            pac, l_pac = index.pac()
+            _gpu_check(lib.salt_gpu_index_set_pac(self._ix, pac, l_pac))
+            self._pac_set = True
+        co, pe = opt._c(), opt._pe()
+        _gpu_check(lib.salt_gpu_align_pe_resident(self._ws, ctypes.byref(co), ctypes.byref(pe), n_pairs, max_read_len, d_seqs, d_offs,
+                                                  d_results, stream))
 
     def align_resident(self, opt, n_reads, max_read_len, d_seqs, d_offs, d_results, stream=0):
         co = opt._c()

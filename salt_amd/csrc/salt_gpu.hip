@@ -553,6 +553,56 @@ extern "C" int salt_gpu_index_set_pac(salt_gpu_index_t *ix, const uint8_t *pac, 
     return SALT_OK;
 }
 
+static int pe_prepare(salt_gpu_ws_t *ws, uint32_t n_pairs, hipStream_t st)
+{
+    if (n_pairs > ws->pe_pairs_cap) {
+        HIPCHK(hipStreamSynchronize(st));
+        hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres);
+        HIPCHK(hipMalloc((void **)&ws->d_pairs, (uint64_t)n_pairs * sizeof(PePair)));
+        HIPCHK(hipMalloc((void **)&ws->d_req, (uint64_t)n_pairs * 2 * sizeof(PeSwReq)));
+        HIPCHK(hipMalloc((void **)&ws->d_swres, (uint64_t)n_pairs * 2 * sizeof(PeSwRes)));
+        ws->pe_pairs_cap = n_pairs;
+    }
+    if (!ws->d_pctl) {
+        HIPCHK(hipMalloc((void **)&ws->d_pctl, 8 * 4));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, ws->ix->device));
+        ws->sw_blocks = (uint32_t)prop.multiProcessorCount * 4u;
+        HIPCHK(hipMalloc((void **)&ws->d_sw_scr, (uint64_t)ws->sw_blocks * 8 * SW_SCRATCH_BYTES));
+    }
+    return SALT_OK;
+}
+
+// everything of alnpe_core1 on device-resident buffers; only enqueues on st
+static int pe_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_pe_opt_t *pe, uint32_t n_pairs, uint32_t max_len,
+                            const void *d_seqs, const void *d_offs, void *d_results, hipStream_t st)
+{
+    int rc = pe_prepare(ws, n_pairs, st);
+    if (rc) return rc;
+    rc = align_resident_impl(ws, o, 2 * n_pairs, max_len, d_seqs, d_offs, d_results, st, 1);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(ws->d_pctl, 0, 32, st));
+    launch_pair(n_pairs, pe->min_tlen, pe->max_tlen, (uint32_t)ws->ix->l_pac, static_cast<const uint32_t *>(d_offs), static_cast<salt_result_t *>(d_results),
+                ws->d_pairs, ws->d_req, ws->d_pctl, st);
+    launch_sw(ws->ix->view, ws->ix->d_pac, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_req, ws->d_pctl, ws->d_swres,
+              ws->d_pctl + 1, ws->d_sw_scr, ws->sw_blocks, st);
+    launch_pe_final(ws->ix->view, PackGeom::make(max_len), n_pairs, ws->d_pm, static_cast<salt_result_t *>(d_results), ws->d_pairs, ws->d_swres, ws->d_lvtab,
+                    ws->d_pctl + 2, ws->heavy_blocks, st);
+    HIPCHK(hipGetLastError());
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_align_pe_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_pe_opt_t *pe, uint32_t n_pairs,
+                                          uint32_t max_read_len, const void *d_seqs, const void *d_offs, void *d_results, void *hip_stream)
+{
+    if (!ws || !o || !pe || !d_seqs || !d_offs || !d_results) return fail(SALT_E_INVAL, "null argument");
+    if (n_pairs == 0) return SALT_OK;
+    if (2ull * n_pairs > ws->max_reads) return fail(SALT_E_CAPACITY, "more mates than the workspace holds");
+    if (!ws->ix->d_pac) return fail(SALT_E_INVAL, "paired end needs the 2-bit genome: call salt_gpu_index_set_pac first");
+    HIPCHK(hipSetDevice(ws->ix->device));
+    return pe_resident_impl(ws, o, pe, n_pairs, max_read_len, d_seqs, d_offs, d_results, static_cast<hipStream_t>(hip_stream));
+}
+
 extern "C" int salt_gpu_align_pe(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_pe_opt_t *pe, uint32_t n_pairs,
                                  const uint8_t *seqs, const uint32_t *offs, salt_result_t *results)
 {
@@ -572,30 +622,10 @@ extern "C" int salt_gpu_align_pe(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, con
     }
     HIPCHK(hipSetDevice(ws->ix->device));
     hipStream_t st = ws->stream;
-    if (n_pairs > ws->pe_pairs_cap) {
-        HIPCHK(hipStreamSynchronize(st));
-        hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres);
-        HIPCHK(hipMalloc((void **)&ws->d_pairs, (uint64_t)n_pairs * sizeof(PePair)));
-        HIPCHK(hipMalloc((void **)&ws->d_req, (uint64_t)n_pairs * 2 * sizeof(PeSwReq)));
-        HIPCHK(hipMalloc((void **)&ws->d_swres, (uint64_t)n_pairs * 2 * sizeof(PeSwRes)));
-        ws->pe_pairs_cap = n_pairs;
-    }
-    if (!ws->d_pctl) {
-        HIPCHK(hipMalloc((void **)&ws->d_pctl, 8 * 4));
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, ws->ix->device));
-        ws->sw_blocks = (uint32_t)prop.multiProcessorCount * 4u;
-        HIPCHK(hipMalloc((void **)&ws->d_sw_scr, (uint64_t)ws->sw_blocks * 8 * SW_SCRATCH_BYTES));
-    }
     HIPCHK(hipMemcpyAsync(ws->d_seqs, seqs, bases, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ws->d_offs, offs, ((uint64_t)n_reads + 1) * 4, hipMemcpyHostToDevice, st));
-    int rc = align_resident_impl(ws, o, n_reads, max_len, ws->d_seqs, ws->d_offs, ws->d_results, st, 1);
+    int rc = pe_resident_impl(ws, o, pe, n_pairs, max_len, ws->d_seqs, ws->d_offs, ws->d_results, st);
     if (rc) return rc;
-    HIPCHK(hipMemsetAsync(ws->d_pctl, 0, 32, st));
-    launch_pair(n_pairs, pe->min_tlen, pe->max_tlen, (uint32_t)ws->ix->l_pac, ws->d_offs, ws->d_results, ws->d_pairs, ws->d_req, ws->d_pctl, st);
-    launch_sw(ws->ix->view, ws->ix->d_pac, ws->d_seqs, ws->d_offs, ws->d_req, ws->d_pctl, ws->d_swres, ws->d_pctl + 1, ws->d_sw_scr, ws->sw_blocks, st);
-    launch_pe_final(ws->ix->view, PackGeom::make(max_len), n_pairs, ws->d_pm, ws->d_results, ws->d_pairs, ws->d_swres, ws->d_lvtab, ws->d_pctl + 2, ws->heavy_blocks, st);
-    HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(results, ws->d_results, (uint64_t)n_reads * sizeof(salt_result_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return SALT_OK;
