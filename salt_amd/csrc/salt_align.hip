@@ -375,6 +375,30 @@ __device__ void sort_loci(uint32_t *a, uint32_t n)
     }
 }
 
+// drop duplicates and out-of-range loci of a sorted list, keeping order (alnse.c:758-762 / 890-894)
+__device__ __forceinline__ uint32_t dedup_loci(uint32_t *loci, uint32_t n, bool gap_mode, uint32_t L, uint32_t ref_len)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t n_out = 0;
+    for (uint32_t b = 0; b < n; b += 64) {
+        uint32_t i = b + lane;
+        bool keep = false; uint32_t pos = 0;
+        if (i < n) {
+            pos = loci[i];
+            bool dup = i > 0 && loci[i - 1] == pos;
+            bool out = gap_mode ? (pos + L + 4 >= ref_len) : (pos >= ref_len);
+            keep = !dup && !out;
+        }
+        uint64_t m = __ballot(keep);
+        WSYNC();                                           // all reads of this chunk are done
+        if (keep) loci[n_out + (uint32_t)__popcll(m & lt)] = pos;
+        n_out += (uint32_t)__popcll(m);
+        WSYNC();
+    }
+    return n_out;
+}
+
 // ---- candidates of one strand: gather seeds, order them, locate, sort, dedup ----------------------
 // Leaves the candidate positions in w.loci[0..return).  gap_mode selects the range filter of
 // alnse_check_withgap (alnse.c:894) instead of alnse_check_nogap's (alnse.c:762).
@@ -383,6 +407,7 @@ struct CandArgs {                      // everything by value: a by-reference In
     const uint32_t *c_sa, *r_pos; const uint4 *sai_c, *sai_r;
     uint32_t ref_len, spr, max_locate, r, L; int strand; bool gap_mode; unsigned long long *phase;
     uint32_t *loci; uint32_t loci_cap; int pe;
+    bool finish;                   // false: stop after locate (unsorted, duplicates and out-of-range loci still in)
 };
 template <bool PE>
 __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, WaveLds &w)
@@ -490,26 +515,11 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
     n_loci_out += n;
     WSYNC();
     pc.stamp(SALT_CTR_T_LOCATE);
+    if (!a.finish) return CandStats{ n, n_sa_c, n_sa_r, n_loci_out };
     sort_loci(loci, n);
     WSYNC();
     pc.stamp(SALT_CTR_T_SORT);
-    // drop duplicates and out-of-range loci, keeping order (alnse.c:758-762 / 890-894)
-    uint32_t n_out = 0;
-    for (uint32_t b = 0; b < n; b += 64) {
-        uint32_t i = b + lane;
-        bool keep = false; uint32_t pos = 0;
-        if (i < n) {
-            pos = loci[i];
-            bool dup = i > 0 && loci[i - 1] == pos;
-            bool out = gap_mode ? (pos + L + 4 >= ix.ref_len) : (pos >= ix.ref_len);
-            keep = !dup && !out;
-        }
-        uint64_t m = __ballot(keep);
-        WSYNC();                                           // all reads of this chunk are done
-        if (keep) loci[n_out + (uint32_t)__popcll(m & lt)] = pos;
-        n_out += (uint32_t)__popcll(m);
-        WSYNC();
-    }
+    const uint32_t n_out = dedup_loci(loci, n, gap_mode, L, ix.ref_len);
     pc.stamp(SALT_CTR_T_DEDUP);
     return CandStats{ n_out, n_sa_c, n_sa_r, n_loci_out };
 }
@@ -926,29 +936,40 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     bool found[2] = { false, false };
     uint32_t n_hits_s[2] = { 0, 0 };            // hits recorded (<= NHIT) per strand
     uint32_t a0[2] = { 0, 0 };                  // n_diff of the first hit of each list
-    uint32_t n_cand_nogap = 0, n_cand_s[2] = { 0, 0 };
-    CandStats cs_s[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+    uint32_t n_cand_nogap = 0;
     if (!too_short)
     for (int strand = 0; strand < 2; ++strand) {
         pc.stamp(SALT_CTR_T_SCAN);
-        const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, loci, loci_cap, ap.pe }, w);
+        // Located rows first, unsorted: only loci that can pass (<= 3 mismatches, inside the reference) matter to the
+        // sequential rule, so the sort (alnse.c:726-729), the duplicate filter (alnse.c:758-762) and the rule run on
+        // those few; the result is the one the full sorted list gives.
+        const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, loci, loci_cap, ap.pe, false }, w);
         pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
-        const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
+        const uint32_t n_loc = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
         uint32_t call_best_n = INF, call_best_pos = 0;
-        // phase A: every candidate's distance, 4 per lane with all loads in flight
-        if (L <= 120) verify_quads<8>(ix.ref, w.pm[strand], L, loci, n_cand, cand_e);
-        else if (L <= 8 * 13) {
-            for (uint32_t b = 0; b < n_cand; b += 256) {
-                uint32_t pp[4], vv[4]; bool aa[4];
-                const uint32_t *const pms[4] = { w.pm[strand], w.pm[strand], w.pm[strand], w.pm[strand] };
-                for (int u = 0; u < 4; ++u) { const uint32_t i = b + 64u * u + lane; aa[u] = i < n_cand; pp[u] = aa[u] ? loci[i] : 0u; }
-                mismatch_batch<13, 4>(ix, pms, L, pp, aa, vv);
-                for (int u = 0; u < 4; ++u) { const uint32_t i = b + 64u * u + lane; if (i < n_cand) cand_e[i] = (uint8_t)vv[u]; }
-            }
-        } else {
-            for (uint32_t i = lane; i < n_cand; i += 64) cand_e[i] = (uint8_t)mismatch_capped(ix, w.pm[strand], L, loci[i]);
+        auto verify_all = [&](uint32_t n) {                   // cand_e[i] = min(mismatches, INF) of loci[i], loads of 128 candidates in flight
+            if (L <= 120) verify_quads<8>(ix.ref, w.pm[strand], L, loci, n, cand_e);
+            else for (uint32_t i = lane; i < n; i += 64) cand_e[i] = (uint8_t)mismatch_capped(ix, w.pm[strand], L, loci[i]);
+            WSYNC();
+        };
+        verify_all(n_loc);
+        uint32_t n_pass = 0;
+        for (uint32_t b = 0; b < n_loc; b += 64) {
+            const uint32_t i = b + lane;
+            const uint32_t pos = i < n_loc ? loci[i] : 0u;
+            const bool keep = i < n_loc && cand_e[i] <= 3 && pos < ix.ref_len;
+            const uint64_t m = __ballot(keep);
+            WSYNC();
+            if (keep) loci[n_pass + (uint32_t)__popcll(m & lt)] = pos;
+            n_pass += (uint32_t)__popcll(m);
+            WSYNC();
         }
+        pc.stamp(SALT_CTR_T_VERIFY);
+        sort_loci(loci, n_pass);
         WSYNC();
+        const uint32_t n_cand = dedup_loci(loci, n_pass, false, L, ix.ref_len);
+        pc.stamp(SALT_CTR_T_SORT);
+        verify_all(n_cand);                                   // the same distances again, now in list order
         pc.stamp(SALT_CTR_T_VERIFY);
         // phase B: the sequential rule, replayed by ballots over 64 candidates at a time
         for (uint32_t b = 0; b < n_cand; b += 64) {
@@ -978,7 +999,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             }
             (void)m3;
         }
-        c_verify += n_cand; n_cand_nogap += n_cand; n_cand_s[strand] = n_cand; cs_s[strand] = cs;
+        c_verify += n_loc; n_cand_nogap += n_loc;
         for (uint32_t b = lane; b < n_cand; b += 64) c_vwords += ((loci[b] & 7u) + L + 7) >> 3;
         if (found[strand]) { q_pos = call_best_pos; q_ndiff = call_best_n; q_gap = 0; q_strand = (uint32_t)strand; }
         WSYNC();
@@ -995,16 +1016,15 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             if (lane == 0) slot = atomicAdd(&g.gctl[2], 1u);
             slot = (uint32_t)__shfl((int)slot, 0);
             if (slot < g.cap) {                                           // k_gap / k_gapfin / k_cigar take it from here
-                // strand 1's gap-free list is still in LDS; strand 0's is located again
                 uint32_t ns[2];
-                ns[1] = store_gap_list(loci, n_cand_s[1], L, ix.ref_len, g.gloci + ((size_t)slot * 2 + 1) * MAXLOC);
-                c_sa_c += cs_s[1].n_sa_c; c_sa_r += cs_s[1].n_sa_r; c_loci += cs_s[1].n_loci;
-                WSYNC();
-                const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, 0, true, phase, loci, loci_cap, ap.pe }, w);
-                c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
-                uint32_t *dst0 = g.gloci + (size_t)slot * 2 * MAXLOC;
-                for (uint32_t i = lane; i < cs.n_cand; i += 64) dst0[i] = loci[i];
-                ns[0] = cs.n_cand;
+                for (int strand = 0; strand < 2; ++strand) {              // the gapped pass's candidate lists, sorted and filtered
+                    const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, loci, loci_cap, ap.pe, true }, w);
+                    c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
+                    uint32_t *dst = g.gloci + ((size_t)slot * 2 + (uint32_t)strand) * MAXLOC;
+                    for (uint32_t i = lane; i < cs.n_cand; i += 64) dst[i] = loci[i];
+                    ns[strand] = cs.n_cand;
+                    WSYNC();
+                }
                 const uint32_t ch0 = (ns[0] + LLV_N - 1) / LLV_N, ch1 = (ns[1] + LLV_N - 1) / LLV_N;
                 uint32_t base = 0;
                 if (lane == 0) { base = atomicAdd(&g.gctl[5], ch0 + ch1); g.gq[slot] = r; g.gn[2 * slot] = ns[0]; g.gn[2 * slot + 1] = ns[1]; }
@@ -1024,7 +1044,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         }
         for (int strand = 0; strand < 2; ++strand) {
             pc.stamp(SALT_CTR_T_GAP);
-            const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, loci, loci_cap, ap.pe }, w);
+            const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, loci, loci_cap, ap.pe, true }, w);
             pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
             const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
             bool any = false;
