@@ -1353,7 +1353,7 @@ k_gapfin(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, salt_res
                 }
             if (n_cig_items) {                                            // main hit (which = 0) and every alternative hit (1 + index)
                 const uint32_t base = atomicAdd(&g.gctl[6], n_cig_items);
-                for (uint32_t c = 0; c < n_cig_items; ++c) g.cq[base + c] = (slot << 3) | c;
+                for (uint32_t c = 0; c < n_cig_items; ++c) g.cq[base + c] = (r << 3) | c;
             }
             if (ctr) atomicMax(ctr + SALT_CTR_MAX_GAPFIN, ((unsigned long long)(__builtin_amdgcn_s_memrealtime() - rt0) << 32) | r);
         }
@@ -1361,23 +1361,25 @@ k_gapfin(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, salt_res
     }
 }
 
-// k_cigar: one LV traceback per wave (query_gen_cigar query.c:282-296; XA CIGARs sam.c:216-225)
+// k_cigar: one LV traceback per wave (query_gen_cigar query.c:282-296; XA CIGARs sam.c:216-225).
+// items[i] = (read << 3) | which, which 0 = the alignment itself, 1 + h = alternative hit h; *count items, *head = the queue head
 __global__ void __launch_bounds__(64)
-k_cigar(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, salt_result_t *__restrict__ results, GapBufs g,
+k_cigar(IndexView ix, PackGeom pg, const uint32_t *__restrict__ pm, salt_result_t *__restrict__ results,
+        const uint32_t *__restrict__ items, const uint32_t *__restrict__ count, uint32_t *__restrict__ head, uint32_t cap_items,
         LvTables *__restrict__ lvtab)
 {
     __shared__ WaveLds w;
     __shared__ uint32_t s_item;
     const uint32_t lane = lane_id();
-    const uint32_t cap_items = g.cap * (1u + SALT_MAX_HITS);
-    const uint32_t n_items = g.gctl[6] < cap_items ? g.gctl[6] : cap_items;
+    const uint32_t n_items = *count < cap_items ? *count : cap_items;
+    struct { PackGeom pg; } ap = { pg };
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(&g.gctl[7], 1u);
+        if (threadIdx.x == 0) s_item = atomicAdd(head, 1u);
         WSYNC();
         const uint32_t it = s_item;
         WSYNC();
         if (it >= n_items) break;
-        const uint32_t item = g.cq[it], which = item & 7u, r = g.gq[item >> 3];
+        const uint32_t item = items[it], which = item & 7u, r = item >> 3;
         salt_result_t *out = results + r;
         const uint32_t *rec = pm + (uint64_t)r * ap.pg.pm_stride;
         const uint32_t L = rec[2 * ap.pg.nw8];
@@ -1650,24 +1652,17 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_pe_final: one wave per pair -- apply the first successful mate rescue (in the order pairing2 /
+// k_pe_final: one thread per pair -- apply the first successful mate rescue (in the order pairing2 /
 // pairing_singleton try them, alnpe.c:213-252, 420-470), then query_gen_cigar for the mates that keep their
-// seed-and-verify mapping (query.c:282-296)
+// seed-and-verify mapping (query.c:282-296): "<L>M", or a k_cigar item when the mapping is gapped
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-k_pe_final(IndexView ix, PackGeom pg, uint32_t n_pairs, const uint32_t *__restrict__ pm,
-           salt_result_t *__restrict__ res, const PePair *__restrict__ pairs, const PeSwRes *__restrict__ sw, LvTables *__restrict__ lvtab,
-           uint32_t *__restrict__ head)
+__global__ void __launch_bounds__(256)
+k_pe_final(PackGeom pg, uint32_t n_pairs, const uint32_t *__restrict__ pm,
+           salt_result_t *__restrict__ res, const PePair *__restrict__ pairs, const PeSwRes *__restrict__ sw,
+           uint32_t *__restrict__ citems, uint32_t *__restrict__ ccount)
 {
-    __shared__ WaveLds w;
-    __shared__ uint32_t s_item;
-    const uint32_t lane = lane_id();
-  for (;;) {                                                              // persistent: the LV table slot is this block's own
-    if (threadIdx.x == 0) s_item = atomicAdd(head, 1u);
-    WSYNC();
-    const uint32_t p = s_item;
-    WSYNC();
-    if (p >= n_pairs) break;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
     const PePair pr = pairs[p];
     int rescued = -1;
     for (int k = 0; k < pr.n_req && rescued < 0; ++k) {
@@ -1675,45 +1670,32 @@ k_pe_final(IndexView ix, PackGeom pg, uint32_t n_pairs, const uint32_t *__restri
         if (!r.ok) continue;
         rescued = pr.rescued[k];
         salt_result_t *q = res + 2 * p + rescued;
-        if (lane == 0) {
-            const int b0 = r.score1, b1 = r.score2;
-            uint32_t mapq = 0;
-            if (b0 != 0) { const uint32_t x = (uint32_t)(b0 > b1 ? b0 - b1 : b1 - b0); const uint64_t v = (uint64_t)255 * x / (uint32_t)b0; mapq = v < 254 ? (uint32_t)v : 254u; }
-            q->b0 = b0; q->b1 = b1; q->mapq = (uint8_t)mapq;
-            q->pos = (uint32_t)r.ref_begin + r.start; q->strand = (uint8_t)r.strand;
-            q->seq_start = (uint16_t)r.read_begin; q->seq_end = (uint16_t)r.read_end;
-            q->n_cigar = (uint8_t)r.n_cigar;
-        }
-        if (lane < r.n_cigar) q->cigar[lane] = r.cigar[lane];
+        const int b0 = r.score1, b1 = r.score2;
+        uint32_t mapq = 0;
+        if (b0 != 0) { const uint32_t x = (uint32_t)(b0 > b1 ? b0 - b1 : b1 - b0); const uint64_t v = (uint64_t)255 * x / (uint32_t)b0; mapq = v < 254 ? (uint32_t)v : 254u; }
+        q->b0 = b0; q->b1 = b1; q->mapq = (uint8_t)mapq;
+        q->pos = (uint32_t)r.ref_begin + r.start; q->strand = (uint8_t)r.strand;
+        q->seq_start = (uint16_t)r.read_begin; q->seq_end = (uint16_t)r.read_end;
+        q->n_cigar = (uint8_t)r.n_cigar;
+        for (uint32_t c = 0; c < r.n_cigar; ++c) q->cigar[c] = r.cigar[c];
     }
     for (int m = 0; m < 2; ++m) {
         if (m == rescued) continue;
         salt_result_t *q = res + 2 * p + m;
-        const uint32_t *rec = pm + (uint64_t)(2 * p + m) * pg.pm_stride;
-        const uint32_t L = rec[2 * pg.nw8];
-        if (lane == 0) { q->seq_start = 0; q->seq_end = (uint16_t)(L - 1); }
-        const uint32_t pos = q->pos;
-        if (pos == 0xFFFFFFFFu) { if (lane == 0) q->n_cigar = 0; continue; }
-        if (q->is_gap) {
-            const int strand = q->strand;
-            for (uint32_t t = lane; t < (L + 7) >> 3; t += 64) w.pm[strand][t] = rec[(uint32_t)strand * pg.nw8 + t];
-            WSYNC();
-            lv_cigar(ix.ref, w, lvtab + blockIdx.x, strand, L, pos, (int)q->n_diff);
-            if (lane < (uint32_t)w.n_cig) q->cigar[lane] = w.cig[lane];
-            if (lane == 0) q->n_cigar = (uint8_t)w.n_cig;
-            WSYNC();
-        } else if (lane == 0) { q->cigar[0] = (uint16_t)((L << 4) | 0u); q->n_cigar = 1; }
+        const uint32_t L = pm[(uint64_t)(2 * p + m) * pg.pm_stride + 2 * pg.nw8];
+        q->seq_start = 0; q->seq_end = (uint16_t)(L - 1);
+        if (q->pos == 0xFFFFFFFFu) q->n_cigar = 0;
+        else if (q->is_gap) { q->n_cigar = 0; citems[atomicAdd(ccount, 1u)] = ((2 * p + (uint32_t)m) << 3) | 0u; }
+        else { q->cigar[0] = (uint16_t)((L << 4) | 0u); q->n_cigar = 1; }
     }
-    WSYNC();
-  }
 }
 
 void launch_pe_final(const IndexView &ix, const PackGeom &pg, uint32_t n_pairs, const uint32_t *pm, salt_result_t *res, const PePair *pairs,
-                     const PeSwRes *sw, void *lvtab, uint32_t *head, uint32_t n_blocks, hipStream_t st)
+                     const PeSwRes *sw, void *lvtab, uint32_t *citems, uint32_t *cctl, uint32_t n_blocks, hipStream_t st)
 {
     if (!n_pairs) return;
-    const uint32_t blocks = n_blocks < n_pairs ? n_blocks : n_pairs;
-    hipLaunchKernelGGL(k_pe_final, dim3(blocks), dim3(64), 0, st, ix, pg, n_pairs, pm, res, pairs, sw, static_cast<LvTables *>(lvtab), head);
+    hipLaunchKernelGGL(k_pe_final, dim3((n_pairs + 255) / 256), dim3(256), 0, st, pg, n_pairs, pm, res, pairs, sw, citems, cctl);
+    hipLaunchKernelGGL(k_cigar, dim3(n_blocks), dim3(64), 0, st, ix, pg, pm, res, citems, cctl, cctl + 1, 2 * n_pairs, static_cast<LvTables *>(lvtab));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1834,7 +1816,7 @@ void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm
     if (ev3) hipEventRecord(ev3[1], st);
     hipLaunchKernelGGL(k_gapfin, dim3(n_blocks), dim3(64), 0, st, ix, ap, pm, results, g, ctr);
     if (ev3) hipEventRecord(ev3[2], st);
-    hipLaunchKernelGGL(k_cigar, dim3(n_blocks), dim3(64), 0, st, ix, ap, pm, results, g, tab);
+    hipLaunchKernelGGL(k_cigar, dim3(n_blocks), dim3(64), 0, st, ix, ap.pg, pm, results, g.cq, g.gctl + 6, g.gctl + 7, g.cap * (1u + SALT_MAX_HITS), tab);
 }
 
 GapBufs gap_bufs_layout(uint8_t *base, uint32_t cap, uint32_t *gctl, size_t *bytes)

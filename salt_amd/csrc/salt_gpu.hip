@@ -42,6 +42,7 @@ struct salt_gpu_ws {
     uint8_t *d_pe_scr = nullptr;                       // per persistent block: PE_LOCI_CAP loci + distances
     PePair *d_pairs = nullptr; PeSwReq *d_req = nullptr; PeSwRes *d_swres = nullptr; uint32_t *d_pctl = nullptr;
     uint8_t *d_sw_scr = nullptr; uint32_t sw_blocks = 0; uint32_t pe_pairs_cap = 0;
+    uint32_t *d_pcq = nullptr;                         // k_cigar items of the gapped, not rescued mates
     uint32_t heavy_blocks = 2048;
     int all_heavy = 0;
     hipStream_t stream = nullptr;
@@ -258,7 +259,7 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
     if (!ws) return;
     hipSetDevice(ws->ix->device);
     hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gap);
-    hipFree(ws->d_pe_scr); hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres); hipFree(ws->d_pctl); hipFree(ws->d_sw_scr);
+    hipFree(ws->d_pe_scr); hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres); hipFree(ws->d_pctl); hipFree(ws->d_sw_scr); hipFree(ws->d_pcq);
     if (ws->stream) hipStreamDestroy(ws->stream);
     for (auto &e : ws->ev) if (e) hipEventDestroy(e);
     delete ws;
@@ -481,6 +482,7 @@ extern "C" int salt_gpu_diag_ssw(uint32_t n_cases, const uint8_t *aware, const u
     std::vector<uint32_t> h_ref(n_sym / 8 + 8, 0u);
     std::vector<uint8_t> h_pac(n_sym / 4 + 8, 0);
     std::vector<PeSwReq> h_req(n_cases);
+    uint32_t diag_max_len = 1;
     for (uint32_t i = 0; i < n_cases; ++i) {
         if (ref_offs[i + 1] <= ref_offs[i] || read_offs[i + 1] <= read_offs[i]) return fail(SALT_E_INVAL, "empty case");
         for (uint64_t p = ref_offs[i]; p < ref_offs[i + 1]; ++p) {
@@ -488,6 +490,7 @@ extern "C" int salt_gpu_diag_ssw(uint32_t n_cases, const uint8_t *aware, const u
             h_pac[p >> 2] |= (uint8_t)((ref_syms[p] & 3u) << ((~p & 3u) << 1));
         }
         h_req[i] = PeSwReq{ ref_offs[i], ref_offs[i + 1] - 1, i, 0, (uint8_t)(aware[i] ? 1 : 0), 0 };
+        if (read_offs[i + 1] - read_offs[i] > diag_max_len) diag_max_len = read_offs[i + 1] - read_offs[i];
     }
     uint32_t *d_ref = nullptr, *d_offs = nullptr, *d_ctl = nullptr; uint8_t *d_pac = nullptr, *d_codes = nullptr, *d_scr = nullptr;
     PeSwReq *d_req = nullptr; PeSwRes *d_res = nullptr;
@@ -503,7 +506,8 @@ extern "C" int salt_gpu_diag_ssw(uint32_t n_cases, const uint8_t *aware, const u
     HIPCHK(hipMalloc((void **)&d_ctl, 8)); HIPCHK(hipMemcpy(d_ctl, ctl, 8, hipMemcpyHostToDevice));
     IndexView v; memset(&v, 0, sizeof v);
     v.ref = d_ref; v.ref_len = (uint32_t)n_sym;
-    launch_sw(v, d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 1, d_scr, blocks, nullptr);
+    if (diag_max_len > SALT_MAX_READ_LEN) return fail(SALT_E_INVAL, "read longer than SALT_MAX_READ_LEN");
+    launch_sw(v, d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 1, d_scr, blocks, diag_max_len, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     std::vector<PeSwRes> h_res(n_cases);
@@ -557,7 +561,8 @@ static int pe_prepare(salt_gpu_ws_t *ws, uint32_t n_pairs, hipStream_t st)
 {
     if (n_pairs > ws->pe_pairs_cap) {
         HIPCHK(hipStreamSynchronize(st));
-        hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres);
+        hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres); hipFree(ws->d_pcq);
+        HIPCHK(hipMalloc((void **)&ws->d_pcq, (uint64_t)n_pairs * 2 * 4));
         HIPCHK(hipMalloc((void **)&ws->d_pairs, (uint64_t)n_pairs * sizeof(PePair)));
         HIPCHK(hipMalloc((void **)&ws->d_req, (uint64_t)n_pairs * 2 * sizeof(PeSwReq)));
         HIPCHK(hipMalloc((void **)&ws->d_swres, (uint64_t)n_pairs * 2 * sizeof(PeSwRes)));
@@ -567,8 +572,8 @@ static int pe_prepare(salt_gpu_ws_t *ws, uint32_t n_pairs, hipStream_t st)
         HIPCHK(hipMalloc((void **)&ws->d_pctl, 8 * 4));
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ws->ix->device));
-        ws->sw_blocks = (uint32_t)prop.multiProcessorCount * 4u;
-        HIPCHK(hipMalloc((void **)&ws->d_sw_scr, (uint64_t)ws->sw_blocks * 8 * SW_SCRATCH_BYTES));
+        ws->sw_blocks = (uint32_t)prop.multiProcessorCount;             // per block-per-CU; the scratch holds SW_MAX_BLOCKS_PER_CU of them
+        HIPCHK(hipMalloc((void **)&ws->d_sw_scr, (uint64_t)ws->sw_blocks * SW_MAX_BLOCKS_PER_CU * 8 * SW_SCRATCH_BYTES));
     }
     return SALT_OK;
 }
@@ -585,9 +590,9 @@ static int pe_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const sa
     launch_pair(n_pairs, pe->min_tlen, pe->max_tlen, (uint32_t)ws->ix->l_pac, static_cast<const uint32_t *>(d_offs), static_cast<salt_result_t *>(d_results),
                 ws->d_pairs, ws->d_req, ws->d_pctl, st);
     launch_sw(ws->ix->view, ws->ix->d_pac, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_req, ws->d_pctl, ws->d_swres,
-              ws->d_pctl + 1, ws->d_sw_scr, ws->sw_blocks, st);
+              ws->d_pctl + 1, ws->d_sw_scr, ws->sw_blocks * sw_blocks_per_cu(max_len), max_len, st);
     launch_pe_final(ws->ix->view, PackGeom::make(max_len), n_pairs, ws->d_pm, static_cast<salt_result_t *>(d_results), ws->d_pairs, ws->d_swres, ws->d_lvtab,
-                    ws->d_pctl + 2, ws->heavy_blocks, st);
+                    ws->d_pcq, ws->d_pctl + 2, ws->heavy_blocks, st);
     HIPCHK(hipGetLastError());
     return SALT_OK;
 }

@@ -78,9 +78,11 @@ struct PePair { uint32_t req0; uint8_t n_req; uint8_t rescued[2]; uint8_t pad; }
 void launch_pair(uint32_t n_pairs, uint32_t min_tlen, uint32_t max_tlen, uint32_t l_pac, const uint32_t *offs, salt_result_t *res,
                  PePair *pairs, PeSwReq *req, uint32_t *pctl, hipStream_t st);
 void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, const uint32_t *offs, const PeSwReq *req, const uint32_t *pctl,
-               PeSwRes *res, uint32_t *head, uint8_t *scratch, uint32_t n_blocks, hipStream_t st);
+               PeSwRes *res, uint32_t *head, uint8_t *scratch, uint32_t n_blocks, uint32_t max_len, hipStream_t st);
+static const uint32_t SW_MAX_BLOCKS_PER_CU = 8;    // bounds the traceback scratch (SW_SCRATCH_BYTES per 8-lane group)
+uint32_t sw_blocks_per_cu(uint32_t max_len);
 void launch_pe_final(const IndexView &ix, const PackGeom &pg, uint32_t n_pairs, const uint32_t *pm, salt_result_t *res, const PePair *pairs,
-                     const PeSwRes *sw, void *lvtab, uint32_t *head, uint32_t n_blocks, hipStream_t st);
+                     const PeSwRes *sw, void *lvtab, uint32_t *citems, uint32_t *cctl, uint32_t n_blocks, hipStream_t st);   // cctl[0] count, cctl[1] head
 
 uint32_t heavy_blocks_per_cu();
 void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const uint32_t *kdiff, const uint8_t *seqs,

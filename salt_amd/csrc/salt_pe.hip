@@ -30,10 +30,12 @@ __device__ __forceinline__ int sw_score(bool aware, uint32_t ref, uint32_t code)
 __device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
 __device__ __forceinline__ int subu16(int a, int b) { unsigned x = (unsigned)a & 0xFFFFu; return (int)(short)(x > (unsigned)b ? x - (unsigned)b : 0u); }
 
-struct SwLds {                       // per 8-lane group
-    short H[2][SW_MAX_SEG][8], E[SW_MAX_SEG][8], Hmax[SW_MAX_SEG][8];
-    uint8_t read[SW_MAX_SEG * 8];
+struct SwLds {                       // per 8-lane group: views into the block's dynamic LDS, seg = ceil(max read length / 8)
+    short *H[2], *E, *Hmax;          // [seg][8]
+    uint8_t *read;                   // [8 * seg]
 };
+__device__ __forceinline__ uint32_t sw_group_bytes(uint32_t seg) { return 4u * seg * 16u + ((8u * seg + 15u) & ~15u); }
+
 
 __device__ __forceinline__ uint32_t ref_symbol(const IndexView &ix, const uint8_t *pac, bool aware, uint32_t p)
 {
@@ -50,13 +52,13 @@ __device__ void sw_word_pass(const IndexView &ix, const uint8_t *pac, bool aware
     const uint64_t gmask = 0xFFull << (threadIdx.x & 56u);
     const int segLen = (readLen + 7) / 8, go = 3, ge = 1;      // aln.h:137-138
     int cur = 0, max = 0, end_ref = 0;
-    for (int j = 0; j < segLen; ++j) { s.H[0][j][lane] = 0; s.H[1][j][lane] = 0; s.E[j][lane] = 0; s.Hmax[j][lane] = 0; }
+    for (int j = 0; j < segLen; ++j) { s.H[0][j * 8 + lane] = 0; s.H[1][j * 8 + lane] = 0; s.E[j * 8 + lane] = 0; s.Hmax[j * 8 + lane] = 0; }
     int vMaxScore = 0, vMaxMark = 0;
     const int begin = ref_dir ? refLen - 1 : 0, end = ref_dir ? -1 : refLen, step = ref_dir ? -1 : 1;
     for (int i = begin; i != end; i += step) {
         const uint32_t sym = ref_symbol(ix, pac, aware, ref0 + (uint32_t)i);
         int vF = 0, vMaxColumn = 0;
-        int vH = __shfl_up((int)s.H[cur][segLen - 1][lane], 1, 8);
+        int vH = __shfl_up((int)s.H[cur][(segLen - 1) * 8 + lane], 1, 8);
         if (lane == 0) vH = 0;
         const int ld = cur, st = cur ^ 1;                        // pvHLoad = old store, pvHStore = the other buffer
         cur = st;
@@ -64,23 +66,23 @@ __device__ void sw_word_pass(const IndexView &ix, const uint8_t *pac, bool aware
             const int q = j + lane * segLen;
             const int prof = q >= readLen ? 0 : sw_score(aware, sym, rd(q));
             int h = sat16(vH + prof);
-            int e = s.E[j][lane];
+            int e = s.E[j * 8 + lane];
             h = h > e ? h : e; h = h > vF ? h : vF;
             vMaxColumn = vMaxColumn > h ? vMaxColumn : h;
-            s.H[st][j][lane] = (short)h;
+            s.H[st][j * 8 + lane] = (short)h;
             h = subu16(h, go);
-            e = subu16(e, ge); e = e > h ? e : h; s.E[j][lane] = (short)e;
+            e = subu16(e, ge); e = e > h ? e : h; s.E[j * 8 + lane] = (short)e;
             vF = subu16(vF, ge); vF = vF > h ? vF : h;
-            vH = s.H[ld][j][lane];
+            vH = s.H[ld][j * 8 + lane];
         }
         bool lazy_done = false;
         for (int k = 0; k < 8 && !lazy_done; ++k) {              // lazy F (ssw.c:487-497)
             vF = __shfl_up(vF, 1, 8);
             if (lane == 0) vF = 0;
             for (int j = 0; j < segLen; ++j) {
-                int h = s.H[st][j][lane];
+                int h = s.H[st][j * 8 + lane];
                 h = h > vF ? h : vF;
-                s.H[st][j][lane] = (short)h;
+                s.H[st][j * 8 + lane] = (short)h;
                 h = subu16(h, go);
                 vF = subu16(vF, ge);
                 if ((__ballot(vF > h) & gmask) == 0) { lazy_done = true; break; }
@@ -91,7 +93,7 @@ __device__ void sw_word_pass(const IndexView &ix, const uint8_t *pac, bool aware
             vMaxMark = vMaxScore;
             int temp = vMaxScore;
             for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(temp, o, 8); temp = temp > t ? temp : t; }
-            if (temp > max) { max = temp; end_ref = i; for (int j = 0; j < segLen; ++j) s.Hmax[j][lane] = s.H[st][j][lane]; }
+            if (temp > max) { max = temp; end_ref = i; for (int j = 0; j < segLen; ++j) s.Hmax[j * 8 + lane] = s.H[st][j * 8 + lane]; }
         }
         int mc = vMaxColumn;
         for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(mc, o, 8); mc = mc > t ? mc : t; }
@@ -100,7 +102,7 @@ __device__ void sw_word_pass(const IndexView &ix, const uint8_t *pac, bool aware
     }
     // smallest read position holding the maximum in the best column (ssw.c:504-512)
     int end_read = readLen - 1;
-    for (int j = 0; j < segLen; ++j) if ((int)s.Hmax[j][lane] == max) { int t = j + lane * segLen; if (t < end_read) end_read = t; }
+    for (int j = 0; j < segLen; ++j) if ((int)s.Hmax[j * 8 + lane] == max) { int t = j + lane * segLen; if (t < end_read) end_read = t; }
     for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(end_read, o, 8); end_read = end_read < t ? end_read : t; }
     out_max = max; out_end_ref = end_ref; out_end_read = end_read;
 }
@@ -183,11 +185,16 @@ __device__ int sw_banded(const IndexView &ix, const uint8_t *pac, bool aware, ui
 __global__ void __launch_bounds__(64)
 k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
      const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
-     uint8_t *__restrict__ scratch)
+     uint8_t *__restrict__ scratch, uint32_t seg)
 {
-    __shared__ SwLds lds[8];
+    extern __shared__ __attribute__((aligned(16))) uint8_t sw_lds[];
     const uint32_t grp = threadIdx.x >> 3, lane = threadIdx.x & 7u;
-    SwLds &s = lds[grp];
+    SwLds s;
+    {
+        uint8_t *base = sw_lds + (size_t)grp * sw_group_bytes(seg);
+        s.H[0] = reinterpret_cast<short *>(base); s.H[1] = s.H[0] + seg * 8; s.E = s.H[1] + seg * 8; s.Hmax = s.E + seg * 8;
+        s.read = reinterpret_cast<uint8_t *>(s.Hmax + seg * 8);
+    }
     const uint32_t n_req = pctl[0];
     uint8_t *my = scratch + ((size_t)blockIdx.x * 8 + grp) * SW_SCRATCH_BYTES;
     uint16_t *maxColumn = reinterpret_cast<uint16_t *>(my);
@@ -204,7 +211,7 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
         const uint32_t off = offs[rq.mate], L = offs[rq.mate + 1] - off;
         const int refLen = (int)(rq.end - rq.start + 1);
         const bool aware = rq.aware != 0;
-        const bool fits = rq.start < ix.ref_len && refLen > 0 && (uint32_t)refLen * 2u <= SW_MAXCOL_BYTES && L <= SW_MAX_SEG * 8u;
+        const bool fits = rq.start < ix.ref_len && refLen > 0 && (uint32_t)refLen * 2u <= SW_MAXCOL_BYTES && L <= seg * 8u;
         if (fits) {
             // the mate's bases on the requested strand
             for (uint32_t i = lane; i < L; i += 8) {
@@ -328,10 +335,20 @@ void launch_pair(uint32_t n_pairs, uint32_t min_tlen, uint32_t max_tlen, uint32_
     if (n_pairs) hipLaunchKernelGGL(k_pair, dim3((n_pairs + 255) / 256), dim3(256), 0, st, n_pairs, min_tlen, max_tlen, l_pac, offs, res, pairs, req, pctl);
 }
 
-void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, const uint32_t *offs, const PeSwReq *req, const uint32_t *pctl,
-               PeSwRes *res, uint32_t *head, uint8_t *scratch, uint32_t n_blocks, hipStream_t st)
+// Blocks per CU are bounded by the dynamic LDS (8 groups x sw_group_bytes), i.e. by the longest read of the batch:
+// 150-bp mates fit 8 blocks per CU where 512-bp reads fit 4.
+uint32_t sw_lds_bytes(uint32_t max_len) { const uint32_t seg = (max_len + 7) / 8; return 8u * (4u * seg * 16u + ((8u * seg + 15u) & ~15u)); }
+uint32_t sw_blocks_per_cu(uint32_t max_len)
 {
-    hipLaunchKernelGGL(k_sw, dim3(n_blocks), dim3(64), 0, st, ix, pac, seqs, offs, req, pctl, res, head, scratch);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sw, 64, sw_lds_bytes(max_len)) != hipSuccess || n < 1) n = 1;
+    return (uint32_t)(n > (int)SW_MAX_BLOCKS_PER_CU ? (int)SW_MAX_BLOCKS_PER_CU : n);
+}
+void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, const uint32_t *offs, const PeSwReq *req, const uint32_t *pctl,
+               PeSwRes *res, uint32_t *head, uint8_t *scratch, uint32_t n_blocks, uint32_t max_len, hipStream_t st)
+{
+    const uint32_t seg = (max_len + 7) / 8;
+    hipLaunchKernelGGL(k_sw, dim3(n_blocks), dim3(64), sw_lds_bytes(max_len), st, ix, pac, seqs, offs, req, pctl, res, head, scratch, seg);
 }
 
 } // namespace salt
