@@ -785,6 +785,80 @@ __device__ __attribute__((noinline)) uint32_t lv_lanes(LaneLv &s, const uint32_t
     return result;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The reference's candidate loop (code_kmismatch alnse.c:348-369 / code_kdiff alnse.c:371-393) walks the SORTED,
+// duplicate-free list: a candidate with distance v counts iff v <= the running bound, the bound drops to the smallest
+// distance seen, the first such candidate and every strictly better one become the best, and the first NHIT that
+// count are kept as hits.  Equivalently, with P = {candidates with v <= bound_in, inside the reference}:
+//   a candidate counts        iff  no member of P at a smaller position has a smaller distance,
+//   best                      =    the smallest position among the members of P with the minimal distance,
+//   hits                      =    the NHIT smallest distinct positions that count, a0 = the distance of the first.
+// None of this needs the list sorted or free of duplicates (equal positions have equal distances), so the kernels run it
+// on the located rows as they come: per distance t the smallest position minpos[t] over P (one wave reduction each), then
+// "counts" is  pos < min(minpos[0..v-1]),  and the hits are extracted by repeated minimum.
+// pos / val: n entries in LDS or global memory; val > VMAX = no candidate.  GAPF: alnse_check_withgap's range filter.
+// ---------------------------------------------------------------------------------------------
+template <int VMAX, bool GAPF>
+__device__ __forceinline__ void rule_unsorted(const uint32_t *pos, const uint8_t *val, const uint32_t n, const uint32_t L, const uint32_t ref_len,
+                                              uint32_t &bound, bool &any, uint32_t &best_pos, uint32_t &best_v,
+                                              uint32_t &n_hits, uint32_t &a0, uint32_t *hit_pos, uint8_t *hit_nd)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t NONE = 0xFFFFFFFFu;
+    auto in_range = [&](uint32_t p) -> bool { return GAPF ? !(p + L + 4 >= ref_len) : p < ref_len; };
+    uint32_t mp[VMAX + 1];
+#pragma unroll
+    for (int t = 0; t <= VMAX; ++t) mp[t] = NONE;
+    for (uint32_t b = 0; b < n; b += 64) {
+        const uint32_t i = b + lane;
+        if (i < n) {
+            const uint32_t p = pos[i], v = val[i];
+            if (v <= bound && in_range(p)) {
+#pragma unroll
+                for (int t = 0; t <= VMAX; ++t) if (v == (uint32_t)t && p < mp[t]) mp[t] = p;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t <= VMAX; ++t)
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)mp[t], o); mp[t] = x < mp[t] ? x : mp[t]; }
+    // before[t] = smallest position of P with a distance below t
+    uint32_t before[VMAX + 1];
+    before[0] = NONE;
+#pragma unroll
+    for (int t = 1; t <= VMAX; ++t) before[t] = mp[t - 1] < before[t - 1] ? mp[t - 1] : before[t - 1];
+    any = false; n_hits = 0;
+#pragma unroll
+    for (int t = VMAX; t >= 0; --t) if (mp[t] != NONE) { any = true; best_v = (uint32_t)t; best_pos = mp[t]; }
+    if (!any) return;
+    unsigned long long last = 0;
+    for (uint32_t h = 0; h < (uint32_t)NHIT; ++h) {
+        unsigned long long cur = ~0ull;
+        for (uint32_t b = 0; b < n; b += 64) {
+            const uint32_t i = b + lane;
+            if (i < n) {
+                const uint32_t p = pos[i], v = val[i];
+                if (v <= bound && in_range(p)) {
+                    uint32_t lim = NONE;
+#pragma unroll
+                    for (int t = 1; t <= VMAX; ++t) if (v == (uint32_t)t) lim = before[t];
+                    const unsigned long long key = ((unsigned long long)p << 8) | v;
+                    if (p < lim && (h == 0 || key > last) && key < cur) cur = key;
+                }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long x = ((unsigned long long)(uint32_t)__shfl_xor((int)(cur >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)cur, o);
+            cur = x < cur ? x : cur;
+        }
+        if (cur == ~0ull) break;
+        if (lane == 0) { hit_pos[h] = (uint32_t)(cur >> 8); hit_nd[h] = (uint8_t)(cur & 255u); }
+        if (h == 0) a0 = (uint32_t)(cur & 255u);
+        last = cur; ++n_hits;
+    }
+    bound = best_v < bound ? best_v : bound;
+}
+
 // unpack text masks / one-hot pattern for LV (editdistance.c:183-227)
 __device__ void lv_unpack(const uint32_t *ref_generic, WaveLds &w, int strand, uint32_t L, uint32_t pos)
 {
@@ -953,52 +1027,16 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             WSYNC();
         };
         verify_all(n_loc);
-        uint32_t n_pass = 0;
-        for (uint32_t b = 0; b < n_loc; b += 64) {
-            const uint32_t i = b + lane;
-            const uint32_t pos = i < n_loc ? loci[i] : 0u;
-            const bool keep = i < n_loc && cand_e[i] <= 3 && pos < ix.ref_len;
-            const uint64_t m = __ballot(keep);
-            WSYNC();
-            if (keep) loci[n_pass + (uint32_t)__popcll(m & lt)] = pos;
-            n_pass += (uint32_t)__popcll(m);
-            WSYNC();
-        }
         pc.stamp(SALT_CTR_T_VERIFY);
-        sort_loci(loci, n_pass);
-        WSYNC();
-        const uint32_t n_cand = dedup_loci(loci, n_pass, false, L, ix.ref_len);
-        pc.stamp(SALT_CTR_T_SORT);
-        verify_all(n_cand);                                   // the same distances again, now in list order
-        pc.stamp(SALT_CTR_T_VERIFY);
-        // phase B: the sequential rule, replayed by ballots over 64 candidates at a time
-        for (uint32_t b = 0; b < n_cand; b += 64) {
-            uint32_t i = b + lane, v = INF, pos = 0;
-            if (i < n_cand) { pos = loci[i]; v = cand_e[i]; }
-            // ballots by value: m[t] = lanes with v <= t
-            uint64_t m0 = __ballot(v <= 0), m1 = __ballot(v <= 1), m2 = __ballot(v <= 2), m3 = __ballot(v <= 3);
-            // a candidate passes iff v <= bound and no earlier candidate of this chunk is smaller
-            uint64_t smaller = v == 0 ? 0ull : (v == 1 ? m0 : (v == 2 ? m1 : m2));
-            bool pass = v <= bound && (smaller & lt) == 0;
-            uint64_t pm = __ballot(pass);
-            if (pm) {
-                uint32_t vmin = m0 & pm ? 0u : (m1 & pm ? 1u : (m2 & pm ? 2u : 3u));   // smallest passing value
-                // record the first hits in order
-                uint32_t rank = n_hits_s[strand] + (uint32_t)__popcll(pm & lt);
-                if (pass && rank < NHIT) { w.hit_pos[strand][rank] = pos; w.hit_nd[strand][rank] = (uint8_t)v; w.hit_gap[strand][rank] = 0; }
-                if (n_hits_s[strand] == 0) a0[strand] = (uint32_t)__shfl((int)v, __ffsll((long long)pm) - 1);
-                uint32_t add = (uint32_t)__popcll(pm);
-                n_hits_s[strand] = n_hits_s[strand] + add > NHIT ? NHIT : n_hits_s[strand] + add;
-                if (vmin < call_best_n) {
-                    uint64_t at = __ballot(pass && v == vmin);
-                    call_best_n = vmin;
-                    call_best_pos = (uint32_t)__shfl((int)pos, __ffsll((long long)at) - 1);
-                }
-                found[strand] = true;
-                bound = vmin < bound ? vmin : bound;
+        {
+            bool any = false; uint32_t bp = 0, bv = 0, nh = 0, a0s = 0;
+            rule_unsorted<3, false>(loci, cand_e, n_loc, L, ix.ref_len, bound, any, bp, bv, nh, a0s, w.hit_pos[strand], w.hit_nd[strand]);
+            if (any) {
+                found[strand] = true; call_best_pos = bp; call_best_n = bv; n_hits_s[strand] = nh; a0[strand] = a0s;
+                if (lane < NHIT) w.hit_gap[strand][lane] = 0;
             }
-            (void)m3;
         }
+        const uint32_t n_cand = n_loc;
         c_verify += n_loc; n_cand_nogap += n_loc;
         for (uint32_t b = lane; b < n_cand; b += 64) c_vwords += ((loci[b] & 7u) + L + 7) >> 3;
         if (found[strand]) { q_pos = call_best_pos; q_ndiff = call_best_n; q_gap = 0; q_strand = (uint32_t)strand; }
