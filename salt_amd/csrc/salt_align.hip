@@ -274,7 +274,7 @@ struct SaiLists { uint32_t sp[2][SLOTS], ep[2][SLOTS], off[2][SLOTS]; };     // 
 struct LvTables { short L[LVK][64]; char A[LVK][64]; };
 // lane-parallel LV (one candidate per lane): nibble-packed text window per lane + two DP rows per lane
 static constexpr int LLV_K = 12;                 // handles k <= 12 (reads up to 129 bp at k = L/10)
-static constexpr int LLV_TW = 18;                // words per lane: up to 133 text nibbles (+1 pad word)
+static constexpr int LLV_TW = 22;                // words per lane: up to 168 text nibbles (+1 pad word): reads up to 164 bases
 static constexpr int LLV_W = 2 * LLV_K + 3;      // diagonals -k-1 .. k+1
 static constexpr int LLV_N = 32;                 // candidates per round (lanes 0..31)
 struct LaneLv { uint32_t T[LLV_N * LLV_TW]; uint8_t rows[2][LLV_W][LLV_N]; };
@@ -1010,7 +1010,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     bool found[2] = { false, false };
     uint32_t n_hits_s[2] = { 0, 0 };            // hits recorded (<= NHIT) per strand
     uint32_t a0[2] = { 0, 0 };                  // n_diff of the first hit of each list
-    uint32_t n_cand_nogap = 0;
+    uint32_t n_cand_nogap = 0, n_loc_s[2] = { 0, 0 };
     if (!too_short)
     for (int strand = 0; strand < 2; ++strand) {
         pc.stamp(SALT_CTR_T_SCAN);
@@ -1037,7 +1037,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             }
         }
         const uint32_t n_cand = n_loc;
-        c_verify += n_loc; n_cand_nogap += n_loc;
+        c_verify += n_loc; n_cand_nogap += n_loc; n_loc_s[strand] = n_loc;
         for (uint32_t b = lane; b < n_cand; b += 64) c_vwords += ((loci[b] & 7u) + L + 7) >> 3;
         if (found[strand]) { q_pos = call_best_pos; q_ndiff = call_best_n; q_gap = 0; q_strand = (uint32_t)strand; }
         WSYNC();
@@ -1049,35 +1049,55 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         int maxd = PE ? 3 : (int)(L / 10);                    // alnse.c:1090 (SE) / alnse.c:1016-1028 (PE keeps 3)
         const int gap_k0 = maxd;
         const bool lanes_fit = gap_k0 <= LLV_K && L + 4 <= 8u * (LLV_TW - 1);
-        if (!PE && lanes_fit && g.cap && n_cand_nogap > 0) {
+        if (lanes_fit && g.cap && n_cand_nogap > 0) {
+            // k_gap / k_gapfin / k_cigar take it from here: both strands' located rows go to the pool as they are (unsorted,
+            // duplicates included -- rule_unsorted needs neither).  Strand 1's rows are still in `loci`; strand 0's are located again.
             uint32_t slot = 0;
             if (lane == 0) slot = atomicAdd(&g.gctl[2], 1u);
             slot = (uint32_t)__shfl((int)slot, 0);
-            if (slot < g.cap) {                                           // k_gap / k_gapfin / k_cigar take it from here
-                uint32_t ns[2];
-                for (int strand = 0; strand < 2; ++strand) {              // the gapped pass's candidate lists, sorted and filtered
-                    const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, loci, loci_cap, ap.pe, true }, w);
-                    c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
-                    uint32_t *dst = g.gloci + ((size_t)slot * 2 + (uint32_t)strand) * MAXLOC;
-                    for (uint32_t i = lane; i < cs.n_cand; i += 64) dst[i] = loci[i];
-                    ns[strand] = cs.n_cand;
-                    WSYNC();
-                }
-                const uint32_t ch0 = (ns[0] + LLV_N - 1) / LLV_N, ch1 = (ns[1] + LLV_N - 1) / LLV_N;
-                uint32_t base = 0;
-                if (lane == 0) { base = atomicAdd(&g.gctl[5], ch0 + ch1); g.gq[slot] = r; g.gn[2 * slot] = ns[0]; g.gn[2 * slot + 1] = ns[1]; }
-                base = (uint32_t)__shfl((int)base, 0);
-                for (uint32_t c = lane; c < ch0 + ch1; c += 64) g.gitems[base + c] = (slot << 8) | (c >= ch0 ? (0x80u | (c - ch0)) : c);
-                if (ctr) {
-                    for (int o = 32; o > 0; o >>= 1) c_vwords += __shfl_down(c_vwords, o);
-                    if (lane == 0) {
-                        atomicAdd(ctr + SALT_CTR_SA_C, c_sa_c); atomicAdd(ctr + SALT_CTR_SA_R, c_sa_r);
-                        atomicAdd(ctr + SALT_CTR_VERIFY, c_verify); atomicAdd(ctr + SALT_CTR_VERIFY_WORDS, c_vwords);
-                        atomicAdd(ctr + SALT_CTR_LV, ns[0] + ns[1]); atomicAdd(ctr + SALT_CTR_READS, 1ull);
-                        atomicAdd(ctr + SALT_CTR_BASES, L); atomicAdd(ctr + SALT_CTR_LOCI, c_loci);
+            if (slot < g.cap) {
+                uint32_t ns[2], off[2];
+                bool ok = true;
+                for (int k = 0; k < 2 && ok; ++k) {
+                    const int strand = 1 - k;
+                    uint32_t n = n_loc_s[1];
+                    if (strand == 0) {
+                        WSYNC();
+                        const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, 0, true, phase, loci, loci_cap, ap.pe, false }, w);
+                        c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
+                        n = cs.n_cand;
                     }
+                    uint32_t o = 0;
+                    if (lane == 0) o = atomicAdd(&g.gctl[8], n);
+                    o = (uint32_t)__shfl((int)o, 0);
+                    ok = (uint64_t)o + n <= g.pool;
+                    if (ok) for (uint32_t i = lane; i < n; i += 64) g.gloci[o + i] = loci[i];
+                    ns[strand] = n; off[strand] = o;
                 }
-                return;
+                const uint32_t ch0 = ok ? (ns[0] + LLV_N - 1) / LLV_N : 0, ch1 = ok ? (ns[1] + LLV_N - 1) / LLV_N : 0;
+                uint32_t base = 0;
+                if (ok && lane == 0) base = atomicAdd(&g.gctl[5], ch0 + ch1);
+                base = (uint32_t)__shfl((int)base, 0);
+                ok = ok && (uint64_t)base + ch0 + ch1 <= g.items_cap;
+                if (lane == 0) {
+                    g.gq[slot] = ok ? r : 0xFFFFFFFFu;                    // an unusable slot is skipped by the later kernels
+                    g.gn[2 * slot] = ok ? ns[0] : 0; g.gn[2 * slot + 1] = ok ? ns[1] : 0;
+                    g.goff[2 * slot] = off[0]; g.goff[2 * slot + 1] = off[1];
+                }
+                if (ok) {
+                    for (uint32_t c = lane; c < ch0 + ch1; c += 64) g.gitems[base + c] = (slot << 11) | (c >= ch0 ? (0x400u | (c - ch0)) : c);
+                    if (ctr) {
+                        for (int o2 = 32; o2 > 0; o2 >>= 1) c_vwords += __shfl_down(c_vwords, o2);
+                        if (lane == 0) {
+                            atomicAdd(ctr + SALT_CTR_SA_C, c_sa_c); atomicAdd(ctr + SALT_CTR_SA_R, c_sa_r);
+                            atomicAdd(ctr + SALT_CTR_VERIFY, c_verify); atomicAdd(ctr + SALT_CTR_VERIFY_WORDS, c_vwords);
+                            atomicAdd(ctr + SALT_CTR_LV, ns[0] + ns[1]); atomicAdd(ctr + SALT_CTR_READS, 1ull);
+                            atomicAdd(ctr + SALT_CTR_BASES, L); atomicAdd(ctr + SALT_CTR_LOCI, c_loci);
+                        }
+                    }
+                    return;
+                }
+                WSYNC();                                                  // pool exhausted: finish this read here
             }
         }
         for (int strand = 0; strand < 2; ++strand) {
@@ -1209,7 +1229,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
 // Persistent kernels: one-wave blocks pull work items through counters in qctl[] until the head passes the count
 //   qctl[0] reads queued by k_light    qctl[1] k_heavy head
 //   qctl[2] gapped reads (slots)       qctl[3] k_gap head        qctl[4] k_gapfin head
-//   qctl[5] k_gap items                qctl[6] CIGAR items       qctl[7] k_cigar head
+//   qctl[5] k_gap items                qctl[6] CIGAR items       qctl[7] k_cigar head      qctl[8] pool entries used
 // ---------------------------------------------------------------------------------------------
 template <bool PE>
 __device__ __forceinline__ void heavy_body(const IndexView &ix, const AlignParams &ap, const uint32_t *__restrict__ pm,
@@ -1263,21 +1283,20 @@ k_gap(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, GapBufs g)
     __shared__ GapLds s;
     __shared__ uint32_t s_item;
     const uint32_t lane = lane_id();
-    const uint32_t cap_items = g.cap * 2u * (MAXLOC / LLV_N);
-    const uint32_t n_items = g.gctl[5] < cap_items ? g.gctl[5] : cap_items;
+    const uint32_t n_items = g.gctl[5] < g.items_cap ? g.gctl[5] : g.items_cap;
     for (;;) {
         if (threadIdx.x == 0) s_item = atomicAdd(&g.gctl[3], 1u);
         WSYNC();
         const uint32_t it = s_item;
         WSYNC();
         if (it >= n_items) break;
-        const uint32_t item = g.gitems[it], slot = item >> 8, strand = (item >> 7) & 1u, chunk = item & 127u;
+        const uint32_t item = g.gitems[it], slot = item >> 11, strand = (item >> 10) & 1u, chunk = item & 1023u;
         const uint32_t r = g.gq[slot];
         const uint32_t *rec = pm + (uint64_t)r * ap.pg.pm_stride;
         const uint32_t L = rec[2 * ap.pg.nw8], nw = (L + 7) >> 3;
         for (uint32_t t = lane; t < nw; t += 64) s.pm[t] = rec[strand * ap.pg.nw8 + t];
         const uint32_t n = g.gn[2 * slot + strand], i = chunk * LLV_N + lane;
-        const size_t row = ((size_t)slot * 2 + strand) * MAXLOC;
+        const size_t row = g.goff[2 * slot + strand];
         bool act = false;
         if (lane < LLV_N && i < n) {
             const uint32_t pos = g.gloci[row + i];
@@ -1285,7 +1304,7 @@ k_gap(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, GapBufs g)
             if (act) lane_text(ix.ref, s.llv.T + lane * LLV_TW, pos, L + 4);
         }
         WSYNC();
-        const uint32_t e = lv_lanes(s.llv, s.pm, (int)L, (int)L + 4, (int)(L / 10), act);
+        const uint32_t e = lv_lanes(s.llv, s.pm, (int)L, (int)L + 4, ap.pe ? 3 : (int)(L / 10), act);   // alnse.c:1090 / 1016-1028
         if (lane < LLV_N && i < n) g.ge[row + i] = (uint8_t)e;
         WSYNC();
     }
@@ -1312,50 +1331,19 @@ k_gapfin(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, salt_res
         if (slot >= n_items) break;
         const uint64_t rt0 = ctr ? __builtin_amdgcn_s_memrealtime() : 0;
         const uint32_t r = g.gq[slot];
+        if (r == 0xFFFFFFFFu) continue;                                   // the pool was full: k_heavy finished this read itself
         const uint32_t L = pm[(uint64_t)r * ap.pg.pm_stride + 2 * ap.pg.nw8];
         salt_result_t *out = results + r;
         uint32_t q_pos = 0xFFFFFFFFu, q_strand = 3, q_ndiff = 255, q_gap = 255;
-        uint32_t bound = L / 10;                                          // alnse.c:1090
+        uint32_t bound = ap.pe ? 3u : L / 10;                             // alnse.c:1090 (SE) / alnse.c:1016-1028 (PE keeps 3)
         uint32_t n_hits_s[2] = { 0, 0 }, a0[2] = { 0, 0 };
         for (int strand = 0; strand < 2; ++strand) {
             const uint32_t n = g.gn[2 * slot + strand];
-            const size_t row = ((size_t)slot * 2 + (uint32_t)strand) * MAXLOC;
-            uint32_t call_best_n = INF, call_best_pos = 0;
-            bool any = false;
-            for (uint32_t b = 0; b < n; b += 64) {
-                const uint32_t i = b + lane;
-                uint32_t v = INF, pos = 0;
-                if (i < n) { pos = g.gloci[row + i]; v = g.ge[row + i]; if (v > (uint32_t)LLV_K) v = INF; }
-                // m[t] = lanes with v <= t; a candidate passes iff v <= bound and no earlier candidate is smaller
-                uint64_t smaller = 0, m_prev = 0;
-                uint64_t pmask_by_t[LLV_K + 1];
-#pragma unroll
-                for (int t = 0; t <= LLV_K; ++t) {
-                    const uint64_t m = __ballot(v <= (uint32_t)t);
-                    if (v == (uint32_t)t) smaller = m_prev;
-                    m_prev = m; pmask_by_t[t] = m;
-                }
-                const bool pass = v <= bound && (smaller & lt) == 0;
-                const uint64_t pmk = __ballot(pass);
-                if (pmk) {
-                    uint32_t vmin = 0;
-#pragma unroll
-                    for (int t = LLV_K; t >= 0; --t) if (pmask_by_t[t] & pmk) vmin = (uint32_t)t;
-                    const uint32_t rank = n_hits_s[strand] + (uint32_t)__popcll(pmk & lt);
-                    if (pass && rank < NHIT) { w.hit_pos[strand][rank] = pos; w.hit_nd[strand][rank] = (uint8_t)v; }
-                    if (n_hits_s[strand] == 0) a0[strand] = (uint32_t)__shfl((int)v, __ffsll((long long)pmk) - 1);
-                    const uint32_t add = (uint32_t)__popcll(pmk);
-                    n_hits_s[strand] = n_hits_s[strand] + add > NHIT ? NHIT : n_hits_s[strand] + add;
-                    if (vmin < call_best_n) {
-                        const uint64_t at = __ballot(pass && v == vmin);
-                        call_best_n = vmin;
-                        call_best_pos = (uint32_t)__shfl((int)pos, __ffsll((long long)at) - 1);
-                    }
-                    any = true;
-                    bound = vmin < bound ? vmin : bound;
-                }
-            }
-            if (any) { q_pos = call_best_pos; q_ndiff = call_best_n; q_gap = 1; q_strand = (uint32_t)strand; }
+            const size_t row = g.goff[2 * slot + strand];
+            bool any = false; uint32_t bp = 0, bv = 0;
+            rule_unsorted<LLV_K, true>(g.gloci + row, g.ge + row, n, L, ix.ref_len, bound, any, bp, bv, n_hits_s[strand], a0[strand],
+                                       w.hit_pos[strand], w.hit_nd[strand]);
+            if (any) { q_pos = bp; q_ndiff = bv; q_gap = 1; q_strand = (uint32_t)strand; }
         }
         WSYNC();
         int b0 = (int)q_ndiff, b1 = 100000, tot = 0;
@@ -1379,6 +1367,7 @@ k_gapfin(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, salt_res
             mapq = q < 254 ? (uint32_t)q : 254u;
         }
         const uint32_t n_cig_items = q_pos != 0xFFFFFFFFu ? 1u + nh[0] + nh[1] : 0u;
+        const uint32_t first_cig = ap.pe ? 1u : 0u;                        // paired end: the alignment's own CIGAR is made after pairing (k_pe_final)
         if (lane == 0) {
             out->pos = q_pos; out->strand = (uint8_t)q_strand; out->n_diff = (uint8_t)q_ndiff; out->is_gap = (uint8_t)q_gap;
             out->mapq = (uint8_t)mapq; out->b0 = b0; out->b1 = b1; out->seq_start = 0; out->seq_end = (uint16_t)(L - 1);
@@ -1389,9 +1378,9 @@ k_gapfin(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, salt_res
                     out->hits[s][j].pos = w.hit_pos[s][h]; out->hits[s][j].n_diff = w.hit_nd[s][h];
                     out->hits[s][j].is_gap = 1; out->hits[s][j].strand = (uint16_t)s;
                 }
-            if (n_cig_items) {                                            // main hit (which = 0) and every alternative hit (1 + index)
-                const uint32_t base = atomicAdd(&g.gctl[6], n_cig_items);
-                for (uint32_t c = 0; c < n_cig_items; ++c) g.cq[base + c] = (r << 3) | c;
+            if (n_cig_items > first_cig) {                                // main hit (which = 0) and every alternative hit (1 + index)
+                const uint32_t base = atomicAdd(&g.gctl[6], n_cig_items - first_cig);
+                for (uint32_t c = first_cig; c < n_cig_items; ++c) g.cq[base + c - first_cig] = (r << 3) | c;
             }
             if (ctr) atomicMax(ctr + SALT_CTR_MAX_GAPFIN, ((unsigned long long)(__builtin_amdgcn_s_memrealtime() - rt0) << 32) | r);
         }
@@ -1840,13 +1829,8 @@ void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm
     if (!ap.n_reads) { if (ev3) for (int i = 0; i < 3; ++i) hipEventRecord(ev3[i], st); return; }
     uint32_t blocks = n_blocks < ap.n_reads ? n_blocks : ap.n_reads;
     LvTables *tab = static_cast<LvTables *>(lvtab);
-    if (ap.pe) {
-        GapBufs none = g; none.cap = 0;
-        hipLaunchKernelGGL(k_heavy_pe, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, none, pe_scr);
-        if (ev3) for (int i = 0; i < 3; ++i) hipEventRecord(ev3[i], st);
-        return;
-    }
-    hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr);
+    if (ap.pe) hipLaunchKernelGGL(k_heavy_pe, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr);
+    else     hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr);
     if (ev3) hipEventRecord(ev3[0], st);
     if (!g.cap) { if (ev3) { hipEventRecord(ev3[1], st); hipEventRecord(ev3[2], st); } return; }
     // the deferred gapped passes: distances by (read, strand, 32 candidates), one finishing wave per read, one traceback per wave
@@ -1861,11 +1845,14 @@ GapBufs gap_bufs_layout(uint8_t *base, uint32_t cap, uint32_t *gctl, size_t *byt
 {
     GapBufs g; size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off = (off + n + 255) & ~(size_t)255; return base ? base + o : nullptr; };
+    g.pool = cap * 2u * (uint32_t)MAXLOC;                                   // an SE read needs at most 2 x 1000 entries; PE mates share the pool
+    g.items_cap = g.pool / LLV_N + 2u * cap;
     g.gq = reinterpret_cast<uint32_t *>(take((size_t)cap * 4));
     g.gn = reinterpret_cast<uint32_t *>(take((size_t)cap * 2 * 4));
-    g.gloci = reinterpret_cast<uint32_t *>(take((size_t)cap * 2 * MAXLOC * 4));
-    g.ge = take((size_t)cap * 2 * MAXLOC);
-    g.gitems = reinterpret_cast<uint32_t *>(take((size_t)cap * 2 * (MAXLOC / LLV_N) * 4));
+    g.goff = reinterpret_cast<uint32_t *>(take((size_t)cap * 2 * 4));
+    g.gloci = reinterpret_cast<uint32_t *>(take((size_t)g.pool * 4));
+    g.ge = take((size_t)g.pool);
+    g.gitems = reinterpret_cast<uint32_t *>(take((size_t)g.items_cap * 4));
     g.cq = reinterpret_cast<uint32_t *>(take((size_t)cap * (1 + SALT_MAX_HITS) * 4));
     g.gctl = gctl; g.cap = cap;
     if (bytes) *bytes = off;

@@ -228,8 +228,8 @@ extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint
     CHKW(hipMalloc((void **)&ws->d_results, (uint64_t)max_reads * sizeof(salt_result_t)));
     CHKW(hipMemset(ws->d_results, 0, (uint64_t)max_reads * sizeof(salt_result_t)));
     CHKW(hipMalloc((void **)&ws->d_queue, (uint64_t)max_reads * 4));
-    CHKW(hipMalloc((void **)&ws->d_qctl, 8 * 4));
-    ws->gcap = max_reads < 8192 ? max_reads : 8192;
+    CHKW(hipMalloc((void **)&ws->d_qctl, 16 * 4));
+    ws->gcap = max_reads < 65536 ? max_reads : 65536;                   // slots for reads whose gapped pass is deferred (8 KB + 2 KB of pool each)
     if (const char *e3 = getenv("SALT_GPU_NO_GAP_DEFER")) if (atoi(e3)) ws->gcap = 0;
     if (ws->gcap) {
         size_t gbytes = 0;
@@ -324,7 +324,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     unsigned long long *ctr = o->collect_counters ? ws->d_ctr : nullptr;
     const bool timed = ws->timing && ws->n_timed < MAX_TIMED;
     hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * 8] : nullptr;
-    HIPCHK(hipMemsetAsync(ws->d_qctl, 0, 32, st));
+    HIPCHK(hipMemsetAsync(ws->d_qctl, 0, 64, st));
     if (timed) HIPCHK(hipEventRecord(ev[0], st));
     launch_pack(pg, n_reads, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_pm, ws->d_tb, st);
     if (timed) HIPCHK(hipEventRecord(ev[1], st));

@@ -52,14 +52,15 @@ void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm
                   const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, unsigned long long *ctr, hipStream_t st);
 // Deferred gapped passes (k_heavy -> k_gap -> k_gapfin -> k_cigar), `cap` slots; gctl = the workspace's qctl[8]
 struct GapBufs {
-    uint32_t *gq;        // [cap] read index of the slot
-    uint32_t *gn;        // [cap][2] candidates per strand
-    uint32_t *gloci;     // [cap][2][1024] candidate lists of the gapped pass
-    uint8_t  *ge;        // [cap][2][1024] Landau-Vishkin distances (255 = more than L/10)
-    uint32_t *gitems;    // k_gap items: (slot << 8) | (strand << 7) | chunk of 32 candidates
-    uint32_t *cq;        // k_cigar items: (slot << 3) | which (0 = the alignment, 1 + i = alternative hit i)
+    uint32_t *gq;        // [cap] read index of the slot (0xFFFFFFFF: not used after all)
+    uint32_t *gn;        // [cap][2] located rows per strand
+    uint32_t *goff;      // [cap][2] where they start in the pool
+    uint32_t *gloci;     // [pool] located positions, unsorted, duplicates included
+    uint8_t  *ge;        // [pool] their Landau-Vishkin distances (255 = none within the bound)
+    uint32_t *gitems;    // k_gap items: (slot << 11) | (strand << 10) | chunk of 32 candidates
+    uint32_t *cq;        // k_cigar items: (read << 3) | which (0 = the alignment, 1 + i = alternative hit i)
     uint32_t *gctl;
-    uint32_t cap;
+    uint32_t cap, pool, items_cap;
 };
 GapBufs gap_bufs_layout(uint8_t *base, uint32_t cap, uint32_t *gctl, size_t *bytes);   // base = nullptr: size only
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint4 *sai_c,
