@@ -859,6 +859,66 @@ __device__ __forceinline__ void rule_unsorted(const uint32_t *pos, const uint8_t
     bound = best_v < bound ? best_v : bound;
 }
 
+// rule_unsorted for short lists with few candidates inside the bound (k_light): the reductions walk the set bits of a
+// ballot with v_readlane, i.e. they cost scalar instructions per candidate instead of six cross-lane steps per value.
+template <int VMAX, bool GAPF>
+__device__ __forceinline__ void rule_sparse(const uint32_t *pos, const uint8_t *val, const uint32_t n, const uint32_t L, const uint32_t ref_len,
+                                            uint32_t &bound, bool &any, uint32_t &best_pos, uint32_t &best_v,
+                                            uint32_t &n_hits, uint32_t &a0, uint32_t *hit_pos, uint8_t *hit_nd)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t NONE = 0xFFFFFFFFu;
+    auto in_range = [&](uint32_t p) -> bool { return GAPF ? !(p + L + 4 >= ref_len) : p < ref_len; };
+    uint32_t mp[VMAX + 1];
+#pragma unroll
+    for (int t = 0; t <= VMAX; ++t) mp[t] = NONE;
+    any = false; n_hits = 0;
+    for (uint32_t b = 0; b < n; b += 64) {
+        const uint32_t i = b + lane;
+        uint32_t p = 0, v = NONE;
+        if (i < n) { p = pos[i]; v = val[i]; }
+        uint64_t m = __ballot(v <= bound && in_range(p));
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)p, l), vl = (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+#pragma unroll
+            for (int t = 0; t <= VMAX; ++t) if (vl == (uint32_t)t && pl < mp[t]) mp[t] = pl;
+            m &= m - 1;
+        }
+    }
+    uint32_t before[VMAX + 1];
+    before[0] = NONE;
+#pragma unroll
+    for (int t = 1; t <= VMAX; ++t) before[t] = mp[t - 1] < before[t - 1] ? mp[t - 1] : before[t - 1];
+#pragma unroll
+    for (int t = VMAX; t >= 0; --t) if (mp[t] != NONE) { any = true; best_v = (uint32_t)t; best_pos = mp[t]; }
+    if (!any) return;
+    uint32_t last_p = 0;
+    for (uint32_t h = 0; h < (uint32_t)NHIT; ++h) {
+        uint32_t cur_p = NONE, cur_v = 0;
+        for (uint32_t b = 0; b < n; b += 64) {
+            const uint32_t i = b + lane;
+            uint32_t p = 0, v = NONE;
+            if (i < n) { p = pos[i]; v = val[i]; }
+            uint32_t lim = NONE;
+#pragma unroll
+            for (int t = 1; t <= VMAX; ++t) if (v == (uint32_t)t) lim = before[t];
+            uint64_t m = __ballot(v <= bound && in_range(p) && p < lim && (h == 0 || p > last_p));
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)p, l);
+                if (pl < cur_p) { cur_p = pl; cur_v = (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+                m &= m - 1;
+            }
+        }
+        if (cur_p == NONE) break;
+        if (lane == 0) { hit_pos[h] = cur_p; hit_nd[h] = (uint8_t)cur_v; }
+        if (h == 0) a0 = cur_v;
+        last_p = cur_p; ++n_hits;
+    }
+    bound = best_v < bound ? best_v : bound;
+}
+
 // unpack text masks / one-hot pattern for LV (editdistance.c:183-227)
 __device__ void lv_unpack(const uint32_t *ref_generic, WaveLds &w, int strand, uint32_t L, uint32_t pos)
 {
@@ -1445,10 +1505,9 @@ struct LightLds {
     uint32_t sp[4][LT_SLOTS], off[4][LT_SLOTS];
     uint32_t pre[4][LT_SLOTS + 1];       // rows enumerated before slot i of list l
     uint32_t loci[2][LT_LOCI];
-    uint32_t tmp[2][LT_LOCI];
     uint32_t hit_pos[2][NHIT];
     uint8_t  hit_nd[2][NHIT];
-    uint8_t  val[2][64];
+    uint8_t  val[2][LT_LOCI];
 };
 
 static constexpr int LT_WAVES = 1;       // independent reads (waves) per block: 4x fewer workgroups to dispatch
@@ -1534,86 +1593,35 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
             stamp(SALT_CTR_LT_LOCATE);
             if (ap.dbg_stop == 2) { const uint32_t x = pos4[0] + pos4[1] + pos4[2] + pos4[3]; if (__ballot(x == 12345u) == 1) results[r].pos = x; return; }
             uint32_t n_s[2];
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < 2; ++s) {                                   // both lists of a strand, as located (no order, duplicates stay)
                 const uint64_t mc = __ballot(keep4[2 * s]), mr = __ballot(keep4[2 * s + 1]);
                 const uint32_t nc = (uint32_t)__popcll(mc);
-                if (keep4[2 * s]) w.tmp[s][(uint32_t)__popcll(mc & lt)] = pos4[2 * s];
-                if (keep4[2 * s + 1]) w.tmp[s][nc + (uint32_t)__popcll(mr & lt)] = pos4[2 * s + 1];
+                if (keep4[2 * s]) w.loci[s][(uint32_t)__popcll(mc & lt)] = pos4[2 * s];
+                if (keep4[2 * s + 1]) w.loci[s][nc + (uint32_t)__popcll(mr & lt)] = pos4[2 * s + 1];
                 n_s[s] = nc + (uint32_t)__popcll(mr);
                 c_sa_c += tot[2 * s]; c_sa_r += tot[2 * s + 1]; c_loci += n_s[s];
             }
             WSYNC();
-            // ---- sort (rank sort), dedup, range filter (alnse.c:726-729, 758-762) ----
-            uint32_t n_c[2];
-            for (int s = 0; s < 2; ++s) {
-                const uint32_t n = n_s[s];
-                uint32_t x0 = 0, x1 = 0, r0 = 0, r1 = 0;
-                const uint32_t i0 = lane, i1 = lane + 64;
-                if (i0 < n) x0 = w.tmp[s][i0];
-                if (i1 < n) x1 = w.tmp[s][i1];
-                for (uint32_t j = 0; j < n; ++j) {
-                    const uint32_t y = w.tmp[s][j];
-                    r0 += (y < x0) || (y == x0 && j < i0);
-                    r1 += (y < x1) || (y == x1 && j < i1);
-                }
-                if (i0 < n) w.loci[s][r0] = x0;
-                if (i1 < n) w.loci[s][r1] = x1;
-                WSYNC();
-                bool k0 = false, k1 = false;
-                if (i0 < n) k0 = !(i0 > 0 && w.loci[s][i0 - 1] == w.loci[s][i0]) && w.loci[s][i0] < ix.ref_len;
-                if (i1 < n) k1 = !(w.loci[s][i1 - 1] == w.loci[s][i1]) && w.loci[s][i1] < ix.ref_len;
-                const uint32_t v0 = i0 < n ? w.loci[s][i0] : 0, v1 = i1 < n ? w.loci[s][i1] : 0;
-                const uint64_t m0 = __ballot(k0), m1 = __ballot(k1);
-                WSYNC();
-                const uint32_t c0 = (uint32_t)__popcll(m0);
-                if (k0) w.loci[s][(uint32_t)__popcll(m0 & lt)] = v0;
-                if (k1) w.loci[s][c0 + (uint32_t)__popcll(m1 & lt)] = v1;
-                n_c[s] = c0 + (uint32_t)__popcll(m1);
-            }
-            WSYNC();
             stamp(SALT_CTR_LT_SORT);
-            if (ap.dbg_stop == 3) { if (lane == 0) results[r].pos = w.loci[0][0] + w.loci[1][0] + n_c[0] + n_c[1]; return; }
-            // ---- round trip 3: masked Hamming distance of every candidate of both strands ----
-            if (n_c[0] > 64 || n_c[1] > 64) heavy = true;                   // rare: leave multi-chunk scans to k_heavy
+            if (ap.dbg_stop == 3) { if (lane == 0) results[r].pos = w.loci[0][0] + w.loci[1][0] + n_s[0] + n_s[1]; return; }
+            // ---- round trip 3: masked Hamming distance of every located row of both strands ----
             uint32_t bound = 3, q_pos = 0xFFFFFFFFu, q_strand = 3, q_ndiff = 255;
             uint32_t n_hits_s[2] = { 0, 0 }, a0[2] = { 0, 0 };
             bool found[2] = { false, false };
-            if (!heavy) {
-                uint32_t v2[2];
-                const uint32_t *const pm2[2] = { w.pm[0], w.pm[1] };
-                const bool a2[2] = { lane < n_c[0], lane < n_c[1] };
-                const uint32_t p2[2] = { a2[0] ? w.loci[0][lane] : 0u, a2[1] ? w.loci[1][lane] : 0u };
-                if (L <= 120) {
-                    verify_quads_2(ix.ref, w.pm[0], w.pm[1], L, w.loci[0], n_c[0], w.loci[1], n_c[1], w.val[0], w.val[1]);
-                    WSYNC();
-                    v2[0] = a2[0] ? w.val[0][lane] : INF; v2[1] = a2[1] ? w.val[1][lane] : INF;
-                } else mismatch_batch<20, 2>(ix, pm2, L, p2, a2, v2);
+            {
+                if (L <= 120) verify_quads_2(ix.ref, w.pm[0], w.pm[1], L, w.loci[0], n_s[0], w.loci[1], n_s[1], w.val[0], w.val[1]);
+                else
+                    for (int s = 0; s < 2; ++s)
+                        for (uint32_t i = lane; i < n_s[s]; i += 64) w.val[s][i] = (uint8_t)mismatch_capped(ix, w.pm[s], L, w.loci[s][i]);
+                WSYNC();
                 stamp(SALT_CTR_LT_VERIFY);
-                if (ap.dbg_stop == 4) { if (__ballot(v2[0] + v2[1] == 12345u) == 1) results[r].pos = v2[0]; return; }
-                c_verify += n_c[0] + n_c[1];
-                if (a2[0]) c_vwords += ((p2[0] & 7u) + L + 7) >> 3;
-                if (a2[1]) c_vwords += ((p2[1] & 7u) + L + 7) >> 3;
-                // ---- the sequential best/first-hit rule, replayed by ballots (alnse.c:348-369, 1079-1083) ----
-#pragma unroll
+                if (ap.dbg_stop == 4) { if (__ballot(w.val[0][0] + w.val[1][0] == 12345u) == 1) results[r].pos = w.val[0][0]; return; }
+                c_verify += n_s[0] + n_s[1];
+                // ---- the sequential best/first-hit rule (alnse.c:348-369, 1079-1083) on the unsorted rows: rule_unsorted ----
                 for (int s = 0; s < 2; ++s) {
-                    const uint32_t vv = v2[s], pp = p2[s];
-                    const uint64_t m0 = __ballot(vv <= 0), m1 = __ballot(vv <= 1), m2 = __ballot(vv <= 2);
-                    const uint64_t smaller = vv == 0 ? 0ull : (vv == 1 ? m0 : (vv == 2 ? m1 : m2));
-                    const bool pass = vv <= bound && (smaller & lt) == 0;
-                    const uint64_t pm = __ballot(pass);
-                    if (pm) {
-                        const uint32_t vmin = m0 & pm ? 0u : (m1 & pm ? 1u : (m2 & pm ? 2u : 3u));
-                        const uint32_t rank = (uint32_t)__popcll(pm & lt);
-                        if (pass && rank < NHIT) { w.hit_pos[s][rank] = pp; w.hit_nd[s][rank] = (uint8_t)vv; }
-                        a0[s] = (uint32_t)__shfl((int)vv, __ffsll((long long)pm) - 1);
-                        const uint32_t add = (uint32_t)__popcll(pm);
-                        n_hits_s[s] = add > NHIT ? NHIT : add;
-                        const uint64_t at = __ballot(pass && vv == vmin);
-                        q_pos = (uint32_t)__shfl((int)pp, __ffsll((long long)at) - 1);
-                        q_ndiff = vmin; q_strand = (uint32_t)s;
-                        found[s] = true;
-                        bound = vmin < bound ? vmin : bound;
-                    }
+                    bool any = false; uint32_t bp = 0, bv = 0;
+                    rule_sparse<3, false>(w.loci[s], w.val[s], n_s[s], L, ix.ref_len, bound, any, bp, bv, n_hits_s[s], a0[s], w.hit_pos[s], w.hit_nd[s]);
+                    if (any) { found[s] = true; q_pos = bp; q_ndiff = bv; q_strand = (uint32_t)s; }
                 }
             }
             if (!heavy && !found[0] && !found[1]) heavy = true;             // needs the gapped pass
