@@ -873,6 +873,23 @@ __device__ __forceinline__ void rule_sparse(const uint32_t *pos, const uint8_t *
 #pragma unroll
     for (int t = 0; t <= VMAX; ++t) mp[t] = NONE;
     any = false; n_hits = 0;
+    if (n == 0) return;
+    if (n <= 64) {                                            // the usual case: every candidate inside the bound is the same locus
+        uint32_t p = 0, v = NONE;
+        if (lane < n) { p = pos[lane]; v = val[lane]; }
+        const bool ok = v <= bound && in_range(p);
+        const uint64_t m = __ballot(ok);
+        if (m == 0) return;
+        const int l0 = __ffsll((long long)m) - 1;
+        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)p, l0);
+        if (__ballot(ok && p != p0) == 0) {
+            const uint32_t v0 = (uint32_t)__builtin_amdgcn_readlane((int)v, l0);
+            any = true; best_pos = p0; best_v = v0; n_hits = 1; a0 = v0;
+            if (lane == 0) { hit_pos[0] = p0; hit_nd[0] = (uint8_t)v0; }
+            bound = v0 < bound ? v0 : bound;
+            return;
+        }
+    }
     for (uint32_t b = 0; b < n; b += 64) {
         const uint32_t i = b + lane;
         uint32_t p = 0, v = NONE;
@@ -1624,6 +1641,7 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
                     if (any) { found[s] = true; q_pos = bp; q_ndiff = bv; q_strand = (uint32_t)s; }
                 }
             }
+            if (ap.dbg_stop == 5) { if (lane == 0) results[r].pos = q_pos + n_hits_s[0] + n_hits_s[1] + a0[0] + a0[1]; return; }
             if (!heavy && !found[0] && !found[1]) heavy = true;             // needs the gapped pass
             if (heavy) { }
             else {
