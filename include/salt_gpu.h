@@ -166,6 +166,14 @@ int  salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[SALT_N_KERNELS], uint32_
  * *n = how many; ids[0..min(*n,cap)) = their indices in the batch, in queue order. */
 int  salt_gpu_ws_heavy_reads(salt_gpu_ws_t *ws, uint32_t *ids, uint32_t cap, uint32_t *n);
 
+/* Unit entry of the candidate rule the kernels evaluate on UNSORTED lists: case i has candidates
+ * pos/val[offs[i]..offs[i+1]) (val > vmax = no candidate) and the incoming bound bound_in[i].  mode 0: gap-free rule
+ * (code_kmismatch, alnse.c:348-369; distances 0..3, range filter pos < ref_len) by rule_unsorted; 1: the same by
+ * rule_sparse; 2: gapped rule (code_kdiff, alnse.c:371-393; distances 0..12, filter !(pos + L + 4 >= ref_len)).
+ * out[i][18] = found, best_pos, best_dist, n_hits, a0, bound_out, then 6 x (hit_pos, hit_dist) in position order. */
+int  salt_gpu_diag_rule(uint32_t n_cases, const uint32_t *pos, const uint8_t *val, const uint32_t *offs, const uint32_t *bound_in,
+                        uint32_t L, uint32_t ref_len, int mode, uint32_t *out);
+
 /* Work-queue counters of the LAST batch (diagnostics): [0] reads k_light handed to k_heavy, [2] reads whose gapped pass
  * was deferred, [5] k_gap items (32 candidates each), [6] k_cigar items; the odd entries are the consumers' heads. */
 int  salt_gpu_ws_queue_counts(salt_gpu_ws_t *ws, uint32_t out[8]);

@@ -1771,6 +1771,39 @@ void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_diag_rule: unit access to rule_unsorted / rule_sparse (tests only).  One wave per case; out[case] = any, best_pos,
+// best_v, n_hits, a0, bound_out, then NHIT x (hit_pos, hit_nd)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_diag_rule(uint32_t n_cases, const uint32_t *__restrict__ pos, const uint8_t *__restrict__ val, const uint32_t *__restrict__ offs,
+            const uint32_t *__restrict__ bound_in, uint32_t L, uint32_t ref_len, int mode, uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t hit_pos[NHIT];
+    __shared__ uint8_t hit_nd[NHIT];
+    const uint32_t c = blockIdx.x, lane = lane_id();
+    if (c >= n_cases) return;
+    const uint32_t o = offs[c], n = offs[c + 1] - o;
+    uint32_t bound = bound_in[c], bp = 0, bv = 0, nh = 0, a0 = 0;
+    bool any = false;
+    if (lane < NHIT) { hit_pos[lane] = 0; hit_nd[lane] = 0; }
+    WSYNC();
+    if (mode == 0) rule_unsorted<3, false>(pos + o, val + o, n, L, ref_len, bound, any, bp, bv, nh, a0, hit_pos, hit_nd);
+    else if (mode == 1) rule_sparse<3, false>(pos + o, val + o, n, L, ref_len, bound, any, bp, bv, nh, a0, hit_pos, hit_nd);
+    else rule_unsorted<LLV_K, true>(pos + o, val + o, n, L, ref_len, bound, any, bp, bv, nh, a0, hit_pos, hit_nd);
+    WSYNC();
+    uint32_t *w = out + (size_t)c * (6 + 2 * NHIT);
+    if (lane == 0) { w[0] = any; w[1] = any ? bp : 0; w[2] = any ? bv : 0; w[3] = nh; w[4] = nh ? a0 : 0; w[5] = bound; }
+    if (lane < NHIT) { w[6 + 2 * lane] = lane < nh ? hit_pos[lane] : 0; w[7 + 2 * lane] = lane < nh ? hit_nd[lane] : 0; }
+}
+
+void launch_diag_rule(uint32_t n_cases, const uint32_t *pos, const uint8_t *val, const uint32_t *offs, const uint32_t *bound_in,
+                      uint32_t L, uint32_t ref_len, int mode, uint32_t *out, hipStream_t st)
+{
+    if (n_cases) hipLaunchKernelGGL(k_diag_rule, dim3(n_cases), dim3(64), 0, st, n_cases, pos, val, offs, bound_in, L, ref_len, mode, out);
+}
+uint32_t diag_rule_words() { return 6 + 2 * NHIT; }
+
+// ---------------------------------------------------------------------------------------------
 // k_diag_lv: unit access to the verify / LV device functions for the golden vectors (tests only)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)

@@ -523,6 +523,28 @@ extern "C" int salt_gpu_diag_ssw(uint32_t n_cases, const uint8_t *aware, const u
     return SALT_OK;
 }
 
+// Unit access to the candidate rule (rule_unsorted / rule_sparse): see include/salt_gpu.h
+extern "C" int salt_gpu_diag_rule(uint32_t n_cases, const uint32_t *pos, const uint8_t *val, const uint32_t *offs, const uint32_t *bound_in,
+                                  uint32_t L, uint32_t ref_len, int mode, uint32_t *out)
+{
+    if (!pos || !val || !offs || !bound_in || !out) return fail(SALT_E_INVAL, "null argument");
+    if (n_cases == 0) return SALT_OK;
+    const uint64_t n = offs[n_cases];
+    uint32_t *d_pos = nullptr, *d_offs = nullptr, *d_b = nullptr, *d_out = nullptr; uint8_t *d_val = nullptr;
+    const uint64_t ow = (uint64_t)n_cases * diag_rule_words();
+    HIPCHK(hipMalloc((void **)&d_pos, (n + 64) * 4)); HIPCHK(hipMemcpy(d_pos, pos, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_val, n + 64)); HIPCHK(hipMemcpy(d_val, val, n, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_offs, ((uint64_t)n_cases + 1) * 4)); HIPCHK(hipMemcpy(d_offs, offs, ((uint64_t)n_cases + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_b, (uint64_t)n_cases * 4)); HIPCHK(hipMemcpy(d_b, bound_in, (uint64_t)n_cases * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_out, ow * 4));
+    launch_diag_rule(n_cases, d_pos, d_val, d_offs, d_b, L, ref_len, mode, d_out, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, d_out, ow * 4, hipMemcpyDeviceToHost));
+    hipFree(d_pos); hipFree(d_val); hipFree(d_offs); hipFree(d_b); hipFree(d_out);
+    return SALT_OK;
+}
+
 extern "C" int salt_gpu_ws_queue_counts(salt_gpu_ws_t *ws, uint32_t out[8])
 {
     if (!ws || !out) return fail(SALT_E_INVAL, "null argument");

@@ -228,3 +228,66 @@ def test_gpu_rejects_what_it_cannot_do():
         aln.alnse_core1(salt_amd.AlnOpt(l_seed=idx.l_seed, l_overlap=1), seq[:300], np.array([0, 300], dtype=np.uint32))
     aln.close()
     idx.destroy()
+
+
+def _sequential_rule(pos, val, bound, vmax, in_range):
+    """The reference's candidate loop on the SORTED, duplicate-free list (code_kmismatch alnse.c:348-369 / code_kdiff
+    alnse.c:371-393 as alnse_check_nogap / alnse_check_withgap drive it): returns what the kernels must reproduce."""
+    seen, cand = set(), []
+    for p, v in sorted(zip(pos, val)):
+        if p in seen:
+            continue
+        seen.add(p)
+        if in_range(p):
+            cand.append((p, v))
+    found, best_pos, best_v, hits, a0 = 0, 0, 0, [], 0
+    for p, v in cand:
+        if v > vmax or v > bound:
+            continue
+        if v < bound or not found:
+            bound, best_pos, best_v = v, p, v
+        if len(hits) < 6:
+            hits.append((p, v))
+        if not found:
+            a0 = v
+        found = 1
+    return found, best_pos, best_v, hits, a0, bound
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_gpu_rule_on_unsorted_lists_equals_the_sequential_rule(mode):
+    """rule_unsorted / rule_sparse (no sort, duplicates allowed) against the sequential loop over the sorted unique list, on
+    3000 random lists: lengths 0..300, few distinct loci or many, duplicates, loci at and beyond the reference end, every
+    incoming bound."""
+    import ctypes
+    import salt_amd
+    lib = salt_amd.gpu_lib()
+    lib.salt_gpu_diag_rule.argtypes = [ctypes.c_uint32] + [ctypes.c_void_p] * 4 + [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    rng = np.random.Generator(np.random.PCG64(100 + mode))
+    L, ref_len, vmax = 100, 1000000, (3 if mode < 2 else 12)
+    in_range = (lambda p: p < ref_len) if mode < 2 else (lambda p: not ((p + L + 4) & 0xFFFFFFFF >= ref_len))
+    pos, val, offs, bounds = [], [], [0], []
+    for c in range(3000):
+        n = int(rng.choice([0, 1, 2, 5, 17, 63, 64, 65, 128, 300]))
+        n_distinct = int(rng.choice([1, 2, 3, 8, 1000]))
+        lo = ref_len - 200 if rng.random() < 0.2 else 0                   # some lists straddle the reference end
+        universe = rng.integers(lo, ref_len + 150 if lo else ref_len - 200, size=max(n_distinct, 1), dtype=np.int64)
+        p = universe[rng.integers(0, len(universe), size=n)]
+        dist_of = {int(u): int(rng.choice([0, 1, 2, 3, 4, 7, 12, 200], p=[.1, .15, .15, .15, .1, .05, .05, .25])) for u in universe}
+        v = np.array([dist_of[int(x)] for x in p], dtype=np.uint8)
+        v[v > vmax] = 255
+        pos.append(p.astype(np.uint32)); val.append(v); offs.append(offs[-1] + n)
+        bounds.append(int(rng.integers(0, vmax + 1)) if rng.random() < 0.5 else vmax)
+    pos_a = np.concatenate(pos) if offs[-1] else np.zeros(1, np.uint32)
+    val_a = np.concatenate(val) if offs[-1] else np.zeros(1, np.uint8)
+    offs_a, b_a = np.array(offs, dtype=np.uint32), np.array(bounds, dtype=np.uint32)
+    out = np.zeros((3000, 18), dtype=np.uint32)
+    rc = lib.salt_gpu_diag_rule(3000, pos_a.ctypes.data, val_a.ctypes.data, offs_a.ctypes.data, b_a.ctypes.data, L, ref_len, mode, out.ctypes.data)
+    assert rc == 0, lib.salt_gpu_last_error()
+    for c in range(3000):
+        found, bp, bv, hits, a0, bound = _sequential_rule([int(x) for x in pos[c]], [int(x) for x in val[c]], bounds[c], vmax, in_range)
+        got = [int(x) for x in out[c]]
+        want = [found, bp if found else 0, bv if found else 0, len(hits), a0 if hits else 0, bound]
+        for h in range(6):
+            want += list(hits[h]) if h < len(hits) else [0, 0]
+        assert got == want, (mode, c, got, want, pos[c][:10], val[c][:10], bounds[c])
