@@ -1870,6 +1870,20 @@ void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const 
     if (n) hipLaunchKernelGGL(k_diag_lv, dim3(n), dim3(64), 0, st, ix, n, pos, kdiff, seqs, offs, out, cig, static_cast<LvTables *>(lvtab));
 }
 
+// first 128 bytes of every result row, densely packed (what the host needs of nearly every row)
+__global__ void __launch_bounds__(256)
+k_heads(const salt_result_t *__restrict__ res, uint32_t n, uint4 *__restrict__ heads)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n * 8u) return;
+    const uint32_t i = (uint32_t)(t >> 3), c = (uint32_t)t & 7u;
+    heads[t] = reinterpret_cast<const uint4 *>(res + i)[c];
+}
+void launch_heads(const salt_result_t *res, uint32_t n, uint8_t *heads, hipStream_t st)
+{
+    if (n) hipLaunchKernelGGL(k_heads, dim3((uint32_t)(((uint64_t)n * 8u + 255) / 256)), dim3(256), 0, st, res, n, reinterpret_cast<uint4 *>(heads));
+}
+
 uint32_t heavy_blocks_per_cu()
 {
     static int cached = 0;

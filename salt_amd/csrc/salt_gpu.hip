@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <cstddef>
 #include <string>
 #include <vector>
 #include "salt_kernels.h"
@@ -34,6 +35,7 @@ struct salt_gpu_ws {
     uint8_t *d_seqs = nullptr; uint32_t *d_offs = nullptr; salt_result_t *d_results = nullptr;
     uint4 *d_sai_c = nullptr, *d_sai_r = nullptr; uint64_t sai_cap = 0;
     uint32_t *d_pm = nullptr, *d_tb = nullptr; uint64_t pm_cap = 0, tb_cap = 0;     // k_pack's records (words)
+    uint8_t *d_heads = nullptr, *h_heads = nullptr;          // first 128 bytes of every result row: dense device copy + pinned host staging
     unsigned long long *d_ctr = nullptr;
     uint32_t *d_queue = nullptr, *d_qctl = nullptr;   // reads k_light hands to k_heavy; {count, head}
     void *d_lvtab = nullptr;                          // one LV traceback table per persistent k_heavy block
@@ -258,7 +260,7 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
 {
     if (!ws) return;
     hipSetDevice(ws->ix->device);
-    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gap);
+    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_heads); if (ws->h_heads) hipHostFree(ws->h_heads); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gap);
     hipFree(ws->d_pe_scr); hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres); hipFree(ws->d_pctl); hipFree(ws->d_sw_scr); hipFree(ws->d_pcq);
     if (ws->stream) hipStreamDestroy(ws->stream);
     for (auto &e : ws->ev) if (e) hipEventDestroy(e);
@@ -309,7 +311,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     const PackGeom pg = PackGeom::make(max_read_len);
     if ((uint64_t)n_reads * pg.pm_stride > ws->pm_cap || (uint64_t)n_reads * pg.tb_stride > ws->tb_cap) {
         HIPCHK(hipStreamSynchronize(st));
-        hipFree(ws->d_pm); hipFree(ws->d_tb); ws->d_pm = ws->d_tb = nullptr; ws->pm_cap = ws->tb_cap = 0;
+        hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_heads); if (ws->h_heads) hipHostFree(ws->h_heads); ws->d_pm = ws->d_tb = nullptr; ws->pm_cap = ws->tb_cap = 0;
         const uint64_t nr = n_reads > ws->max_reads ? n_reads : ws->max_reads;
         HIPCHK(hipMalloc((void **)&ws->d_pm, nr * pg.pm_stride * 4));
         HIPCHK(hipMalloc((void **)&ws->d_tb, nr * pg.tb_stride * 4));
@@ -342,6 +344,37 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     return SALT_OK;
 }
 
+// Results to host memory without moving 880 bytes per read over PCIe: nearly every row is fully described by its first
+// 128 bytes (header, hits, hit_n_cigar, the first 8 CIGAR ops); those travel as one dense copy, the few rows with longer
+// or alternative-hit CIGARs are fetched whole.
+static const uint32_t HEAD_BYTES = 128;
+static_assert(offsetof(salt_result_t, cigar) + 8 * sizeof(uint16_t) == HEAD_BYTES, "result head");
+static int fetch_results(salt_gpu_ws_t *ws, uint32_t n_reads, salt_result_t *results, hipStream_t st)
+{
+    if (!ws->d_heads) {
+        HIPCHK(hipMalloc((void **)&ws->d_heads, (uint64_t)ws->max_reads * HEAD_BYTES));
+        HIPCHK(hipHostMalloc((void **)&ws->h_heads, (uint64_t)ws->max_reads * HEAD_BYTES, hipHostMallocDefault));
+    }
+    launch_heads(ws->d_results, n_reads, ws->d_heads, st);
+    HIPCHK(hipMemcpyAsync(ws->h_heads, ws->d_heads, (uint64_t)n_reads * HEAD_BYTES, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint32_t> full;
+    for (uint32_t i = 0; i < n_reads; ++i) {
+        memcpy(&results[i], ws->h_heads + (uint64_t)i * HEAD_BYTES, HEAD_BYTES);
+        const salt_result_t &r = results[i];
+        bool more = r.n_cigar > 8;
+        for (int h = 0; h < SALT_MAX_HITS; ++h) more |= r.hit_n_cigar[h] != 0;
+        if (more) full.push_back(i);
+    }
+    if (full.size() > 4096) {                                  // unusual batch: one plain copy is cheaper than thousands of small ones
+        HIPCHK(hipMemcpyAsync(results, ws->d_results, (uint64_t)n_reads * sizeof(salt_result_t), hipMemcpyDeviceToHost, st));
+    } else {
+        for (uint32_t i : full) HIPCHK(hipMemcpyAsync(&results[i], ws->d_results + i, sizeof(salt_result_t), hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return SALT_OK;
+}
+
 extern "C" int salt_gpu_align_se(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint32_t n_reads, const uint8_t *seqs,
                                  const uint32_t *offs, salt_result_t *results)
 {
@@ -363,9 +396,7 @@ extern "C" int salt_gpu_align_se(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uin
     HIPCHK(hipMemcpyAsync(ws->d_offs, offs, ((uint64_t)n_reads + 1) * 4, hipMemcpyHostToDevice, ws->stream));
     int rc = salt_gpu_align_se_resident(ws, o, n_reads, max_len, ws->d_seqs, ws->d_offs, ws->d_results, ws->stream);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(results, ws->d_results, (uint64_t)n_reads * sizeof(salt_result_t), hipMemcpyDeviceToHost, ws->stream));
-    HIPCHK(hipStreamSynchronize(ws->stream));
-    return SALT_OK;
+    return fetch_results(ws, n_reads, results, ws->stream);
 }
 
 extern "C" int salt_gpu_index_replicate(salt_gpu_index_t *src, const int *devices, int n, salt_gpu_index_t **out)
@@ -653,9 +684,7 @@ extern "C" int salt_gpu_align_pe(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, con
     HIPCHK(hipMemcpyAsync(ws->d_offs, offs, ((uint64_t)n_reads + 1) * 4, hipMemcpyHostToDevice, st));
     int rc = pe_resident_impl(ws, o, pe, n_pairs, max_len, ws->d_seqs, ws->d_offs, ws->d_results, st);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(results, ws->d_results, (uint64_t)n_reads * sizeof(salt_result_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    return SALT_OK;
+    return fetch_results(ws, n_reads, results, st);
 }
 
 extern "C" int salt_gpu_ws_counters(salt_gpu_ws_t *ws, uint64_t out[SALT_CTR_N])

@@ -20,6 +20,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -33,6 +34,7 @@ const int N_SEQS = 100000;
 struct Batch {
     long seq_no = 0;
     std::vector<char> raw;                    // the FASTQ text; names and qualities are NUL-terminated in place
+    std::vector<uint32_t> rec;                // offset of every record's '@' line in raw (found by the reader)
     std::vector<uint32_t> name, qual;         // offsets into raw
     std::vector<uint8_t> seqs;
     std::vector<uint32_t> offs{ 0 };
@@ -64,16 +66,18 @@ struct RawReader {
         return true;
     }
     // appends whole records to out until n_rec records or end of file; returns records appended
-    int take(std::vector<char> &out, int n_rec)
+    int take(std::vector<char> &out, int n_rec, std::vector<uint32_t> &rec)
     {
         int got = 0;
+        rec.clear();
         for (;;) {
-            size_t scan = pos; int lines = 0; size_t rec_end = pos;
+            size_t scan = pos; int lines = 0; size_t rec_end = pos, rec_start = pos;
             while (got < n_rec) {
                 const char *nl = (const char *)memchr(buf.data() + scan, '\n', have - scan);
                 if (!nl) break;
+                if (lines == 0) rec_start = scan;
                 scan = (size_t)(nl - buf.data()) + 1;
-                if (++lines == 4) { lines = 0; ++got; rec_end = scan; }
+                if (++lines == 4) { lines = 0; ++got; rec_end = scan; rec.push_back((uint32_t)(out.size() + (rec_start - pos))); }
             }
             out.insert(out.end(), buf.begin() + (long)pos, buf.begin() + (long)rec_end);
             pos = rec_end;
@@ -81,7 +85,7 @@ struct RawReader {
             if (!fill()) {                                  // end of file: a last record without trailing newline
                 if (have > pos) {
                     int nl = 0; for (size_t i = pos; i < have; ++i) nl += buf[i] == '\n';
-                    if (nl >= 3) { out.insert(out.end(), buf.begin() + (long)pos, buf.begin() + (long)have); out.push_back('\n'); ++got; }
+                    if (nl >= 3) { rec.push_back((uint32_t)out.size()); out.insert(out.end(), buf.begin() + (long)pos, buf.begin() + (long)have); out.push_back('\n'); ++got; }
                     pos = have;
                 }
                 return got;
@@ -90,16 +94,45 @@ struct RawReader {
     }
 };
 
-struct Batch;
-void parse_batch(std::vector<char> &raw, Batch &b, int n_threads);
 
-void format_batch(const salt_index_t *ix, const salt_sam_opt_t *so, Batch &b, int n_threads)
-{
-    const int n = b.n();
-    std::vector<std::string> part((size_t)n_threads);
+// Helper threads of one align worker, created once (a batch needs three parallel loops; spawning threads for each costs more
+// than the loops' bodies at 100 000 reads per batch).
+class Pool {
     std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; ++t)
-        th.emplace_back([&, t]() {
+    std::mutex mu; std::condition_variable cv_go, cv_done;
+    std::function<void(int)> fn; int n_tasks = 0, next = 0, pending = 0; long gen = 0; bool stop = false;
+    void run() {
+        long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_go.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            while (next < n_tasks) { int t = next++; lk.unlock(); fn(t); lk.lock(); if (--pending == 0) cv_done.notify_all(); }
+        }
+    }
+public:
+    const int n;
+    explicit Pool(int n_threads) : n(n_threads < 1 ? 1 : n_threads) { for (int i = 1; i < n; ++i) th.emplace_back([this] { run(); }); }
+    ~Pool() { { std::unique_lock<std::mutex> lk(mu); stop = true; } cv_go.notify_all(); for (auto &t : th) t.join(); }
+    // fn(t) for t in [0, n): the calling thread takes part
+    void parallel(const std::function<void(int)> &f) {
+        if (n == 1) { f(0); return; }
+        std::unique_lock<std::mutex> lk(mu);
+        fn = f; n_tasks = n; next = 0; pending = n; ++gen;
+        cv_go.notify_all();
+        while (next < n_tasks) { int t = next++; lk.unlock(); fn(t); lk.lock(); --pending; }
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+
+void parse_batch(std::vector<char> &raw, Batch &b, Pool &pool);
+
+void format_batch(const salt_index_t *ix, const salt_sam_opt_t *so, Batch &b, Pool &pool)
+{
+    const int n = b.n(), n_threads = pool.n;
+    std::vector<std::string> part((size_t)n_threads);
+    pool.parallel([&](int t) {
             std::vector<char> buf(1 << 16);
             int lo = (int)((long)n * t / n_threads), hi = (int)((long)n * (t + 1) / n_threads);
             std::string &out = part[(size_t)t];
@@ -112,21 +145,18 @@ void format_batch(const salt_index_t *ix, const salt_sam_opt_t *so, Batch &b, in
                 out.append(buf.data(), (size_t)w);
                 out.push_back('\n');
             }
-        });
-    for (auto &t : th) t.join();
+    });
     b.sam.clear();
     for (auto &p : part) b.sam += p;
 }
 
 // -p: both SAM records of every pair (alnpe_sam, sam.c:331-457); res holds the mates interleaved
-void format_batch_pe(const salt_index_t *ix, const salt_sam_opt_t *so, const salt_pe_opt_t *po, Batch &b, int n_threads)
+void format_batch_pe(const salt_index_t *ix, const salt_sam_opt_t *so, const salt_pe_opt_t *po, Batch &b, Pool &pool)
 {
-    const int n = b.n();
+    const int n = b.n(), n_threads = pool.n;
     const Batch &m = *b.mate;
     std::vector<std::string> part((size_t)n_threads);
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; ++t)
-        th.emplace_back([&, t]() {
+    pool.parallel([&](int t) {
             std::vector<char> buf(1 << 17);
             int lo = (int)((long)n * t / n_threads), hi = (int)((long)n * (t + 1) / n_threads);
             std::string &out = part[(size_t)t];
@@ -141,67 +171,49 @@ void format_batch_pe(const salt_index_t *ix, const salt_sam_opt_t *so, const sal
                 if (w < 0) { fprintf(stderr, "[salt] SAM record too long for pair %s\n", nm[0]); exit(1); }
                 out.append(buf.data(), (size_t)w);
             }
-        });
-    for (auto &t : th) t.join();
+    });
     b.sam.clear();
     for (auto &p : part) b.sam += p;
 }
 
-void parse_batch(std::vector<char> &raw, Batch &b, int n_threads)
+void parse_batch(std::vector<char> &raw, Batch &b, Pool &pool)
 {
-    // line starts of every record (serial scan), then per-thread parsing of record ranges
-    std::vector<size_t> rec;                                   // offset of each record's '@' line
-    {
-        size_t p = 0; int lines = 0;
-        rec.push_back(0);
-        while (p < raw.size()) {
-            const char *nl = (const char *)memchr(raw.data() + p, '\n', raw.size() - p);
-            if (!nl) break;
-            p = (size_t)(nl - raw.data()) + 1;
-            if (++lines == 4) { lines = 0; if (p < raw.size()) rec.push_back(p); }
-        }
-    }
-    const int n = (int)rec.size();
+    const std::vector<uint32_t> &rec = b.rec;                  // record starts, found by the reader
+    const int n = (int)rec.size(), n_threads = pool.n;
     b.name.assign((size_t)n, 0u); b.qual.assign((size_t)n, 0u);
     std::vector<uint32_t> len((size_t)n, 0);
     std::vector<std::pair<size_t, size_t>> seq_span((size_t)n);
     auto line_end = [&](size_t p) { const char *nl = (const char *)memchr(raw.data() + p, '\n', raw.size() - p); size_t e = nl ? (size_t)(nl - raw.data()) : raw.size(); return e; };
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; ++t)
-        th.emplace_back([&, t]() {
-            for (int i = (int)((long)n * t / n_threads); i < (int)((long)n * (t + 1) / n_threads); ++i) {
-                size_t p = rec[(size_t)i], e = line_end(p);
-                size_t ne = p + 1;
-                while (ne < e && !isspace((unsigned char)raw[ne])) ++ne;
-                size_t nl_ = ne - (p + 1);
-                if (nl_ > 2 && raw[ne - 2] == '/' && isdigit((unsigned char)raw[ne - 1])) ne -= 2;   // trim_readno (query.c:139-143)
-                b.name[(size_t)i] = (uint32_t)(p + 1);
-                const size_t name_end = ne;
-                size_t s0 = e + 1, s1 = line_end(s0);
-                size_t se = s1; while (se > s0 && raw[se - 1] == '\r') --se;
-                seq_span[(size_t)i] = { s0, se }; len[(size_t)i] = (uint32_t)(se - s0);
-                size_t p2 = s1 + 1, e2 = line_end(p2);           // '+' line
-                size_t q0 = e2 + 1, q1 = line_end(q0);
-                while (q1 > q0 && raw[q1 - 1] == '\r') --q1;
-                b.qual[(size_t)i] = (uint32_t)q0;
-                raw[name_end] = 0;                               // terminate in place (after every read of these lines)
-                if (q1 < raw.size()) raw[q1] = 0;
-            }
-        });
-    for (auto &t : th) t.join();
+    pool.parallel([&](int t) {
+        for (int i = (int)((long)n * t / n_threads); i < (int)((long)n * (t + 1) / n_threads); ++i) {
+            size_t p = rec[(size_t)i], e = line_end(p);
+            size_t ne = p + 1;
+            while (ne < e && !isspace((unsigned char)raw[ne])) ++ne;
+            size_t nl_ = ne - (p + 1);
+            if (nl_ > 2 && raw[ne - 2] == '/' && isdigit((unsigned char)raw[ne - 1])) ne -= 2;   // trim_readno (query.c:139-143)
+            b.name[(size_t)i] = (uint32_t)(p + 1);
+            const size_t name_end = ne;
+            size_t s0 = e + 1, s1 = line_end(s0);
+            size_t se = s1; while (se > s0 && raw[se - 1] == '\r') --se;
+            seq_span[(size_t)i] = { s0, se }; len[(size_t)i] = (uint32_t)(se - s0);
+            size_t p2 = s1 + 1, e2 = line_end(p2);           // '+' line
+            size_t q0 = e2 + 1, q1 = line_end(q0);
+            while (q1 > q0 && raw[q1 - 1] == '\r') --q1;
+            b.qual[(size_t)i] = (uint32_t)q0;
+            raw[name_end] = 0;                               // terminate in place (after every read of these lines)
+            if (q1 < raw.size()) raw[q1] = 0;
+        }
+    });
     b.offs.assign((size_t)n + 1, 0);
     for (int i = 0; i < n; ++i) b.offs[(size_t)i + 1] = b.offs[(size_t)i] + len[(size_t)i];
     b.seqs.resize(b.offs[(size_t)n]);
-    th.clear();
-    for (int t = 0; t < n_threads; ++t)
-        th.emplace_back([&, t]() {
-            for (int i = (int)((long)n * t / n_threads); i < (int)((long)n * (t + 1) / n_threads); ++i) {
-                uint8_t *d = b.seqs.data() + b.offs[(size_t)i];
-                const char *sp = raw.data() + seq_span[(size_t)i].first;
-                for (uint32_t j = 0; j < len[(size_t)i]; ++j) d[j] = nt4((unsigned char)sp[j]);
-            }
-        });
-    for (auto &t : th) t.join();
+    pool.parallel([&](int t) {
+        for (int i = (int)((long)n * t / n_threads); i < (int)((long)n * (t + 1) / n_threads); ++i) {
+            uint8_t *d = b.seqs.data() + b.offs[(size_t)i];
+            const char *sp = raw.data() + seq_span[(size_t)i].first;
+            for (uint32_t j = 0; j < len[(size_t)i]; ++j) d[j] = nt4((unsigned char)sp[j]);
+        }
+    });
 }
 
 double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + ts.tv_nsec * 1e-9; }
@@ -284,7 +296,8 @@ int main(int argc, char **argv)
         for (int i = 0; i < n_gpus; ++i)
             if (salt_gpu_index_set_pac(gix[(size_t)i], pac, l_pac)) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
     }
-    const int WPG = 2;                                    // workers per GPU: one batch on the device while another is parsed / formatted
+    // workers per GPU: each takes a batch through parse -> device -> format, so several batches overlap on the host
+    const int WPG = n_threads / n_gpus >= 32 ? 4 : n_threads / n_gpus >= 12 ? 3 : 2;
     std::vector<salt_gpu_ws_t *> ws((size_t)n_gpus * WPG, nullptr);
     for (int i = 0; i < n_gpus * WPG; ++i)
         if (salt_gpu_ws_create(gix[(size_t)(i / WPG)], N_SEQS, (uint64_t)N_SEQS * SALT_MAX_READ_LEN, &ws[(size_t)i])) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
@@ -331,11 +344,11 @@ int main(int argc, char **argv)
             b->seq_no = seq_no;
             b->raw.reserve((size_t)N_SEQS * 260);
             double tr0 = now();
-            const int got = rr.take(b->raw, per_batch);
+            const int got = rr.take(b->raw, per_batch, b->rec);
             if (pe && got) {
                 b->mate = std::make_unique<Batch>();
                 b->mate->raw.reserve((size_t)per_batch * 260);
-                if (rr2->take(b->mate->raw, got) != got) { fprintf(stderr, "[salt] the two read files hold different numbers of reads\n"); failed = true; }
+                if (rr2->take(b->mate->raw, got, b->mate->rec) != got) { fprintf(stderr, "[salt] the two read files hold different numbers of reads\n"); failed = true; }
             }
             if (got == 0 || failed) b.reset();
             t_read += now() - tr0;
@@ -350,6 +363,7 @@ int main(int argc, char **argv)
     const int fmt_threads = n_threads / (n_gpus * WPG) > 0 ? n_threads / (n_gpus * WPG) : 1;
     for (int g = 0; g < n_gpus * WPG; ++g)
         workers.emplace_back([&, g]() {
+            Pool pool(fmt_threads);
             for (;;) {
                 std::unique_ptr<Batch> b;
                 {
@@ -359,11 +373,11 @@ int main(int argc, char **argv)
                     b = std::move(todo.front()); todo.pop_front();
                 }
                 double tp0 = now();
-                parse_batch(b->raw, *b, fmt_threads);
+                parse_batch(b->raw, *b, pool);
                 std::vector<uint8_t> iseq; std::vector<uint32_t> ioff;
                 if (pe && b->n()) {                              // interleave the mates: pair i = reads 2i, 2i+1
                     Batch &m = *b->mate;
-                    parse_batch(m.raw, m, fmt_threads);
+                    parse_batch(m.raw, m, pool);
                     if (m.n() != b->n()) { fprintf(stderr, "[salt] the two read files hold different numbers of reads\n"); failed = true; cv.notify_all(); break; }
                     const size_t n = (size_t)b->n();
                     ioff.resize(2 * n + 1); ioff[0] = 0;
@@ -386,7 +400,7 @@ int main(int argc, char **argv)
                     failed = true; cv.notify_all(); break;
                 }
                 double tf0 = now();
-                if (pe) format_batch_pe(ix, &so, &po, *b, fmt_threads); else format_batch(ix, &so, *b, fmt_threads);
+                if (pe) format_batch_pe(ix, &so, &po, *b, pool); else format_batch(ix, &so, *b, pool);
                 t_fmt = t_fmt + (now() - tf0);
                 std::unique_lock<std::mutex> lk(mu);
                 done.push_back(std::move(b));
