@@ -10,6 +10,7 @@
 //            banded traceback (banded_sw, ssw.c:549-727) by the group's first lane.
 // The results are applied to the mates by k_pe_final (salt_align.hip), which also writes the CIGARs.
 #include "salt_device.h"
+#include <stdlib.h>
 #include "salt_kernels.h"
 
 namespace salt {
@@ -185,7 +186,7 @@ __device__ int sw_banded(const IndexView &ix, const uint8_t *pac, bool aware, ui
 __global__ void __launch_bounds__(64)
 k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
      const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
-     uint8_t *__restrict__ scratch, uint32_t seg)
+     uint8_t *__restrict__ scratch, uint32_t seg, int dbg_skip_tb)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sw_lds[];
     const uint32_t grp = threadIdx.x >> 3, lane = threadIdx.x & 7u;
@@ -245,7 +246,8 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
             if (lane == 0) {
                 const int rfl = end_ref1 - beg_ref + 1, rdl = end_read1 - read_begin + 1;
                 int bw = rfl - rdl; bw = (bw < 0 ? -bw : bw) + 1;
-                if (rfl > 0 && rdl > 0)
+                if (dbg_skip_tb) { out.cigar[0] = (uint16_t)(rdl << 4); n_cig = 1; }
+                else if (rfl > 0 && rdl > 0)
                     n_cig = sw_banded(ix, pac, aware, rq.start + (uint32_t)beg_ref, s.read + read_begin, rfl, rdl, max1, bw, hb, eb, hc, direction,
                                       dir_cap, out.cigar, SALT_MAX_CIGAR_OPS);
             }
@@ -348,7 +350,7 @@ void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, con
                PeSwRes *res, uint32_t *head, uint8_t *scratch, uint32_t n_blocks, uint32_t max_len, hipStream_t st)
 {
     const uint32_t seg = (max_len + 7) / 8;
-    hipLaunchKernelGGL(k_sw, dim3(n_blocks), dim3(64), sw_lds_bytes(max_len), st, ix, pac, seqs, offs, req, pctl, res, head, scratch, seg);
+    hipLaunchKernelGGL(k_sw, dim3(n_blocks), dim3(64), sw_lds_bytes(max_len), st, ix, pac, seqs, offs, req, pctl, res, head, scratch, seg, (getenv("SALT_GPU_SW_SKIP_TB") && atoi(getenv("SALT_GPU_SW_SKIP_TB"))) ? 1 : 0);
 }
 
 } // namespace salt
