@@ -1573,6 +1573,8 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
             }
             return;
         }
+        uint32_t tot[4] = { 0, 0, 0, 0 };
+        bool small = false;
         {
             // lane = (list, slot); list: 0 C/fwd 1 R/fwd 2 C/rev 3 R/rev.  The reference orders each list by
             // interval size (alnse.c:307-308), which only decides what is located first when the max_locate
@@ -1584,17 +1586,43 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
             if (sz > 65u) sz = 65u;                                         // keeps the sums below from wrapping
             uint32_t inc = sz;                                              // inclusive prefix sum within the 16-lane row
             for (int o = 1; o < 16; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 16); if (slot >= (uint32_t)o) inc += t; }
-            w.sp[l][slot] = v.x; w.off[l][slot] = v.z;
-            w.pre[l][slot + 1] = inc;
-            if (slot == 0) w.pre[l][0] = 0;
+            for (int q = 0; q < 4; ++q) tot[q] = (uint32_t)__builtin_amdgcn_readlane((int)inc, 16 * q + 15);
+            small = tot[0] <= 16 && tot[1] <= 16 && tot[2] <= 16 && tot[3] <= 16;       // (uniform) the usual case
+            if (small) {
+                // every seed writes the suffix-array rows of its interval where the row lanes of its list will look them up
+                for (uint32_t k2 = 0; k2 < sz; ++k2) { w.sp[l][inc - sz + k2] = v.x + k2; w.off[l][inc - sz + k2] = v.z; }
+            } else {
+                w.sp[l][slot] = v.x; w.off[l][slot] = v.z;
+                w.pre[l][slot + 1] = inc;
+                if (slot == 0) w.pre[l][0] = 0;
+            }
         }
         WSYNC();
         stamp(SALT_CTR_LT_SEEDS);
-        uint32_t tot[4];
-        for (int l = 0; l < 4; ++l) { tot[l] = w.pre[l][16]; heavy |= tot[l] > 64; }
+        for (int l = 0; l < 4; ++l) heavy |= tot[l] > 64;
         if (ap.dbg_stop == 1) { if (lane == 0) results[r].pos = tot[0] + tot[1] + tot[2] + tot[3] + w.pm[0][0] + w.pm[1][1]; return; }
         if (!heavy) {
             // ---- round trip 2: every suffix-array row of the four lists at once ----
+            uint32_t n_s[2];
+            if (small) {
+                // lane = (list, row): at most 16 rows per list, so one lane per row covers all four lists in one go
+                const uint32_t l = lane >> 4, x = lane & 15u;
+                const uint32_t tl = l == 0 ? tot[0] : l == 1 ? tot[1] : l == 2 ? tot[2] : tot[3];
+                bool keep = false; uint32_t p = 0;
+                if (x < tl) {
+                    const uint32_t j = w.sp[l][x];
+                    p = ((l & 1) ? ix.r_pos[j] : ix.c_sa[j]) - w.off[l][x];
+                    keep = (l & 1) ? !(p > ix.ref_len || p + L > ix.ref_len) : !(p + L > ix.ref_len);       // alnse.c:672-673,715-717
+                }
+                stamp(SALT_CTR_LT_LOCATE);
+                if (ap.dbg_stop == 2) { if (__ballot(p == 12345u) == 1) results[r].pos = p; return; }
+                const uint64_t km = __ballot(keep);
+                const uint32_t s = lane >> 5, ms = (uint32_t)(km >> (32 * s));
+                WSYNC();                                                    // the row table aliases nothing below, but keep LDS ordered
+                if (keep) w.loci[s][(uint32_t)__popc(ms & ((1u << (lane & 31u)) - 1u))] = p;
+                n_s[0] = (uint32_t)__popc((uint32_t)km); n_s[1] = (uint32_t)__popc((uint32_t)(km >> 32));
+                c_sa_c += tot[0] + tot[2]; c_sa_r += tot[1] + tot[3]; c_loci += n_s[0] + n_s[1];
+            } else {
             uint32_t pos4[4]; bool keep4[4];
             for (int l = 0; l < 4; ++l) {
                 keep4[l] = false; pos4[l] = 0;
@@ -1609,7 +1637,6 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
             }
             stamp(SALT_CTR_LT_LOCATE);
             if (ap.dbg_stop == 2) { const uint32_t x = pos4[0] + pos4[1] + pos4[2] + pos4[3]; if (__ballot(x == 12345u) == 1) results[r].pos = x; return; }
-            uint32_t n_s[2];
             for (int s = 0; s < 2; ++s) {                                   // both lists of a strand, as located (no order, duplicates stay)
                 const uint64_t mc = __ballot(keep4[2 * s]), mr = __ballot(keep4[2 * s + 1]);
                 const uint32_t nc = (uint32_t)__popcll(mc);
@@ -1617,6 +1644,7 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
                 if (keep4[2 * s + 1]) w.loci[s][nc + (uint32_t)__popcll(mr & lt)] = pos4[2 * s + 1];
                 n_s[s] = nc + (uint32_t)__popcll(mr);
                 c_sa_c += tot[2 * s]; c_sa_r += tot[2 * s + 1]; c_loci += n_s[s];
+            }
             }
             WSYNC();
             stamp(SALT_CTR_LT_SORT);
