@@ -1935,11 +1935,12 @@ void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm
     if (ev3) hipEventRecord(ev3[0], st);
     if (!g.cap) { if (ev3) { hipEventRecord(ev3[1], st); hipEventRecord(ev3[2], st); } return; }
     // the deferred gapped passes: distances by (read, strand, 32 candidates), one finishing wave per read, one traceback per wave
+    // grids: k_gap has many ~70 us items and wants every wave; the other two have few, short items and start faster on fewer blocks
     hipLaunchKernelGGL(k_gap, dim3(n_blocks), dim3(64), 0, st, ix, ap, pm, g);
     if (ev3) hipEventRecord(ev3[1], st);
-    hipLaunchKernelGGL(k_gapfin, dim3(n_blocks), dim3(64), 0, st, ix, ap, pm, results, g, ctr);
+    hipLaunchKernelGGL(k_gapfin, dim3((n_blocks + 3) / 4), dim3(64), 0, st, ix, ap, pm, results, g, ctr);
     if (ev3) hipEventRecord(ev3[2], st);
-    hipLaunchKernelGGL(k_cigar, dim3(n_blocks), dim3(64), 0, st, ix, ap.pg, pm, results, g.cq, g.gctl + 6, g.gctl + 7, g.cap * (1u + SALT_MAX_HITS), tab);
+    hipLaunchKernelGGL(k_cigar, dim3((n_blocks + 1) / 2), dim3(64), 0, st, ix, ap.pg, pm, results, g.cq, g.gctl + 6, g.gctl + 7, g.cap * (1u + SALT_MAX_HITS), tab);
 }
 
 GapBufs gap_bufs_layout(uint8_t *base, uint32_t cap, uint32_t *gctl, size_t *bytes)
