@@ -166,6 +166,10 @@ int  salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[SALT_N_KERNELS], uint32_
  * *n = how many; ids[0..min(*n,cap)) = their indices in the batch, in queue order. */
 int  salt_gpu_ws_heavy_reads(salt_gpu_ws_t *ws, uint32_t *ids, uint32_t cap, uint32_t *n);
 
+/* Plain device buffers for callers without a HIP runtime of their own (resident inputs / results, image copies). */
+int  salt_gpu_buffer_alloc(int device, uint64_t bytes, void **dev_ptr);
+int  salt_gpu_buffer_free(int device, void *dev_ptr);
+
 /* Unit entry of the candidate rule the kernels evaluate on UNSORTED lists: case i has candidates
  * pos/val[offs[i]..offs[i+1]) (val > vmax = no candidate) and the incoming bound bound_in[i].  mode 0: gap-free rule
  * (code_kmismatch, alnse.c:348-369; distances 0..3, range filter pos < ref_len) by rule_unsorted; 1: the same by

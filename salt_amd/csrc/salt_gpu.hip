@@ -554,6 +554,22 @@ extern "C" int salt_gpu_diag_ssw(uint32_t n_cases, const uint8_t *aware, const u
     return SALT_OK;
 }
 
+extern "C" int salt_gpu_buffer_alloc(int device, uint64_t bytes, void **dev_ptr)
+{
+    if (!dev_ptr || !bytes) return fail(SALT_E_INVAL, "null argument");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMalloc(dev_ptr, bytes));
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_buffer_free(int device, void *dev_ptr)
+{
+    if (!dev_ptr) return SALT_OK;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipFree(dev_ptr));
+    return SALT_OK;
+}
+
 // Unit access to the candidate rule (rule_unsorted / rule_sparse): see include/salt_gpu.h
 extern "C" int salt_gpu_diag_rule(uint32_t n_cases, const uint32_t *pos, const uint8_t *val, const uint32_t *offs, const uint32_t *bound_in,
                                   uint32_t L, uint32_t ref_len, int mode, uint32_t *out)

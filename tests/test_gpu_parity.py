@@ -291,3 +291,28 @@ def test_gpu_rule_on_unsorted_lists_equals_the_sequential_rule(mode):
         for h in range(6):
             want += list(hits[h]) if h < len(hits) else [0, 0]
         assert got == want, (mode, c, got, want, pos[c][:10], val[c][:10], bounds[c])
+
+
+def test_gpu_attach_to_a_copied_image_gives_the_same_rows(lam):
+    """The multi-GPU path on one GPU: the packed device image is copied into another buffer (what the RCCL broadcast in
+    bench.py / salt_gpu_index_replicate delivers to the other ranks) and a second aligner attaches to the copy."""
+    import ctypes
+    salt_amd, idx, aln, (names, seqs, offs, quals) = lam
+    lib = salt_amd.gpu_lib()
+    lib.salt_gpu_buffer_alloc.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+    lib.salt_gpu_buffer_free.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    ptr, nbytes = aln.image()
+    buf = ctypes.c_void_p()
+    assert lib.salt_gpu_buffer_alloc(0, nbytes, ctypes.byref(buf)) == 0, lib.salt_gpu_last_error()
+    other = None
+    try:
+        aln.image_copy(buf.value, nbytes)
+        other = salt_amd.GpuAligner(None, device=0, max_reads=2048, image=(buf.value, nbytes))
+        opt, _ = salt_amd.AlnOpt.from_argv(read_cases()["se_default"], idx.l_seed)
+        a = aln.alnse_core1(opt, seqs, offs)
+        b = other.alnse_core1(opt, seqs, offs)
+    finally:
+        if other:
+            other.close()
+        lib.salt_gpu_buffer_free(0, buf)
+    assert salt_amd.sam_text(idx, opt, names, seqs, offs, quals, a) == salt_amd.sam_text(idx, opt, names, seqs, offs, quals, b)
