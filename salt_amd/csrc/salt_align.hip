@@ -1733,6 +1733,278 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_light2: k_light with TWO reads per wave (32 lanes each) for short reads with few seed slots (L <= 120, spr <= 8:
+// the 100-bp single-end case).  k_light is bound by instruction issue and by the dispatch of one workgroup per read; with
+// two reads per wave both halve.  Same steps, same results; every ballot / shuffle stays inside the read's half-wave.
+// ---------------------------------------------------------------------------------------------
+static constexpr int L2_SLOTS = 8;       // seed slots per list
+struct LightLds2 {
+    uint32_t pm[2][16];
+    uint32_t sp[4][L2_SLOTS], off[4][L2_SLOTS];
+    uint32_t pre[4][L2_SLOTS + 1];
+    uint32_t loci[2][LT_LOCI];
+    uint32_t hit_pos[2][NHIT];
+    uint8_t  hit_nd[2][NHIT];
+    uint8_t  val[2][LT_LOCI];
+};
+
+// rule_sparse on a half-wave: n candidates, lane hl of the half holds candidates hl, hl + 32, ...
+__device__ __forceinline__ void rule_sparse_h(const uint32_t *pos, const uint8_t *val, const uint32_t n, const uint32_t ref_len,
+                                              uint32_t &bound, bool &any, uint32_t &best_pos, uint32_t &best_v,
+                                              uint32_t &n_hits, uint32_t &a0, uint32_t *hit_pos, uint8_t *hit_nd)
+{
+    const uint32_t lane = lane_id(), hl = lane & 31u, hb = lane & 32u;
+    const uint32_t NONE = 0xFFFFFFFFu;
+    auto HB = [&](bool x) -> uint32_t { return (uint32_t)(__ballot(x) >> hb); };
+    auto SHF = [&](uint32_t v, int src) -> uint32_t { return (uint32_t)__shfl((int)v, (int)hb + src); };
+    any = false; n_hits = 0;
+    if (n == 0) return;
+    if (n <= 32) {                                            // the usual case: every candidate inside the bound is the same locus
+        uint32_t p = 0, v = NONE;
+        if (hl < n) { p = pos[hl]; v = val[hl]; }
+        const bool ok = v <= bound && p < ref_len;
+        const uint32_t m = HB(ok);
+        if (m == 0) return;
+        const int l0 = __ffs((int)m) - 1;
+        const uint32_t p0 = SHF(p, l0);
+        if (HB(ok && p != p0) == 0) {
+            const uint32_t v0 = SHF(v, l0);
+            any = true; best_pos = p0; best_v = v0; n_hits = 1; a0 = v0;
+            if (hl == 0) { hit_pos[0] = p0; hit_nd[0] = (uint8_t)v0; }
+            bound = v0 < bound ? v0 : bound;
+            return;
+        }
+    }
+    uint32_t mp[4] = { NONE, NONE, NONE, NONE };
+    for (uint32_t b = 0; b < n; b += 32) {
+        const uint32_t i = b + hl;
+        uint32_t p = 0, v = NONE;
+        if (i < n) { p = pos[i]; v = val[i]; }
+        uint32_t m = HB(v <= bound && p < ref_len);
+        while (m) {
+            const int l = __ffs((int)m) - 1;
+            const uint32_t pl = SHF(p, l), vl = SHF(v, l);
+#pragma unroll
+            for (int t = 0; t <= 3; ++t) if (vl == (uint32_t)t && pl < mp[t]) mp[t] = pl;
+            m &= m - 1;
+        }
+    }
+    uint32_t before[4];
+    before[0] = NONE;
+#pragma unroll
+    for (int t = 1; t <= 3; ++t) before[t] = mp[t - 1] < before[t - 1] ? mp[t - 1] : before[t - 1];
+#pragma unroll
+    for (int t = 3; t >= 0; --t) if (mp[t] != NONE) { any = true; best_v = (uint32_t)t; best_pos = mp[t]; }
+    if (!any) return;
+    uint32_t last_p = 0;
+    for (uint32_t h = 0; h < (uint32_t)NHIT; ++h) {
+        uint32_t cur_p = NONE, cur_v = 0;
+        for (uint32_t b = 0; b < n; b += 32) {
+            const uint32_t i = b + hl;
+            uint32_t p = 0, v = NONE;
+            if (i < n) { p = pos[i]; v = val[i]; }
+            const uint32_t lim = v == 1 ? before[1] : v == 2 ? before[2] : v == 3 ? before[3] : NONE;
+            uint32_t m = HB(v <= bound && p < ref_len && p < lim && (h == 0 || p > last_p));
+            while (m) {
+                const int l = __ffs((int)m) - 1;
+                const uint32_t pl = SHF(p, l);
+                if (pl < cur_p) { cur_p = pl; cur_v = SHF(v, l); }
+                m &= m - 1;
+            }
+        }
+        if (cur_p == NONE) break;
+        if (hl == 0) { hit_pos[h] = cur_p; hit_nd[h] = (uint8_t)cur_v; }
+        if (h == 0) a0 = cur_v;
+        last_p = cur_p; ++n_hits;
+    }
+    bound = best_v < bound ? best_v : bound;
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
+         const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
+         uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl)
+{
+    __shared__ LightLds2 w2[2];
+    const uint32_t lane = lane_id(), hl = lane & 31u, hb = lane & 32u, half = lane >> 5;
+    LightLds2 &w = w2[half];
+    const uint32_t lt = (1u << hl) - 1u;
+    auto HB = [&](bool x) -> uint32_t { return (uint32_t)(__ballot(x) >> hb); };
+    auto SHF = [&](uint32_t v, int src) -> uint32_t { return (uint32_t)__shfl((int)v, (int)hb + src); };
+    const uint32_t r = 2u * blockIdx.x + half;
+    if (r >= ap.n_reads) return;
+    const uint32_t *rec = pm + (uint64_t)r * ap.pg.pm_stride;
+    const uint32_t L = rec[2 * ap.pg.nw8];
+    bool heavy = L > 120u || L < (uint32_t)ap.l_seed || ap.spr > (uint32_t)L2_SLOTS || ap.max_locate < 2 * 64;
+    if (!heavy) {
+        // ---- round trip 1: the read (one-hot nibble words, both strands) and its seeds ----
+        const uint32_t nw = (L + 7) >> 3;                                   // <= 15
+        uint32_t n_amb = 0;
+        if (hl < 2 * nw) {
+            const uint32_t s = hl >= nw, j = s ? hl - nw : hl;
+            const uint32_t word = rec[s * ap.pg.nw8 + j];
+            w.pm[s][j] = word;
+            if (!s) n_amb = (uint32_t)__popc(word & (word >> 1) & (word >> 2) & (word >> 3) & 0x11111111u);
+        }
+        if (ap.max_amb < L) {
+            for (int o = 16; o > 0; o >>= 1) n_amb += (uint32_t)__shfl_xor((int)n_amb, o);
+            if (n_amb > ap.max_amb) {                                       // alnse.c:1328 / alnpe.c:495: record left untouched
+                if (hl == 0) {
+                    salt_result_t *out = results + r;
+                    out->pos = 0xFFFFFFFFu; out->strand = 3; out->n_diff = 255; out->is_gap = 255; out->mapq = 0;
+                    out->b0 = -1; out->b1 = -1; out->seq_start = 0; out->seq_end = (uint16_t)(L - 1);
+                    out->n_hits[0] = out->n_hits[1] = 0; out->n_cigar = 0; out->skipped = 1;
+                }
+                return;
+            }
+        }
+        uint32_t tot[4];
+        bool small;
+        {
+            // half-lane = (list, slot); list: 0 C/fwd 1 R/fwd 2 C/rev 3 R/rev (see k_light)
+            const uint32_t l = hl >> 3, slot = hl & 7u;
+            uint4 v = make_uint4(1, 0, 0, 0);
+            if (slot < ap.spr) v = ((l & 1) ? sai_r : sai_c)[((uint64_t)r * 2u + (l >> 1)) * ap.spr + slot];
+            uint32_t sz = v.w ? v.y - v.x + 1u : 0u;
+            if (sz > 65u) sz = 65u;
+            uint32_t inc = sz;                                              // inclusive prefix sum within the 8-lane row
+            for (int o = 1; o < 8; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 8); if (slot >= (uint32_t)o) inc += t; }
+            for (int q = 0; q < 4; ++q) tot[q] = SHF(inc, 8 * q + 7);
+            small = tot[0] <= 8 && tot[1] <= 8 && tot[2] <= 8 && tot[3] <= 8;
+            if (small) {
+                for (uint32_t k2 = 0; k2 < sz; ++k2) { w.sp[l][inc - sz + k2] = v.x + k2; w.off[l][inc - sz + k2] = v.z; }
+            } else {
+                w.sp[l][slot] = v.x; w.off[l][slot] = v.z;
+                w.pre[l][slot + 1] = inc;
+                if (slot == 0) w.pre[l][0] = 0;
+            }
+        }
+        WSYNC();
+        for (int l = 0; l < 4; ++l) heavy |= tot[l] > 64;
+        if (!heavy) {
+            // ---- round trip 2: the suffix-array rows of the four lists ----
+            uint32_t n_s[2] = { 0, 0 };
+            if (small) {
+                const uint32_t l = hl >> 3, x = hl & 7u;
+                const uint32_t tl = l == 0 ? tot[0] : l == 1 ? tot[1] : l == 2 ? tot[2] : tot[3];
+                bool keep = false; uint32_t p = 0;
+                if (x < tl) {
+                    const uint32_t j = w.sp[l][x];
+                    p = ((l & 1) ? ix.r_pos[j] : ix.c_sa[j]) - w.off[l][x];
+                    keep = (l & 1) ? !(p > ix.ref_len || p + L > ix.ref_len) : !(p + L > ix.ref_len);       // alnse.c:672-673,715-717
+                }
+                const uint32_t km = HB(keep);
+                const uint32_t s = hl >> 4, ms = (km >> (16 * s)) & 0xFFFFu;
+                if (keep) w.loci[s][(uint32_t)__popc(ms & ((1u << (hl & 15u)) - 1u))] = p;
+                n_s[0] = (uint32_t)__popc(km & 0xFFFFu); n_s[1] = (uint32_t)__popc(km >> 16);
+            } else {
+                for (int l = 0; l < 4; ++l) {
+                    const int s = l >> 1;
+                    for (uint32_t x = hl; x - hl < tot[l]; x += 32) {         // (x - hl) is the same for the whole half: a uniform trip count
+                        bool keep = false; uint32_t p = 0;
+                        if (x < tot[l]) {
+                            uint32_t i = 0;
+                            while (w.pre[l][i + 1] <= x) ++i;
+                            const uint32_t j = w.sp[l][i] + (x - w.pre[l][i]);
+                            p = ((l & 1) ? ix.r_pos[j] : ix.c_sa[j]) - w.off[l][i];
+                            keep = (l & 1) ? !(p > ix.ref_len || p + L > ix.ref_len) : !(p + L > ix.ref_len);
+                        }
+                        const uint32_t km = HB(keep);
+                        if (keep) w.loci[s][n_s[s] + (uint32_t)__popc(km & lt)] = p;
+                        n_s[s] += (uint32_t)__popc(km);
+                    }
+                }
+            }
+            WSYNC();
+            // ---- round trip 3: masked Hamming distance of every located row of both strands, 4 lanes per row ----
+            {
+                const uint32_t sub = hl & 3u, q = hl >> 2, n = n_s[0] + n_s[1];
+                const uint32_t nvalid = L > 32u * sub ? (L - 32u * sub < 32u ? L - 32u * sub : 32u) : 0u;
+                uint32_t pa[4], pb[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { const bool in = (4 * sub + t) < nw; pa[t] = in ? w.pm[0][4 * sub + t] : 0u; pb[t] = in ? w.pm[1][4 * sub + t] : 0u; }
+                for (uint32_t b = 0; b < n; b += 32) {                      // 4 groups of 8 rows per trip
+                    uint32_t pos[4]; u32x4_a4 x[4]; bool act[4], rev[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (b + 8u * g >= n) break;
+                        const uint32_t c = b + 8u * g + q;
+                        act[g] = c < n; rev[g] = c >= n_s[0];
+                        pos[g] = act[g] ? (rev[g] ? w.loci[1][c - n_s[0]] : w.loci[0][c]) : 0u;
+                        x[g] = *reinterpret_cast<const u32x4_a4 *>(ix.ref + (pos[g] >> 3) + 4 * sub);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (b + 8u * g >= n) break;
+                        const uint32_t pw[4] = { rev[g] ? pb[0] : pa[0], rev[g] ? pb[1] : pa[1], rev[g] ? pb[2] : pa[2], rev[g] ? pb[3] : pa[3] };
+                        const uint32_t mism = quad_mismatch(x[g], pos[g], pw, nvalid);
+                        if (act[g] && sub == 0) {
+                            const uint32_t c = b + 8u * g + q;
+                            const uint8_t v = (uint8_t)(mism > 3 ? INF : mism);
+                            if (rev[g]) w.val[1][c - n_s[0]] = v; else w.val[0][c] = v;
+                        }
+                    }
+                }
+            }
+            WSYNC();
+            // ---- the sequential best/first-hit rule on the unsorted rows ----
+            uint32_t bound = 3, q_pos = 0xFFFFFFFFu, q_strand = 3, q_ndiff = 255;
+            uint32_t n_hits_s[2] = { 0, 0 }, a0[2] = { 0, 0 };
+            bool found[2] = { false, false };
+            for (int s = 0; s < 2; ++s) {
+                bool any = false; uint32_t bp = 0, bv = 0;
+                rule_sparse_h(w.loci[s], w.val[s], n_s[s], ix.ref_len, bound, any, bp, bv, n_hits_s[s], a0[s], w.hit_pos[s], w.hit_nd[s]);
+                if (any) { found[s] = true; q_pos = bp; q_ndiff = bv; q_strand = (uint32_t)s; }
+            }
+            if (!found[0] && !found[1]) heavy = true;                       // needs the gapped pass
+            else {
+                WSYNC();
+                // ---- query_set_hits / gen_mapq (query.c:270-333), see k_light ----
+                const uint32_t hs = hl >= (uint32_t)NHIT, hj = hl - hs * NHIT;
+                uint32_t hp = 0xFFFFFFFFu, hn = 0;
+                bool cand = false;
+                if (hl < 2u * NHIT && hj < (hs ? n_hits_s[1] : n_hits_s[0])) {
+                    hp = w.hit_pos[hs][hj]; hn = w.hit_nd[hs][hj];
+                    cand = hp != 0xFFFFFFFFu && hp != q_pos && (hs ? a0[1] : a0[0]) <= q_ndiff;
+                }
+                const uint32_t cm = HB(cand);
+                const bool sel = cand && (uint32_t)__popc(cm & lt) < (uint32_t)ap.max_hits;
+                const uint32_t sm = HB(sel);
+                const uint32_t nh0 = (uint32_t)__popc(sm & ((1u << NHIT) - 1u)), nh1 = (uint32_t)__popc(sm >> NHIT);
+                const int b0 = (int)q_ndiff;
+                int b1 = 100000;
+                if (nh0) b1 = (int)a0[0];
+                if (nh1 && (int)a0[1] <= b1) b1 = (int)a0[1];
+                uint32_t mapq = 0;
+                if (b0 != 0) {
+                    const uint32_t x = (uint32_t)(b0 > b1 ? b0 - b1 : b1 - b0);
+                    const uint64_t qq = (uint64_t)255 * x / (uint32_t)b0;
+                    mapq = qq < 254 ? (uint32_t)qq : 254u;
+                }
+                salt_result_t *out = results + r;
+                if (sel) {
+                    const uint32_t hidx = (uint32_t)__popc(sm & lt);
+                    salt_hit_t hv; hv.pos = hp; hv.n_diff = (uint8_t)hn; hv.is_gap = 0; hv.strand = (uint16_t)hs;
+                    out->hits[hs][hs ? hidx - nh0 : hidx] = hv;
+                    out->hit_n_cigar[hidx] = 0;
+                }
+                if (hl >= 16 && hl < 22) {                                  // the 24 header bytes as six dwords
+                    const uint32_t t = hl - 16;
+                    const uint32_t d = t == 0 ? q_pos
+                                     : t == 1 ? (q_strand | (q_ndiff << 8) | (mapq << 24))
+                                     : t == 2 ? (uint32_t)b0
+                                     : t == 3 ? (uint32_t)b1
+                                     : t == 4 ? ((L - 1) << 16)
+                                     : (nh0 | (nh1 << 8) | (1u << 16));
+                    reinterpret_cast<uint32_t *>(out)[t] = d;
+                } else if (hl == 22) out->cigar[0] = (uint16_t)((L << 4) | 0u);
+            }
+        }
+    }
+    if (heavy && hl == 0) queue[atomicAdd(&qctl[0], 1u)] = r;                // k_heavy does all of it
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_pe_final: one thread per pair -- apply the first successful mate rescue (in the order pairing2 /
 // pairing_singleton try them, alnpe.c:213-252, 420-470), then query_gen_cigar for the mates that keep their
 // seed-and-verify mapping (query.c:282-296): "<L>M", or a k_cigar item when the mapping is gapped
@@ -1795,6 +2067,11 @@ void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm
                   const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, unsigned long long *ctr, hipStream_t st)
 {
     if (!ap.n_reads) return;
+    static const bool no_half = getenv("SALT_GPU_NO_LIGHT2") && atoi(getenv("SALT_GPU_NO_LIGHT2"));
+    if (!no_half && !ctr && !ap.dbg_stop && ap.spr <= (uint32_t)L2_SLOTS && ap.pg.nw8 <= 15) {          // reads of at most 120 bases: two per wave
+        hipLaunchKernelGGL(k_light2, dim3((ap.n_reads + 1) / 2), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl);
+        return;
+    }
     hipLaunchKernelGGL(k_light, dim3((ap.n_reads + LT_WAVES - 1) / LT_WAVES), dim3(64 * LT_WAVES), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr);
 }
 
