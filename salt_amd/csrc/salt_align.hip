@@ -220,11 +220,11 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
                 const uint32_t c = base2(s + (uint32_t)i);
                 if (alive_c) {
                     uint32_t ok, ol; c_occ2(ix, kc - 1, lc, c, ok, ol);
-                    kc = ix.c_L2[c] + ok + 1; lc = ix.c_L2[c] + ol; alive_c = kc <= lc; n_occ_c += 2;
+                    { const uint32_t l2 = pick4(ix.c_L2, c); kc = l2 + ok + 1; lc = l2 + ol; } alive_c = kc <= lc; n_occ_c += 2;
                 }
                 if (alive_r) {
                     uint32_t ok, ol; r_occ2(ix, kr, lr + 1, c, ok, ol);
-                    kr = ix.r_cum[c] + ok + 1; lr = ix.r_cum[c] + ol; alive_r = kr <= lr; n_occ_r += 2;
+                    { const uint32_t cm = pick5(ix.r_cum, c); kr = cm + ok + 1; lr = cm + ol; } alive_r = kr <= lr; n_occ_r += 2;
                 }
             }
             if (alive_c) {                                    // shrink big intervals leftwards (alnse.c:246-258)
@@ -235,7 +235,7 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
                     uint32_t ok, ol; c_occ2(ix, kc - 1, lc, c, ok, ol);
                     n_occ_c += 2;
                     if (ok + 1 > ol) break;
-                    kc = ix.c_L2[c] + ok + 1; lc = ix.c_L2[c] + ol; ++ext;
+                    { const uint32_t l2 = pick4(ix.c_L2, c); kc = l2 + ok + 1; lc = l2 + ol; } ++ext;
                     if (lc - kc <= sp.max_seed) break;
                 }
                 oc = make_uint4(kc, lc, s - ext, 1);
@@ -247,7 +247,7 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
                     uint32_t ok, ol; r_occ2(ix, kr, lr + 1, c, ok, ol);
                     n_occ_r += 2;
                     if (ok + 1 > ol) break;
-                    kr = ix.r_cum[c] + ok + 1; lr = ix.r_cum[c] + ol; ++ext;
+                    { const uint32_t cm = pick5(ix.r_cum, c); kr = cm + ok + 1; lr = cm + ol; } ++ext;
                     if (lr - kr <= sp.max_seed) break;
                 }
                 orr = make_uint4(kr, lr, s - ext, 1);

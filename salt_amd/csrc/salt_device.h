@@ -57,6 +57,10 @@ __device__ __forceinline__ uint32_t sel4(uint4 v, uint32_t c)
     return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
 }
 
+// a[c] for a per-lane c without indexing the kernel argument (a dynamic index would move the array to LDS or scratch)
+__device__ __forceinline__ uint32_t pick4(const uint32_t *a, uint32_t c) { return c == 0 ? a[0] : c == 1 ? a[1] : c == 2 ? a[2] : a[3]; }
+__device__ __forceinline__ uint32_t pick5(const uint32_t *a, uint32_t c) { return c == 0 ? a[0] : c == 1 ? a[1] : c == 2 ? a[2] : c == 3 ? a[3] : a[4]; }
+
 // Occ(k, c) of the C index: occurrences of c in BWT rows [0, k]  (bwt_occ, bwt.c:113-138)
 __device__ __forceinline__ uint32_t c_occ(const IndexView &ix, uint32_t k, uint32_t c)
 {
@@ -85,7 +89,7 @@ __device__ __forceinline__ uint32_t c_occ_eval(const uint4 cnt, const uint4 pl, 
 }
 __device__ __forceinline__ void c_occ2(const IndexView &ix, const uint32_t k, const uint32_t l, const uint32_t c, uint32_t &ok, uint32_t &ol)
 {
-    const uint32_t full = ix.c_L2[c + 1] - ix.c_L2[c];
+    const uint32_t full = pick4(ix.c_L2 + 1, c) - pick4(ix.c_L2, c);
     const bool ks = k == ix.c_seq_len || k == 0xFFFFFFFFu, ls = l == ix.c_seq_len || l == 0xFFFFFFFFu;
     const uint32_t kk = k - (k >= ix.c_primary), ll = l - (l >= ix.c_primary);
     uint4 cnt = make_uint4(0, 0, 0, 0), pl = make_uint4(0, 0, 0, 0);
