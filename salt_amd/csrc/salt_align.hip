@@ -78,83 +78,141 @@ __device__ __forceinline__ uint32_t pk_nibbles(uint32_t x)        // 4 bytes (lo
     return (t | (t >> 8)) & 0xFFFFu;
 }
 
+// Phase 1: one thread per (read, 32 forward bases): the bytes come straight from global memory as aligned dwords (never
+// past the ends of seqs[]), are clamped (codes > 4 read as N) and packed with shift-and-mask steps; the forward words go to
+// global memory and to LDS.  Phase 2: one thread per reverse-strand word, derived from the forward WORDS: reversing a
+// read reverses its bit string, complementing a base reverses the bits of its one-hot nibble / inverts its 2-bit code.
+struct PackWords { uint32_t pm[64], tb[32], nm[16]; };               // forward words of one read (up to 512 bases)
+
 __global__ void __launch_bounds__(256)
 k_pack(PackGeom pg, uint32_t n_reads, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
        uint32_t *__restrict__ pm, uint32_t *__restrict__ tb)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t sb[8192];              // [read][strand][32 * nw32], 8 = no base
-    __shared__ uint8_t raw[4096 + 64];                                     // the block's reads as they lie in seqs[]
+    extern __shared__ uint32_t pk_lds[];                                    // [rpb][nw8 + nw16 + nw32] forward words
     __shared__ uint32_t so[65];
-    const uint32_t tpr = 2 * pg.nw32, rpb = 256 / tpr < 64 ? 256 / tpr : 64, slot = 32 * pg.nw32;   // threads per read, reads per block, bytes per strand
+    const uint32_t tpr = pg.nw32, rpb = 256 / tpr < 64 ? 256 / tpr : 64;   // threads per read in phase 1, reads per block
+    const uint32_t wpr = pg.nw8 + pg.nw16 + pg.nw32;                       // forward words per read
     const uint32_t r0 = blockIdx.x * rpb, nr = n_reads - r0 < rpb ? n_reads - r0 : rpb;
     if (threadIdx.x <= nr) so[threadIdx.x] = offs[r0 + threadIdx.x];
-    reinterpret_cast<uint4 *>(sb)[threadIdx.x] = make_uint4(0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u);
-    reinterpret_cast<uint4 *>(sb)[threadIdx.x + 256] = make_uint4(0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u);
-    __syncthreads();
-    const uint32_t base = so[0];
-    uint32_t total = so[nr] - base;
-    if (total > 4096u) total = 4096u;                                       // reads longer than max_read_len says: truncated, never out of bounds
-    {   // one contiguous copy, all loads independent of each other
-        const uint8_t *src = seqs + base;
-#pragma unroll 4
-        for (uint32_t i = threadIdx.x; i < total; i += 256) raw[i] = src[i];
-    }
     __syncthreads();
     const uint32_t cap = 8 * pg.nw8;                                        // bases the records hold per strand
-    for (uint32_t rr = threadIdx.x >> 6; rr < nr; rr += 4) {                // one wave per read: both strands at aligned slots
-        const uint32_t o = so[rr] - base;
-        uint32_t L = so[rr + 1] - so[rr];
-        if (L > cap) L = cap;
-        if (o >= total) L = 0; else if (L > total - o) L = total - o;
-        uint8_t *f = sb + (size_t)rr * 2 * slot, *v = f + slot;
-        for (uint32_t i = threadIdx.x & 63u; i < L; i += 64) {
-            uint32_t c = raw[o + i];
-            if (c > 4) c = 4;
-            f[i] = (uint8_t)c;
-            v[L - 1 - i] = (uint8_t)(c < 4 ? 3 - c : c);
+    const uint64_t total_bases = offs[n_reads];                             // end of the valid bytes of seqs[]
+    {
+        const uint32_t rr = threadIdx.x / tpr, j = threadIdx.x - rr * tpr;
+        if (rr < nr) {
+            uint32_t L = so[rr + 1] - so[rr];
+            if (L > cap) L = cap;                                           // longer than max_read_len says: truncated, never out of bounds
+            // 32 bytes from seqs + so[rr] + 32 j as 9 aligned dwords; dwords outside [seqs, seqs + total_bases) read as 0
+            const uintptr_t a0 = (uintptr_t)seqs + so[rr] + 32u * j, lo = (uintptr_t)seqs & ~(uintptr_t)3, hi = (uintptr_t)seqs + total_bases;
+            const uintptr_t ab = a0 & ~(uintptr_t)3;
+            const uint32_t sh = (uint32_t)(a0 & 3u) * 8u;
+            uint32_t wv[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { const uintptr_t ad = ab + 4u * t; wv[t] = (ad >= lo && ad < hi) ? *reinterpret_cast<const uint32_t *>(ad) : 0u; }
+            uint32_t d[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                uint32_t x = __funnelshift_r(wv[t], wv[t + 1], sh);
+                const uint32_t big = ((((x & 0x7F7F7F7Fu) + 0x7B7B7B7Bu) | x) & 0x80808080u) >> 7;   // 1 in every byte >= 5
+                const uint32_t mb = big * 0xFFu;
+                x = (x & ~mb) | (0x04040404u & mb);                                            // codes > 4 read as N
+                const int nv = (int)L - (int)(32u * j + 4u * t);                               // bases of the read in this dword
+                const uint32_t vm = nv >= 4 ? 0xFFFFFFFFu : nv <= 0 ? 0u : (0xFFFFFFFFu >> (8 * (4 - nv)));
+                d[t] = (x & vm) | (0x08080808u & ~vm);                                         // 8 = no base
+            }
+            uint32_t *pmr = pm + (uint64_t)(r0 + rr) * pg.pm_stride, *tbr = tb + (uint64_t)(r0 + rr) * pg.tb_stride;
+            uint32_t *fw = pk_lds + (size_t)rr * wpr;
+            uint32_t p16[4], nb = 0;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const uint32_t n8 = pk_nibbles(d[2 * h]) | (pk_nibbles(d[2 * h + 1]) << 16);     // base q of the chunk in nibble q
+                const uint32_t one = 0x11111111u;
+                const uint32_t aa = n8 & one, bb = (n8 >> 1) & one, isn = (n8 >> 2) & one, valid = ~(n8 >> 3) & one;
+                const uint32_t na = aa ^ one, nb_ = bb ^ one;
+                uint32_t oh = (na & nb_) | ((aa & nb_) << 1) | ((na & bb) << 2) | ((aa & bb) << 3);  // 1 << code
+                oh = (oh | isn * 15u) & (valid * 15u);                                          // N -> 15, no base -> 0 (nt2bit, editdistance.c:40)
+                if (4 * j + h < pg.nw8) { pmr[4 * j + h] = oh; fw[4 * j + h] = oh; }
+                uint32_t t = n8 & 0x33333333u;                                                  // 2-bit codes (N and 'no base' read 0)
+                t = (t | (t >> 2)) & 0x0F0F0F0Fu; t = (t | (t >> 4)) & 0x00FF00FFu; p16[h] = (t | (t >> 8)) & 0xFFFFu;
+                uint32_t u = isn;
+                u = (u | (u >> 3)) & 0x03030303u; u = (u | (u >> 6)) & 0x000F000Fu; u = (u | (u >> 12)) & 0xFFu;
+                nb |= u << (8 * h);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const uint32_t rv = __brev(p16[2 * g] | (p16[2 * g + 1] << 16));               // first base highest; then put each pair back in order
+                const uint32_t wd = ((rv & 0x55555555u) << 1) | ((rv >> 1) & 0x55555555u);
+                if (2 * j + g < pg.nw16) { tbr[2 * j + g] = wd; fw[pg.nw8 + 2 * j + g] = wd; }
+            }
+            const uint32_t nmw = __brev(nb);
+            tbr[2 * pg.nw16 + j] = nmw; fw[pg.nw8 + pg.nw16 + j] = nmw;
+            if (j == 0) { pmr[2 * pg.nw8] = L; tbr[2 * pg.nw16 + 2 * pg.nw32] = L; }
         }
     }
     __syncthreads();
-    const uint32_t rr = threadIdx.x / tpr, sub = threadIdx.x - rr * tpr;
-    if (rr >= nr) return;
-    const uint32_t strand = sub >= pg.nw32, j = sub - strand * pg.nw32;
-    uint32_t L = so[rr + 1] - so[rr];
-    if (L > cap) L = cap;
-    { const uint32_t o = so[rr] - base; if (o >= total) L = 0; else if (L > total - o) L = total - o; }
-    const uint4 *src = reinterpret_cast<const uint4 *>(sb + ((size_t)rr * 2 + strand) * slot + 32 * j);
-    const uint4 q0 = src[0], q1 = src[1];
-    const uint32_t d[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
-    uint32_t *pmr = pm + (uint64_t)(r0 + rr) * pg.pm_stride, *tbr = tb + (uint64_t)(r0 + rr) * pg.tb_stride;
-    uint32_t p16[4], nb = 0;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        const uint32_t n8 = pk_nibbles(d[2 * h]) | (pk_nibbles(d[2 * h + 1]) << 16);     // base q of the chunk in nibble q
-        const uint32_t one = 0x11111111u;
-        const uint32_t a = n8 & one, b = (n8 >> 1) & one, isn = (n8 >> 2) & one, valid = ~(n8 >> 3) & one;
-        const uint32_t na = a ^ one, nb_ = b ^ one;
-        uint32_t oh = (na & nb_) | ((a & nb_) << 1) | ((na & b) << 2) | ((a & b) << 3);  // 1 << code
-        oh = (oh | isn * 15u) & (valid * 15u);                                          // N -> 15, no base -> 0 (nt2bit, editdistance.c:40)
-        if (4 * j + h < pg.nw8) pmr[strand * pg.nw8 + 4 * j + h] = oh;
-        uint32_t t = n8 & 0x33333333u;                                                  // 2-bit codes (N and 'no base' read 0)
-        t = (t | (t >> 2)) & 0x0F0F0F0Fu; t = (t | (t >> 4)) & 0x00FF00FFu; p16[h] = (t | (t >> 8)) & 0xFFFFu;
-        uint32_t u = isn;
-        u = (u | (u >> 3)) & 0x03030303u; u = (u | (u >> 6)) & 0x000F000Fu; u = (u | (u >> 12)) & 0xFFu;
-        nb |= u << (8 * h);
+    // ---- phase 2: the reverse-complement strand, word by word, from the forward words ----
+    for (uint32_t t = threadIdx.x; t < nr * wpr; t += 256) {
+        const uint32_t rr = t / wpr, wi = t - rr * wpr;
+        uint32_t L = so[rr + 1] - so[rr];
+        if (L > cap) L = cap;
+        const uint32_t *fw = pk_lds + (size_t)rr * wpr;
+        uint32_t *pmr = pm + (uint64_t)(r0 + rr) * pg.pm_stride, *tbr = tb + (uint64_t)(r0 + rr) * pg.tb_stride;
+        if (wi < pg.nw8) {
+            // nibbles 8k .. 8k+7 of the reverse strand = forward nibbles L-1-8k down to L-8-8k, each bit-reversed:
+            // take forward nibbles a .. a+7 (a = L-8-8k; nibbles before the read are zero) and reverse all 32 bits
+            const uint32_t k = wi;
+            const int a = (int)L - 8 - 8 * (int)k;
+            uint32_t x = 0;
+            if (a > -8) {
+                if (a >= 0) { const uint32_t j0 = (uint32_t)a >> 3; x = __funnelshift_r(fw[j0], j0 + 1 < pg.nw8 ? fw[j0 + 1] : 0u, 4u * ((uint32_t)a & 7u)); }
+                else x = fw[0] << (4 * -a);
+            }
+            pmr[pg.nw8 + k] = __brev(x);
+        } else if (wi < pg.nw8 + pg.nw16) {
+            // 16 bases of the reverse strand (first base highest) = forward bases a+15 down to a (a = L-16-16k), complemented; N -> 0
+            const uint32_t k = wi - pg.nw8;
+            const int a = (int)L - 16 - 16 * (int)k;
+            const uint32_t *f2 = fw + pg.nw8, *fn = fw + pg.nw8 + pg.nw16;
+            uint32_t y = 0, z = 0;                                          // y: forward bases a..a+15 (a at the top), z: their N flags (a at bit 15)
+            if (a > -16) {
+                if (a >= 0) {
+                    const uint32_t j0 = (uint32_t)a >> 4, s2 = 2u * ((uint32_t)a & 15u);
+                    const uint32_t w0 = f2[j0], w1 = j0 + 1 < pg.nw16 ? f2[j0 + 1] : 0u;
+                    y = s2 ? (w0 << s2) | (w1 >> (32 - s2)) : w0;
+                    const uint32_t n0 = (uint32_t)a >> 5, s1 = (uint32_t)a & 31u;
+                    const uint32_t m0 = fn[n0], m1 = n0 + 1 < pg.nw32 ? fn[n0 + 1] : 0u;
+                    z = (s1 ? (m0 << s1) | (m1 >> (32 - s1)) : m0) >> 16;
+                } else { y = f2[0] >> (2 * -a); z = (fn[0] >> 16) >> (-a); }
+            }
+            const uint32_t ry = __brev(y);                                  // base a+15 first, bits inside every pair swapped
+            uint32_t rev = ~(((ry & 0x55555555u) << 1) | ((ry >> 1) & 0x55555555u));            // pairs back in order, complemented
+            uint32_t zz = __brev(z) >> 16;                                  // N flag of base a+15 at bit 15 ... base a at bit 0
+            zz = (zz | (zz << 8)) & 0x00FF00FFu; zz = (zz | (zz << 4)) & 0x0F0F0F0Fu;           // spread every flag to a pair of bits
+            zz = (zz | (zz << 2)) & 0x33333333u; zz = (zz | (zz << 1)) & 0x55555555u; zz |= zz << 1;
+            const int nv = (int)L - 16 * (int)k;                            // bases of the reverse strand in this word
+            const uint32_t vm = nv >= 16 ? 0xFFFFFFFFu : nv <= 0 ? 0u : ~(0xFFFFFFFFu >> (2 * nv));
+            tbr[pg.nw16 + k] = rev & ~zz & vm;
+        } else {
+            // 32 N flags of the reverse strand (first base highest) = forward flags a+31 down to a (a = L-32-32k)
+            const uint32_t k = wi - pg.nw8 - pg.nw16;
+            const int a = (int)L - 32 - 32 * (int)k;
+            const uint32_t *fn = fw + pg.nw8 + pg.nw16;
+            uint32_t y = 0;
+            if (a > -32) {
+                if (a >= 0) { const uint32_t n0 = (uint32_t)a >> 5, s1 = (uint32_t)a & 31u; const uint32_t m0 = fn[n0], m1 = n0 + 1 < pg.nw32 ? fn[n0 + 1] : 0u; y = s1 ? (m0 << s1) | (m1 >> (32 - s1)) : m0; }
+                else y = fn[0] >> (-a);
+            }
+            tbr[2 * pg.nw16 + pg.nw32 + k] = __brev(y);
+        }
     }
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const uint32_t r = __brev(p16[2 * g] | (p16[2 * g + 1] << 16));                 // first base highest; then put each pair back in order
-        if (2 * j + g < pg.nw16) tbr[strand * pg.nw16 + 2 * j + g] = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
-    }
-    tbr[2 * pg.nw16 + strand * pg.nw32 + j] = __brev(nb);
-    if (sub == 0) { pmr[2 * pg.nw8] = L; tbr[2 * pg.nw16 + 2 * pg.nw32] = L; }
 }
 
 void launch_pack(const PackGeom &pg, uint32_t n_reads, const uint8_t *seqs, const uint32_t *offs, uint32_t *pm, uint32_t *tb, hipStream_t st)
 {
     if (!n_reads) return;
-    const uint32_t rpb = 256 / (2 * pg.nw32) < 64 ? 256 / (2 * pg.nw32) : 64;
-    hipLaunchKernelGGL(k_pack, dim3((n_reads + rpb - 1) / rpb), dim3(256), 0, st, pg, n_reads, seqs, offs, pm, tb);
+    const uint32_t rpb = 256 / pg.nw32 < 64 ? 256 / pg.nw32 : 64;
+    const uint32_t lds = rpb * (pg.nw8 + pg.nw16 + pg.nw32) * 4u;
+    hipLaunchKernelGGL(k_pack, dim3((n_reads + rpb - 1) / rpb), dim3(256), lds, st, pg, n_reads, seqs, offs, pm, tb);
 }
 
 // ---------------------------------------------------------------------------------------------
