@@ -272,20 +272,52 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
                 if (alive_r) { kr = v.z; lr = v.w; alive_r = kr <= lr; n_occ_r += 2 * W; }
             }
             const int i_r_start = (int)(k - W) - 1;         // first head index still to consume
+            bool c_located = false;                          // the C interval is one row and has been resolved to its text position
+            // A C interval of ONE row cannot branch any more: the rest of its backward search (bwt.c:281-309) succeeds iff the
+            // read's remaining bases equal the text in front of that suffix.  One suffix-array load and one text load replace up
+            // to k - W Occ steps, and the seed leaves k_seed already located (flag 2: .x = .y = the genome position).
+            auto resolve_unique = [&](int i_top) {           // bases s .. s+i_top are still to be consumed, newest first
+                const uint32_t m = (uint32_t)i_top + 1u;
+                const uint32_t reln = s - (nb << 5);
+                const uint64_t vn = ((uint64_t)n0 << 32) | n1;
+                uint32_t p0 = ix.c_sa[kc];
+                if (p0 == 0xFFFFFFFFu) p0 = ix.c_seq_len;    // row 0: the empty suffix
+                bool ok = ((vn >> (64 - reln - m)) & ((1ull << m) - 1ull)) == 0 && p0 >= m;
+                uint32_t steps = m;
+                for (uint32_t done = 0; done < m && ok; ) {  // at most two pieces of up to 16 bases, the later bases (consumed first) first
+                    const uint32_t cnt = (m - done) > 16u ? 16u : (m - done);
+                    const uint32_t r0 = s + (m - done - cnt), t0 = p0 - done - cnt;       // read bases r0 .. r0+cnt-1 against text t0 ..
+                    const uint32_t rel = r0 - (wb << 4), rr = rel & 15u;
+                    const uint64_t vr = rel < 16 ? (((uint64_t)w0 << 32) | w1) : (((uint64_t)w1 << 32) | w2);
+                    const uint32_t xr = (uint32_t)((vr >> (64 - 2 * rr - 2 * cnt)) & ((1ull << (2 * cnt)) - 1ull));
+                    const uint32_t tj = t0 >> 4, tr = t0 & 15u;
+                    const uint64_t vt = ((uint64_t)ix.text[tj] << 32) | ix.text[tj + 1];
+                    const uint32_t xt = (uint32_t)((vt >> (64 - 2 * tr - 2 * cnt)) & ((1ull << (2 * cnt)) - 1ull));
+                    const uint32_t diff = xr ^ xt;
+                    if (diff) { ok = false; steps = done + ((uint32_t)__ffs((int)diff) - 1u) / 2u + 1u; }
+                    done += cnt;
+                }
+                n_occ_c += 2 * steps;
+                alive_c = ok;
+                if (ok) { kc = lc = p0 - m; c_located = true; }
+            };
+            if (inreg && alive_c && kc == lc && i_r_start >= 0) resolve_unique(i_r_start);
             // joint backward search over the seed head, newest base last (bwt.c:281-309, rbwt.c:619-648)
-            for (int i = i_r_start; i >= 0 && (alive_c || alive_r); --i) {
-                if (is_n(s + (uint32_t)i)) { alive_c = false; alive_r = false; break; }
+            for (int i = i_r_start; i >= 0 && ((alive_c && !c_located) || alive_r); --i) {
+                if (is_n(s + (uint32_t)i)) { if (!c_located) alive_c = false; alive_r = false; break; }
                 const uint32_t c = base2(s + (uint32_t)i);
-                if (alive_c) {
+                if (alive_c && !c_located) {
                     uint32_t ok, ol; c_occ2(ix, kc - 1, lc, c, ok, ol);
                     { const uint32_t l2 = pick4(ix.c_L2, c); kc = l2 + ok + 1; lc = l2 + ol; } alive_c = kc <= lc; n_occ_c += 2;
+                    if (inreg && alive_c && kc == lc && i > 0) resolve_unique(i - 1);
                 }
                 if (alive_r) {
                     uint32_t ok, ol; r_occ2(ix, kr, lr + 1, c, ok, ol);
                     { const uint32_t cm = pick5(ix.r_cum, c); kr = cm + ok + 1; lr = cm + ol; } alive_r = kr <= lr; n_occ_r += 2;
                 }
             }
-            if (alive_c) {                                    // shrink big intervals leftwards (alnse.c:246-258)
+            if (c_located) oc = make_uint4(kc, kc, s, 2);
+            if (alive_c && !c_located) {                      // shrink big intervals leftwards (alnse.c:246-258)
                 uint32_t ext = 0;
                 while (lc - kc > sp.max_seed && ext < s) {
                     if (is_n(s - ext - 1)) break;
@@ -498,7 +530,7 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
             uint64_t m = __ballot(v.w != 0);
             uint32_t sz = 0;
             if (v.w) {
-                uint32_t at = n + (uint32_t)__popcll(m & lt); w.u.sai.sp[which][at] = v.x; w.u.sai.ep[which][at] = v.y; w.u.sai.off[which][at] = v.z;
+                uint32_t at = n + (uint32_t)__popcll(m & lt); w.u.sai.sp[which][at] = v.x; w.u.sai.ep[which][at] = v.y; w.u.sai.off[which][at] = v.z | (v.w == 2 ? 0x80000000u : 0u);
                 sz = v.y - v.x + 1u;
                 if (which == 1 && !PE) { uint32_t skip = sz / 0x40000u; if (skip > 1) sz = (sz + skip - 1) / skip; }
                 if (sz > cap_total) sz = cap_total + 1u;
@@ -520,7 +552,8 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
     uint32_t n = 0;
     bool full = false;
     for (uint32_t i = 0; i < n_list[0] && !full; ++i) {
-        const uint32_t sp = w.u.sai.sp[0][i], off = w.u.sai.off[0][i];
+        const uint32_t sp = w.u.sai.sp[0][i], off = w.u.sai.off[0][i] & 0x7FFFFFFFu;
+        const bool located = (w.u.sai.off[0][i] >> 31) != 0;                  // k_seed resolved this one-row interval to its position
         uint32_t ep = w.u.sai.ep[0][i];
         if (PE && ep - sp > ap.max_locate) ep = sp + ap.max_locate;             // j - sp <= max_locate (alnse.c:523)
         for (uint64_t j0 = sp; j0 <= ep && !full; j0 += 64) {
@@ -528,7 +561,7 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
             uint64_t j = j0 + lane;
             bool in = j <= ep, keep = false;
             uint32_t pos = 0;
-            if (in) { pos = ix.c_sa[j] - off; keep = !(pos + L > ix.ref_len); }        // u32 wrap as in alnse.c:672-673
+            if (in) { pos = (located ? (uint32_t)j : ix.c_sa[j]) - off; keep = !(pos + L > ix.ref_len); }        // u32 wrap as in alnse.c:672-673
             uint64_t m = __ballot(keep);
             uint32_t rank = (uint32_t)__popcll(m & lt);
             if (keep && n + rank < cap_total) loci[n + rank] = pos;
@@ -1648,9 +1681,9 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
             small = tot[0] <= 16 && tot[1] <= 16 && tot[2] <= 16 && tot[3] <= 16;       // (uniform) the usual case
             if (small) {
                 // every seed writes the suffix-array rows of its interval where the row lanes of its list will look them up
-                for (uint32_t k2 = 0; k2 < sz; ++k2) { w.sp[l][inc - sz + k2] = v.x + k2; w.off[l][inc - sz + k2] = v.z; }
+                for (uint32_t k2 = 0; k2 < sz; ++k2) { w.sp[l][inc - sz + k2] = v.x + k2; w.off[l][inc - sz + k2] = v.z | (v.w == 2 ? 0x80000000u : 0u); }
             } else {
-                w.sp[l][slot] = v.x; w.off[l][slot] = v.z;
+                w.sp[l][slot] = v.x; w.off[l][slot] = v.z | (v.w == 2 ? 0x80000000u : 0u);        // bit 31: .x is a genome position already
                 w.pre[l][slot + 1] = inc;
                 if (slot == 0) w.pre[l][0] = 0;
             }
@@ -1668,8 +1701,8 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
                 const uint32_t tl = l == 0 ? tot[0] : l == 1 ? tot[1] : l == 2 ? tot[2] : tot[3];
                 bool keep = false; uint32_t p = 0;
                 if (x < tl) {
-                    const uint32_t j = w.sp[l][x];
-                    p = ((l & 1) ? ix.r_pos[j] : ix.c_sa[j]) - w.off[l][x];
+                    const uint32_t j = w.sp[l][x], of = w.off[l][x];
+                    p = ((of >> 31) ? j : (l & 1) ? ix.r_pos[j] : ix.c_sa[j]) - (of & 0x7FFFFFFFu);
                     keep = (l & 1) ? !(p > ix.ref_len || p + L > ix.ref_len) : !(p + L > ix.ref_len);       // alnse.c:672-673,715-717
                 }
                 stamp(SALT_CTR_LT_LOCATE);
@@ -1687,8 +1720,8 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
                 if (lane < tot[l]) {
                     uint32_t i = 0;
                     while (w.pre[l][i + 1] <= lane) ++i;                   // skips empty slots (equal prefix sums)
-                    const uint32_t j = w.sp[l][i] + (lane - w.pre[l][i]);
-                    const uint32_t p = ((l & 1) ? ix.r_pos[j] : ix.c_sa[j]) - w.off[l][i];
+                    const uint32_t j = w.sp[l][i] + (lane - w.pre[l][i]), of = w.off[l][i];
+                    const uint32_t p = ((of >> 31) ? j : (l & 1) ? ix.r_pos[j] : ix.c_sa[j]) - (of & 0x7FFFFFFFu);
                     pos4[l] = p;
                     keep4[l] = (l & 1) ? !(p > ix.ref_len || p + L > ix.ref_len) : !(p + L > ix.ref_len);   // alnse.c:672-673,715-717
                 }
@@ -1930,9 +1963,9 @@ k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
             for (int q = 0; q < 4; ++q) tot[q] = SHF(inc, 8 * q + 7);
             small = tot[0] <= 8 && tot[1] <= 8 && tot[2] <= 8 && tot[3] <= 8;
             if (small) {
-                for (uint32_t k2 = 0; k2 < sz; ++k2) { w.sp[l][inc - sz + k2] = v.x + k2; w.off[l][inc - sz + k2] = v.z; }
+                for (uint32_t k2 = 0; k2 < sz; ++k2) { w.sp[l][inc - sz + k2] = v.x + k2; w.off[l][inc - sz + k2] = v.z | (v.w == 2 ? 0x80000000u : 0u); }
             } else {
-                w.sp[l][slot] = v.x; w.off[l][slot] = v.z;
+                w.sp[l][slot] = v.x; w.off[l][slot] = v.z | (v.w == 2 ? 0x80000000u : 0u);        // bit 31: .x is a genome position already
                 w.pre[l][slot + 1] = inc;
                 if (slot == 0) w.pre[l][0] = 0;
             }
@@ -1947,8 +1980,8 @@ k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
                 const uint32_t tl = l == 0 ? tot[0] : l == 1 ? tot[1] : l == 2 ? tot[2] : tot[3];
                 bool keep = false; uint32_t p = 0;
                 if (x < tl) {
-                    const uint32_t j = w.sp[l][x];
-                    p = ((l & 1) ? ix.r_pos[j] : ix.c_sa[j]) - w.off[l][x];
+                    const uint32_t j = w.sp[l][x], of = w.off[l][x];
+                    p = ((of >> 31) ? j : (l & 1) ? ix.r_pos[j] : ix.c_sa[j]) - (of & 0x7FFFFFFFu);
                     keep = (l & 1) ? !(p > ix.ref_len || p + L > ix.ref_len) : !(p + L > ix.ref_len);       // alnse.c:672-673,715-717
                 }
                 const uint32_t km = HB(keep);
@@ -1963,8 +1996,8 @@ k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
                         if (x < tot[l]) {
                             uint32_t i = 0;
                             while (w.pre[l][i + 1] <= x) ++i;
-                            const uint32_t j = w.sp[l][i] + (x - w.pre[l][i]);
-                            p = ((l & 1) ? ix.r_pos[j] : ix.c_sa[j]) - w.off[l][i];
+                            const uint32_t j = w.sp[l][i] + (x - w.pre[l][i]), of = w.off[l][i];
+                            p = ((of >> 31) ? j : (l & 1) ? ix.r_pos[j] : ix.c_sa[j]) - (of & 0x7FFFFFFFu);
                             keep = (l & 1) ? !(p > ix.ref_len || p + L > ix.ref_len) : !(p + L > ix.ref_len);
                         }
                         const uint32_t km = HB(keep);

@@ -13,6 +13,9 @@
 //          1-in-8 samples by the reference's own LF walk (bwt.c:89-102) -- locate is then one load.
 //   r_pos  for every R suffix-array row the value Rbwt_back_bwt_sa() (rbwt.c:316-333) returns,
 //          again expanded once at attach time.
+//   text   the genome the C index was built over, 2 bits per base, 16 per word with the first base in the high bits
+//          (rebuilt at attach time from the expanded suffix array and the BWT: text[SA[row] - 1] = BWT[row]).  Once a seed's C
+//          interval is down to one row, the rest of its backward search is a comparison against this text.
 //   wlkt   W-mer table, 16 B per W-mer (W = 12..16, default 14, never above the seed length): for every W-mer
 //          the SA intervals both searches hold after consuming it (.x/.y = C, .z/.w = R; one gather serves both) -- C: LKT_lookup_sa on its last 12 bases
 //          (lookup.h:39-53, with that table's A-padded tail quirk) followed by W-12 steps of
@@ -37,7 +40,7 @@ struct ImageHeader {
     uint32_t lkt_len, lkt_n;
     uint32_t r_text_len, r_inv_sa0, r_cum[6];
     uint32_t ref_len, r_lkt_len;
-    uint64_t off_c_occ, off_c_sa, off_lkt, off_r_occ, off_r_pos, off_wlkt, off_ref, off_unused;
+    uint64_t off_c_occ, off_c_sa, off_lkt, off_r_occ, off_r_pos, off_wlkt, off_ref, off_text;
     uint64_t n_c_blocks, n_r_blocks;
     uint64_t reserved[7];
 };
@@ -46,7 +49,7 @@ static const uint64_t IMAGE_MAGIC = 0x53414c5447465839ull;          // "SALTGFX9
 // What kernels receive (by value): resolved pointers + scalars.
 struct IndexView {
     const COcc *c_occ; const uint32_t *c_sa; const uint32_t *lkt;
-    const ROcc *r_occ; const uint32_t *r_pos; const uint4 *wlkt; const uint32_t *ref;
+    const ROcc *r_occ; const uint32_t *r_pos; const uint4 *wlkt; const uint32_t *ref; const uint32_t *text;
     uint32_t c_primary, c_L2[5], c_seq_len;
     uint32_t r_text_len, r_inv_sa0, r_cum[6];
     uint32_t ref_len, lkt_len, r_lkt_len;

@@ -68,6 +68,7 @@ static void make_view(salt_gpu_index *ix)
     v.r_pos = reinterpret_cast<const uint32_t *>(b + h.off_r_pos);
     v.wlkt = reinterpret_cast<const uint4 *>(b + h.off_wlkt);
     v.ref = reinterpret_cast<const uint32_t *>(b + h.off_ref);
+    v.text = reinterpret_cast<const uint32_t *>(b + h.off_text);
     v.c_primary = h.c_primary; memcpy(v.c_L2, h.c_L2, sizeof v.c_L2); v.c_seq_len = h.c_seq_len;
     v.r_text_len = h.r_text_len; v.r_inv_sa0 = h.r_inv_sa0; memcpy(v.r_cum, h.r_cum, sizeof v.r_cum);
     v.ref_len = h.ref_len; v.lkt_len = h.lkt_len; v.r_lkt_len = h.r_lkt_len;
@@ -117,8 +118,8 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     hd.off_r_occ = off; off = align_up(off + hd.n_r_blocks * sizeof(ROcc), 256);
     hd.off_r_pos = off; off = align_up(off + ((uint64_t)h->r_text_len + 1) * 4, 256);
     hd.off_wlkt = off; off = align_up(off + (1ull << (2 * hd.r_lkt_len)) * 16, 256);
-    hd.off_unused = 0;
     hd.off_ref = off;   off = align_up(off + (ref_words + 4) * 4, 256);
+    hd.off_text = off;  off = align_up(off + ((uint64_t)h->c_seq_len / 16 + 4) * 4, 256);
     hd.bytes = off;
     ix->bytes = off;
 
@@ -165,6 +166,7 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
 #define CHK2(x) do { hipError_t e2 = (x); if (e2 != hipSuccess) { hipFree(ix->image); hipFree(d_sa_s); hipFree(d_r_sa); delete ix; \
     return fail(SALT_E_HIP, std::string(#x) + ": " + hipGetErrorString(e2)); } } while (0)
     CHK2(hipMemset(ix->image, 0, hd.off_wlkt));      // the W-mer table is fully written by its kernel
+    CHK2(hipMemset(ix->image + hd.off_text, 0, ((uint64_t)h->c_seq_len / 16 + 4) * 4));
     CHK2(hipMemcpy(ix->image, &hd, sizeof hd, hipMemcpyHostToDevice));
     CHK2(hipMemcpy(ix->image + hd.off_c_occ, cocc.data(), cocc.size() * sizeof(COcc), hipMemcpyHostToDevice));
     CHK2(hipMemcpy(ix->image + hd.off_lkt, h->lkt, (uint64_t)h->lkt_n * 4, hipMemcpyHostToDevice));
@@ -178,6 +180,7 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     CHK2(hipMemcpy(d_r_sa, h->r_sa, (uint64_t)h->r_n_sa * 4, hipMemcpyHostToDevice));
     launch_build_c_sa(ix->view, d_sa_s, h->c_sa_intv, reinterpret_cast<uint32_t *>(ix->image + hd.off_c_sa), nullptr);
     launch_build_r_pos(ix->view, d_r_sa, reinterpret_cast<uint32_t *>(ix->image + hd.off_r_pos), nullptr);
+    launch_build_text(ix->view, reinterpret_cast<uint32_t *>(ix->image + hd.off_text), nullptr);       // after c_sa (same stream)
     launch_build_wlkt(ix->view, hd.r_lkt_len, reinterpret_cast<uint4 *>(ix->image + hd.off_wlkt), nullptr);
     CHK2(hipGetLastError());
     CHK2(hipDeviceSynchronize());
@@ -319,6 +322,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     }
     SeedParams sp; sp.pg = pg; sp.n_reads = n_reads; sp.spr = spr; sp.l_seed = o->l_seed; sp.l_overlap = o->l_overlap;
     sp.max_seed = o->max_seed; sp.seed_only_ref = o->seed_only_ref;
+    if (getenv("SALT_GPU_DBG_NO_R")) sp.seed_only_ref = 1;     // timing experiments only
     if (n_reads > ws->max_reads) return fail(SALT_E_CAPACITY, "more reads than the workspace holds");
     AlignParams ap; ap.pg = pg; ap.n_reads = n_reads; ap.spr = spr; ap.l_seed = o->l_seed; ap.max_locate = o->max_locate; ap.max_hits = o->max_hits;
     ap.all_heavy = ws->all_heavy; ap.pe = pe; { const char *e = getenv("SALT_GPU_LIGHT_STOP"); ap.dbg_stop = e ? atoi(e) : 0; } ap.max_amb = pe ? 5u : 200u;

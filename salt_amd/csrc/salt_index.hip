@@ -4,6 +4,7 @@
 // kernels replace a data-dependent walk by one load:
 //   k_build_c_sa   bwt_sa / bwt_invPsi                 (Align_src/bwt.c:89-102, bwt.h:67-71)
 //   k_build_r_pos  Rbwt_back_bwt_sa                    (Align_src/rbwt.c:316-333)
+//   k_build_text   the indexed genome, from SA and BWT (text[SA[row] - 1] = BWT[row])
 //   k_build_wlkt   both searches' interval after the last W bases of a seed
 //                                                      (Align_src/rbwt.c:619-648, alnse.c:273-275)
 #include "salt_device.h"
@@ -26,6 +27,25 @@ k_build_c_sa(IndexView ix, const uint32_t *__restrict__ sa_sampled, uint32_t int
         }
     }
     out[j] = steps + sa_sampled[k / intv];          // sa_sampled[0] = 0xFFFFFFFF: wraps exactly as in C
+}
+
+// text[SA[row] - 1] = BWT[row]: the genome the C index was built over, 16 bases per word, first base in the high bits
+__global__ void __launch_bounds__(256)
+k_build_text(IndexView ix, uint32_t *__restrict__ out)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > ix.c_seq_len || j == ix.c_primary) return;             // the primary row holds '$'
+    uint32_t p = ix.c_sa[j];
+    if (p == 0xFFFFFFFFu) p = ix.c_seq_len;                        // row 0: the empty suffix (bwt_sa's sa[0] = -1)
+    if (p == 0 || p > ix.c_seq_len) return;
+    const uint32_t c = c_sym(ix, (uint32_t)(j < ix.c_primary ? j : j - 1)), i = p - 1;
+    atomicOr(out + (i >> 4), c << (30 - 2 * (i & 15u)));
+}
+
+void launch_build_text(const IndexView &ix, uint32_t *out, hipStream_t st)
+{
+    const uint64_t n = (uint64_t)ix.c_seq_len + 1;
+    hipLaunchKernelGGL(k_build_text, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, ix, out);
 }
 
 __global__ void __launch_bounds__(256)

@@ -96,6 +96,7 @@ void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const 
 // attach-time expansion kernels (salt_index.hip)
 void launch_build_c_sa(const IndexView &ix, const uint32_t *sa_sampled, uint32_t sa_intv, uint32_t *out, hipStream_t st);
 void launch_build_r_pos(const IndexView &ix, const uint32_t *r_sa, uint32_t *out, hipStream_t st);
+void launch_build_text(const IndexView &ix, uint32_t *out, hipStream_t st);
 void launch_build_wlkt(const IndexView &ix, uint32_t len, uint4 *out, hipStream_t st);
 
 } // namespace salt
