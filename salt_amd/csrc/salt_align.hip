@@ -238,7 +238,7 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
         if (L >= k && s + k <= L) {
             const uint32_t e = s + k - 1, W = ix.r_lkt_len;
             // seeds of up to 33 bases sit in 3 + 2 registers (bases wb*16 .. wb*16+47); longer ones read the record
-            const bool inreg = k <= 33;
+            const bool inreg = k <= 33, uniq = inreg && sp.resolve_unique;
             const uint32_t wb = s >> 4, nb = s >> 5;
             const uint32_t w0 = t2[wb], w1 = t2[wb + 1], w2 = t2[wb + 2];       // stays inside the record (PackGeom)
             const uint32_t n0 = tn[nb], n1 = tn[nb + 1];
@@ -301,7 +301,7 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
                 alive_c = ok;
                 if (ok) { kc = lc = p0 - m; c_located = true; }
             };
-            if (inreg && alive_c && kc == lc && i_r_start >= 0) resolve_unique(i_r_start);
+            if (uniq && alive_c && kc == lc && i_r_start >= 0) resolve_unique(i_r_start);
             // joint backward search over the seed head, newest base last (bwt.c:281-309, rbwt.c:619-648)
             for (int i = i_r_start; i >= 0 && ((alive_c && !c_located) || alive_r); --i) {
                 if (is_n(s + (uint32_t)i)) { if (!c_located) alive_c = false; alive_r = false; break; }
@@ -309,7 +309,7 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
                 if (alive_c && !c_located) {
                     uint32_t ok, ol; c_occ2(ix, kc - 1, lc, c, ok, ol);
                     { const uint32_t l2 = pick4(ix.c_L2, c); kc = l2 + ok + 1; lc = l2 + ol; } alive_c = kc <= lc; n_occ_c += 2;
-                    if (inreg && alive_c && kc == lc && i > 0) resolve_unique(i - 1);
+                    if (uniq && alive_c && kc == lc && i > 0) resolve_unique(i - 1);
                 }
                 if (alive_r) {
                     uint32_t ok, ol; r_occ2(ix, kr, lr + 1, c, ok, ol);

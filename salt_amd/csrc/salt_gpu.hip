@@ -322,7 +322,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     }
     SeedParams sp; sp.pg = pg; sp.n_reads = n_reads; sp.spr = spr; sp.l_seed = o->l_seed; sp.l_overlap = o->l_overlap;
     sp.max_seed = o->max_seed; sp.seed_only_ref = o->seed_only_ref;
-    if (getenv("SALT_GPU_DBG_NO_R")) sp.seed_only_ref = 1;     // timing experiments only
+    { static const bool off = getenv("SALT_GPU_NO_UNIQUE") && atoi(getenv("SALT_GPU_NO_UNIQUE")); sp.resolve_unique = !off; }
     if (n_reads > ws->max_reads) return fail(SALT_E_CAPACITY, "more reads than the workspace holds");
     AlignParams ap; ap.pg = pg; ap.n_reads = n_reads; ap.spr = spr; ap.l_seed = o->l_seed; ap.max_locate = o->max_locate; ap.max_hits = o->max_hits;
     ap.all_heavy = ws->all_heavy; ap.pe = pe; { const char *e = getenv("SALT_GPU_LIGHT_STOP"); ap.dbg_stop = e ? atoi(e) : 0; } ap.max_amb = pe ? 5u : 200u;

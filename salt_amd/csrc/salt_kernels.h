@@ -28,6 +28,7 @@ struct SeedParams {
     int32_t  l_seed, l_overlap;
     uint32_t max_seed;
     int32_t  seed_only_ref;
+    int32_t  resolve_unique;        // finish one-row C intervals against the genome text (k_seed)
     PackGeom pg;
 };
 
