@@ -18,6 +18,8 @@ ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 CONFIGS = {
     # name: genome_len, n_snps, k, n_reads, read_len
     "chr21": dict(genome_len=40_000_000, n_snps=190_000, k=21, n_reads=1_000_000, read_len=100),
+    # a tenth of GRCh38 (configs[2] scaled to what one gpurun call can index): 8 contigs, SNP density of snp144Common
+    "grch38_tenth": dict(genome_len=320_000_000, n_snps=1_520_000, k=21, n_reads=1_000_000, read_len=100, contigs=8),
     "mini": dict(genome_len=2_000_000, n_snps=9_500, k=21, n_reads=50_000, read_len=100),
     "tiny": dict(genome_len=200_000, n_snps=1_000, k=19, n_reads=4_000, read_len=100),
 }
@@ -52,24 +54,35 @@ def make_snps(genome, n_snps, seed=144):
     return pos.astype(np.int64), mask
 
 
-def write_fasta(path, name, genome):
-    s = ACGT[genome]
+def contig_bounds(n, contigs):
+    """Start offsets (contigs + 1 of them) of `contigs` near-equal contigs named synth1 .. synthN over n bases."""
+    return [n * i // contigs for i in range(contigs + 1)]
+
+
+def write_fasta(path, name, genome, contigs=1):
+    b = contig_bounds(len(genome), contigs)
     with open(path, "wb") as f:
-        f.write(b">" + name.encode() + b"\n")
-        w = 80
-        full = len(s) // w * w
-        body = np.concatenate([s[:full].reshape(-1, w), np.full((full // w, 1), 10, dtype=np.uint8)], axis=1)
-        f.write(body.tobytes())
-        if full < len(s):
-            f.write(s[full:].tobytes() + b"\n")
+        for ci in range(contigs):
+            s = ACGT[genome[b[ci]:b[ci + 1]]]
+            f.write(b">" + (name if contigs == 1 else "synth%d" % (ci + 1)).encode() + b"\n")
+            w = 80
+            full = len(s) // w * w
+            body = np.concatenate([s[:full].reshape(-1, w), np.full((full // w, 1), 10, dtype=np.uint8)], axis=1)
+            f.write(body.tobytes())
+            if full < len(s):
+                f.write(s[full:].tobytes() + b"\n")
 
 
-def write_snps(path, name, genome, pos, mask):
+def write_snps(path, name, genome, pos, mask, contigs=1):
     lines = []
-    nm = name.encode()
+    b = contig_bounds(len(genome), contigs)
+    ci = 0
     for p, m in zip(pos.tolist(), mask.tolist()):
-        al = b"/".join(bytes([ACGT[b]]) for b in range(4) if (m >> b) & 1)
-        lines.append(b"%s\t%d\t%s\t%s\n" % (nm, p + 1, al, bytes([ACGT[genome[p]]])))
+        while p >= b[ci + 1]:
+            ci += 1
+        nm = (name if contigs == 1 else "synth%d" % (ci + 1)).encode()
+        al = b"/".join(bytes([ACGT[x]]) for x in range(4) if (m >> x) & 1)
+        lines.append(b"%s\t%d\t%s\t%s\n" % (nm, p - b[ci] + 1, al, bytes([ACGT[genome[p]]])))
     with open(path, "wb") as f:
         f.write(b"".join(lines))
 
@@ -187,7 +200,8 @@ def prepare(config, cache_dir):
     """Generates (or finds cached) genome FASTA + SNP file + index for `config`; returns paths."""
     from . import api
     import ctypes
-    c = CONFIGS[config]
+    c = dict(CONFIGS[config])
+    nc = c.setdefault("contigs", 1)
     d = os.path.join(cache_dir, "salt_%s_g%d_s%d_k%d" % (config, c["genome_len"], c["n_snps"], c["k"]))
     os.makedirs(d, exist_ok=True)
     fa, snp, prefix = os.path.join(d, "genome.fa"), os.path.join(d, "snps.txt"), os.path.join(d, "idx")
@@ -195,8 +209,8 @@ def prepare(config, cache_dir):
     genome = make_genome(c["genome_len"])
     pos, mask = make_snps(genome, c["n_snps"])
     if not os.path.exists(done):
-        write_fasta(fa, "synth1", genome)
-        write_snps(snp, "synth1", genome, pos, mask)
+        write_fasta(fa, "synth1", genome, nc)
+        write_snps(snp, "synth1", genome, pos, mask, nc)
         lib = api.host_lib()
         lib.salt_idx_build.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
         lib.salt_idx_last_error.restype = ctypes.c_char_p
