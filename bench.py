@@ -96,25 +96,32 @@ def main():
     # ---- device index: rank 0 packs, the others get the image by one broadcast over RCCL ----
     t0 = time.time()
     idx = None
+    nbytes = cbytes = 0
     if rank == 0:
         idx = salt_amd.Index.reload(w["prefix"], rebuild_lkt=False)
         aln = salt_amd.GpuAligner(idx, device=local_rank, max_reads=n_reads, max_bases=n_reads * L)
-        ptr, nbytes = aln.image()
-    img = None
+        nbytes = aln.image()[1]
+        cbytes = aln.image_compact()[1]
     if world > 1:
-        sz = torch.tensor([nbytes if rank == 0 else 0], dtype=torch.int64, device=dev)
+        # only the compact part travels (FM-indexes, suffix arrays, mixRef, 2-bit text); the 16-byte W-mer table that
+        # ends the image is a function of it and each rank tabulates its own copy
+        sz = torch.tensor([cbytes], dtype=torch.int64, device=dev)
         dist.broadcast(sz, 0)
-        nbytes = int(sz.item())
-        img = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        cbytes = int(sz.item())
+        img = torch.empty(cbytes, dtype=torch.uint8, device=dev)
         if rank == 0:
-            aln.image_copy(img.data_ptr(), nbytes)
-        dist.broadcast(img, 0)
+            aln.image_copy(img.data_ptr(), cbytes)
+        chunk = 1 << 30
+        for o in range(0, cbytes, chunk):
+            dist.broadcast(img[o:o + chunk], 0)
         if rank != 0:
             aln = salt_amd.GpuAligner(None, device=local_rank, max_reads=n_reads, max_bases=n_reads * L,
-                                      image=(img.data_ptr(), nbytes))
+                                      compact=(img.data_ptr(), cbytes))
+        torch.cuda.synchronize()
+        del img
     torch.cuda.synchronize()
     if rank == 0:
-        log("device index: %.2f GiB, attach+broadcast %.1f s" % (nbytes / 2**30, time.time() - t0))
+        log("device index: %.2f GiB (compact part, the only thing broadcast: %.2f GiB), attach+broadcast %.1f s" % (nbytes / 2**30, cbytes / 2**30, time.time() - t0))
 
     opt = salt_amd.AlnOpt(l_seed=cfg["k"])
     d_seqs = torch.from_numpy(seqs).to(dev)

@@ -119,11 +119,19 @@ void salt_gpu_index_detach(salt_gpu_index_t *ix);
  * driver can broadcast it (RCCL) instead of re-packing on every rank. */
 int  salt_gpu_index_image(const salt_gpu_index_t *ix, void **dev_ptr, uint64_t *bytes);
 int  salt_gpu_index_attach_image(void *dev_ptr, uint64_t bytes, int device, salt_gpu_index_t **out);
-/* Replicates the packed image of `src` (attached on devices[0]) onto devices[1..n): one RCCL broadcast
- * over xGMI inside this process (ncclCommInitAll + grouped ncclBroadcast), then attaches each copy.
+/* The image ends with the W-mer table (16 B x 4^W: 16 GiB at the default W = 15), which is a pure function of what
+ * precedes it.  The part before it is the COMPACT image -- what a multi-GPU driver needs to move: broadcast
+ * [dev_ptr, dev_ptr + bytes) of salt_gpu_index_image_compact, then salt_gpu_index_attach_compact on each receiver
+ * allocates the full image, copies the compact part in and tabulates the W-mer table there (it owns the result;
+ * the broadcast buffer may be freed afterwards). */
+int  salt_gpu_index_image_compact(const salt_gpu_index_t *ix, void **dev_ptr, uint64_t *bytes);
+int  salt_gpu_index_attach_compact(const void *dev_ptr, uint64_t bytes, int device, salt_gpu_index_t **out);
+/* Replicates the image of `src` (attached on devices[0]) onto devices[1..n): one RCCL broadcast of the compact part
+ * over xGMI inside this process (ncclCommInitAll + grouped ncclBroadcast); each device then builds its W-mer table.
  * out[0] = src; out[i] owns its copy and is released with salt_gpu_index_detach. */
 int  salt_gpu_index_replicate(salt_gpu_index_t *src, const int *devices, int n, salt_gpu_index_t **out);
-/* device-to-device copy of the image into a caller-owned buffer of >= bytes (e.g. a broadcast buffer) */
+/* device-to-device copy into a caller-owned buffer (e.g. a broadcast buffer): the full image when dst_bytes >= its
+ * size, else its compact part (dst_bytes >= the compact size) */
 int  salt_gpu_index_image_copy(const salt_gpu_index_t *ix, void *dst_dev_ptr, uint64_t dst_bytes);
 
 /* ---- per-batch work ----------------------------------------------------------------------- */
@@ -169,6 +177,8 @@ int  salt_gpu_ws_heavy_reads(salt_gpu_ws_t *ws, uint32_t *ids, uint32_t cap, uin
 /* Plain device buffers for callers without a HIP runtime of their own (resident inputs / results, image copies). */
 int  salt_gpu_buffer_alloc(int device, uint64_t bytes, void **dev_ptr);
 int  salt_gpu_buffer_free(int device, void *dev_ptr);
+/* *equal = 1 iff the two device buffers hold the same bytes (bytes % 4 == 0); tests compare index images with it */
+int  salt_gpu_buffer_equal(int device, const void *a, const void *b, uint64_t bytes, int *equal);
 
 /* Unit entry of the candidate rule the kernels evaluate on UNSORTED lists: case i has candidates
  * pos/val[offs[i]..offs[i+1]) (val > vmax = no candidate) and the incoming bound bound_in[i].  mode 0: gap-free rule

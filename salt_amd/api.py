@@ -131,6 +131,8 @@ def gpu_lib():
         lib.salt_gpu_align_pe_resident.argtypes = [ctypes.c_void_p, ctypes.POINTER(_AlnOpt), ctypes.POINTER(_PeOpt), ctypes.c_uint32, ctypes.c_uint32,
                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.salt_gpu_ws_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        lib.salt_gpu_index_image_compact.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+        lib.salt_gpu_index_attach_compact.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         lib.salt_gpu_index_image_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
         lib.salt_gpu_ws_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.salt_gpu_ws_queue_counts.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
@@ -277,12 +279,15 @@ KERNELS = ("k_pack", "k_seed", "k_light", "k_heavy", "k_gap", "k_gapfin", "k_cig
 class GpuAligner:
     """Device copy of the index + one batch workspace on one GPU."""
 
-    def __init__(self, index=None, device=0, max_reads=100000, max_bases=None, image=None):
-        """index: a host Index to re-pack and upload, or image=(device_ptr, bytes): an already packed
-        device image (e.g. received by an RCCL broadcast) that stays owned by the caller."""
+    def __init__(self, index=None, device=0, max_reads=100000, max_bases=None, image=None, compact=None):
+        """index: a host Index to re-pack and upload; or image=(device_ptr, bytes): an already packed full
+        device image that stays owned by the caller; or compact=(device_ptr, bytes): the compact part of an image
+        (e.g. received by an RCCL broadcast), from which this device builds its own full image."""
         lib = gpu_lib()
         self._ix = ctypes.c_void_p()
-        if image is not None:
+        if compact is not None:
+            _gpu_check(lib.salt_gpu_index_attach_compact(compact[0], compact[1], device, ctypes.byref(self._ix)))
+        elif image is not None:
             _gpu_check(lib.salt_gpu_index_attach_image(image[0], image[1], device, ctypes.byref(self._ix)))
         else:
             _gpu_check(lib.salt_gpu_index_attach(index.view, device, ctypes.byref(self._ix)))
@@ -299,6 +304,12 @@ class GpuAligner:
     def image(self):
         p, n = ctypes.c_void_p(), ctypes.c_uint64()
         _gpu_check(gpu_lib().salt_gpu_index_image(self._ix, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def image_compact(self):
+        """(device pointer, bytes) of the part of the image a multi-GPU driver broadcasts (everything but the W-mer table)."""
+        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+        _gpu_check(gpu_lib().salt_gpu_index_image_compact(self._ix, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
 
     def image_copy(self, dst_ptr, dst_bytes):

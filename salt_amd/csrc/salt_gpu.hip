@@ -117,9 +117,10 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     hd.off_lkt = off;   off = align_up(off + (uint64_t)h->lkt_n * 4, 256);
     hd.off_r_occ = off; off = align_up(off + hd.n_r_blocks * sizeof(ROcc), 256);
     hd.off_r_pos = off; off = align_up(off + ((uint64_t)h->r_text_len + 1) * 4, 256);
-    hd.off_wlkt = off; off = align_up(off + (1ull << (2 * hd.r_lkt_len)) * 16, 256);
     hd.off_ref = off;   off = align_up(off + (ref_words + 4) * 4, 256);
     hd.off_text = off;  off = align_up(off + ((uint64_t)h->c_seq_len / 16 + 4) * 4, 256);
+    // last: everything before it is the COMPACT image, from which the W-mer table can be rebuilt on any device
+    hd.off_wlkt = off; off = align_up(off + (1ull << (2 * hd.r_lkt_len)) * 16, 256);
     hd.bytes = off;
     ix->bytes = off;
 
@@ -165,8 +166,7 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     uint32_t *d_sa_s = nullptr, *d_r_sa = nullptr;
 #define CHK2(x) do { hipError_t e2 = (x); if (e2 != hipSuccess) { hipFree(ix->image); hipFree(d_sa_s); hipFree(d_r_sa); delete ix; \
     return fail(SALT_E_HIP, std::string(#x) + ": " + hipGetErrorString(e2)); } } while (0)
-    CHK2(hipMemset(ix->image, 0, hd.off_wlkt));      // the W-mer table is fully written by its kernel
-    CHK2(hipMemset(ix->image + hd.off_text, 0, ((uint64_t)h->c_seq_len / 16 + 4) * 4));
+    CHK2(hipMemset(ix->image, 0, hd.off_wlkt));      // the W-mer table (last) is fully written by its kernel
     CHK2(hipMemcpy(ix->image, &hd, sizeof hd, hipMemcpyHostToDevice));
     CHK2(hipMemcpy(ix->image + hd.off_c_occ, cocc.data(), cocc.size() * sizeof(COcc), hipMemcpyHostToDevice));
     CHK2(hipMemcpy(ix->image + hd.off_lkt, h->lkt, (uint64_t)h->lkt_n * 4, hipMemcpyHostToDevice));
@@ -215,6 +215,42 @@ extern "C" int salt_gpu_index_attach_image(void *dev_ptr, uint64_t bytes, int de
     if (e != hipSuccess) { delete ix; return fail(SALT_E_HIP, std::string("hipMemcpy(image header): ") + hipGetErrorString(e)); }
     if (ix->hdr.magic != IMAGE_MAGIC || ix->hdr.bytes != bytes) { delete ix; return fail(SALT_E_INDEX, "not a salt device-index image"); }
     make_view(ix);
+    *out = ix;
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_index_image_compact(const salt_gpu_index_t *ix, void **dev_ptr, uint64_t *bytes)
+{
+    if (!ix || !dev_ptr || !bytes) return fail(SALT_E_INVAL, "null argument");
+    *dev_ptr = ix->image; *bytes = ix->hdr.off_wlkt;
+    return SALT_OK;
+}
+
+// the W-mer table of an image whose compact part is in place (device of ix current)
+static int rebuild_wlkt(salt_gpu_index *ix)
+{
+    launch_build_wlkt(ix->view, ix->hdr.r_lkt_len, reinterpret_cast<uint4 *>(ix->image + ix->hdr.off_wlkt), nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_index_attach_compact(const void *dev_ptr, uint64_t bytes, int device, salt_gpu_index_t **out)
+{
+    if (!dev_ptr || !out || bytes < sizeof(ImageHeader)) return fail(SALT_E_INVAL, "bad image");
+    HIPCHK(hipSetDevice(device));
+    ImageHeader hd;
+    HIPCHK(hipMemcpy(&hd, dev_ptr, sizeof hd, hipMemcpyDeviceToHost));
+    if (hd.magic != IMAGE_MAGIC || hd.off_wlkt != bytes || hd.bytes < bytes) return fail(SALT_E_INDEX, "not a compact salt device-index image");
+    salt_gpu_index *ix = new salt_gpu_index();
+    ix->device = device; ix->bytes = hd.bytes; ix->owns = true; ix->hdr = hd;
+    hipError_t e = hipMalloc((void **)&ix->image, hd.bytes);
+    if (e != hipSuccess) { delete ix; return fail(SALT_E_NOMEM, std::string("hipMalloc(index image): ") + hipGetErrorString(e)); }
+    e = hipMemcpy(ix->image, dev_ptr, bytes, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { hipFree(ix->image); delete ix; return fail(SALT_E_HIP, std::string("hipMemcpy(compact image): ") + hipGetErrorString(e)); }
+    make_view(ix);
+    int rc = rebuild_wlkt(ix);
+    if (rc) { hipFree(ix->image); delete ix; return rc; }
     *out = ix;
     return SALT_OK;
 }
@@ -418,7 +454,7 @@ extern "C" int salt_gpu_index_replicate(salt_gpu_index_t *src, const int *device
     for (int i = 0; i < n; ++i) { HIPCHK(hipSetDevice(devices[i])); HIPCHK(hipStreamCreate(&st[i])); }
     ncclGroupStart();
     for (int i = 0; i < n; ++i) {
-        rc = ncclBroadcast(buf[i], buf[i], src->bytes, ncclUint8, 0, comm[i], st[i]);
+        rc = ncclBroadcast(buf[i], buf[i], src->hdr.off_wlkt, ncclUint8, 0, comm[i], st[i]);      // the compact part only
         if (rc != ncclSuccess) { ncclGroupEnd(); return fail(SALT_E_HIP, std::string("ncclBroadcast: ") + ncclGetErrorString(rc)); }
     }
     rc = ncclGroupEnd();
@@ -428,15 +464,21 @@ extern "C" int salt_gpu_index_replicate(salt_gpu_index_t *src, const int *device
         int r2 = salt_gpu_index_attach_image(buf[i], src->bytes, devices[i], &out[i]);
         if (r2) return r2;
         out[i]->owns = true;
+        HIPCHK(hipSetDevice(devices[i]));
+        r2 = rebuild_wlkt(out[i]);                                  // each device tabulates its own W-mer table
+        if (r2) return r2;
     }
+    HIPCHK(hipSetDevice(devices[0]));
     return SALT_OK;
 }
 
 extern "C" int salt_gpu_index_image_copy(const salt_gpu_index_t *ix, void *dst, uint64_t dst_bytes)
 {
-    if (!ix || !dst || dst_bytes < ix->bytes) return fail(SALT_E_INVAL, "destination too small for the index image");
+    if (!ix || !dst) return fail(SALT_E_INVAL, "null argument");
+    const uint64_t n = dst_bytes >= ix->bytes ? ix->bytes : ix->hdr.off_wlkt;       // the full image, or its compact part
+    if (dst_bytes < n) return fail(SALT_E_INVAL, "destination too small for the (compact) index image");
     HIPCHK(hipSetDevice(ix->device));
-    HIPCHK(hipMemcpy(dst, ix->image, ix->bytes, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(dst, ix->image, n, hipMemcpyDeviceToDevice));
     return SALT_OK;
 }
 
@@ -571,6 +613,28 @@ extern "C" int salt_gpu_buffer_free(int device, void *dev_ptr)
     if (!dev_ptr) return SALT_OK;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(dev_ptr));
+    return SALT_OK;
+}
+
+__global__ void k_buffer_diff(const uint32_t *a, const uint32_t *b, uint64_t n_words, unsigned long long *n_diff)
+{
+    unsigned long long d = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) d += a[i] != b[i];
+    if (d) atomicAdd(n_diff, d);
+}
+
+extern "C" int salt_gpu_buffer_equal(int device, const void *a, const void *b, uint64_t bytes, int *equal)
+{
+    if (!a || !b || !equal || (bytes & 3u)) return fail(SALT_E_INVAL, "bad buffer compare arguments (bytes must be a multiple of 4)");
+    HIPCHK(hipSetDevice(device));
+    unsigned long long *d = nullptr, h = 0;
+    HIPCHK(hipMalloc((void **)&d, 8));
+    HIPCHK(hipMemset(d, 0, 8));
+    hipLaunchKernelGGL(k_buffer_diff, dim3(4096), dim3(256), 0, nullptr, static_cast<const uint32_t *>(a), static_cast<const uint32_t *>(b), bytes / 4, d);
+    hipError_t e = hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return fail(SALT_E_HIP, std::string("buffer compare: ") + hipGetErrorString(e));
+    *equal = h == 0;
     return SALT_OK;
 }
 

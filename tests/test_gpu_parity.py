@@ -316,3 +316,39 @@ def test_gpu_attach_to_a_copied_image_gives_the_same_rows(lam):
             other.close()
         lib.salt_gpu_buffer_free(0, buf)
     assert salt_amd.sam_text(idx, opt, names, seqs, offs, quals, a) == salt_amd.sam_text(idx, opt, names, seqs, offs, quals, b)
+
+
+def test_gpu_attach_to_the_compact_image_rebuilds_the_kmer_table(lam):
+    """What bench.py's ranks > 0 and salt_gpu_index_replicate do: only the compact part of the image (everything but the
+    W-mer table) is copied; the receiver tabulates the table itself, owns the result (the transfer buffer is freed before
+    aligning), and its full image equals the sender's byte for byte."""
+    import ctypes
+    salt_amd, idx, aln, (names, seqs, offs, quals) = lam
+    lib = salt_amd.gpu_lib()
+    lib.salt_gpu_buffer_alloc.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+    lib.salt_gpu_buffer_free.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    lib.salt_gpu_buffer_equal.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int)]
+    _, nbytes = aln.image()
+    cptr, cbytes = aln.image_compact()
+    assert 0 < cbytes < nbytes
+    buf = ctypes.c_void_p()
+    assert lib.salt_gpu_buffer_alloc(0, cbytes, ctypes.byref(buf)) == 0, lib.salt_gpu_last_error()
+    try:
+        aln.image_copy(buf.value, cbytes)
+        other = salt_amd.GpuAligner(None, device=0, max_reads=2048, compact=(buf.value, cbytes))
+    finally:
+        lib.salt_gpu_buffer_free(0, buf)
+    try:
+        optr, obytes = other.image()
+        same = ctypes.c_int(0)
+        assert obytes == nbytes
+        assert lib.salt_gpu_buffer_equal(0, aln.image()[0], optr, nbytes, ctypes.byref(same)) == 0, lib.salt_gpu_last_error()
+        assert same.value == 1
+        opt, _ = salt_amd.AlnOpt.from_argv(read_cases()["se_default"], idx.l_seed)
+        a = aln.alnse_core1(opt, seqs, offs)
+        b = other.alnse_core1(opt, seqs, offs)
+    finally:
+        other.close()
+    assert salt_amd.sam_text(idx, opt, names, seqs, offs, quals, a) == salt_amd.sam_text(idx, opt, names, seqs, offs, quals, b)
+    with pytest.raises(salt_amd.SaltError):
+        salt_amd.GpuAligner(None, device=0, max_reads=64, compact=(cptr, cbytes - 256))
