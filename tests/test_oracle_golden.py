@@ -27,6 +27,15 @@ def test_oracle_sam_matches_reference(case, oracle_cli, tmp_path):
     assert out == want
 
 
+@pytest.mark.parametrize("case,args", [("span_default", ["-d", "-c"]), ("span_r5", ["-d", "-c", "-r", "5"])])
+def test_oracle_sam_matches_reference_on_contig_boundary_reads(case, args, oracle_cli):
+    """Reads straddling the contig boundary, hanging over the genome's start / end, and at contig ends
+    (tests/golden/make_span_fixture.py): the reference's own SAM for them."""
+    out = subprocess.run([oracle_cli] + args + [os.path.join(LAMBDA, "idx"), os.path.join(LAMBDA, "reads_span.fq")],
+                         check=True, capture_output=True).stdout
+    assert out == open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
+
+
 def test_oracle_threads_do_not_change_output(oracle_cli):
     base = [os.path.join(LAMBDA, "idx"), os.path.join(LAMBDA, "reads_se.fq")]
     a = subprocess.run([oracle_cli, "-d", "-c"] + base, check=True, capture_output=True).stdout

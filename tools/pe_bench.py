@@ -12,7 +12,7 @@ from salt_amd import workload
 import oracle_py
 
 cache = os.environ.get("SALT_BENCH_CACHE", "/tmp/salt_bench_cache")
-w = workload.prepare("chr21", cache)
+w = workload.prepare(os.environ.get("SALT_PE_WORKLOAD", "chr21"), cache)
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
 n_check = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 L = 150
