@@ -25,6 +25,17 @@ def read_cases():
     return cases
 
 
+# fixtures beyond cases.txt, each with its own FASTQ (tests/golden/make_span_fixture.py, make_ragged_fixture.py):
+# name -> (salt arguments, FASTQ file names under tests/golden/lambda)
+EXTRA_CASES = {
+    "span_default": (["-d", "-c"], ["reads_span.fq"]),
+    "span_r5": (["-d", "-c", "-r", "5"], ["reads_span.fq"]),
+    "ragged_default": (["-d", "-c"], ["reads_ragged.fq"]),
+    "ragged_r7_s10": (["-d", "-c", "-r", "7", "-s", "10"], ["reads_ragged.fq"]),
+    "ragged_pe": (["-d", "-p", "-c", "-a", "300", "-b", "700"], ["reads_ragged_pe_1.fq", "reads_ragged_pe_2.fq"]),
+}
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     """The CPU restatement (checker only).  Built on demand with gcc."""

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import LAMBDA, read_cases
+from conftest import EXTRA_CASES, LAMBDA, read_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -138,24 +138,29 @@ def test_cli_salt_matches_reference_golden(tmp_path):
         assert got == want, case
 
 
-@pytest.mark.parametrize("case,args", [("span_default", ["-d", "-c"]), ("span_r5", ["-d", "-c", "-r", "5"])])
-def test_gpu_and_cli_match_reference_on_contig_boundary_reads(case, args, lam, tmp_path):
-    """Reads straddling the contig boundary, hanging over the genome's start / end (candidate positions wrap below 0 or run
-    past mixRef.l), and lying exactly at contig ends: the reference's own SAM (tests/golden/make_span_fixture.py), through
-    the C ABI and through the C++ CLI."""
+@pytest.mark.parametrize("case", sorted(EXTRA_CASES))
+def test_gpu_and_cli_match_reference_on_boundary_and_ragged_reads(case, lam, tmp_path):
+    """The reference's own SAM (a) for reads straddling the contig boundary, hanging over the genome's start / end (candidate
+    positions wrap below 0 or run past mixRef.l) and lying exactly at contig ends (make_span_fixture.py); (b) for mixed read
+    lengths 19..300 bp, SE and PE with unequal mates (make_ragged_fixture.py) -- through the C ABI and through the C++ CLI."""
     salt_amd, idx, aln, _ = lam
-    names, seqs, offs, quals = salt_amd.read_fastq(os.path.join(LAMBDA, "reads_span.fq"))
-    opt, _ = salt_amd.AlnOpt.from_argv(args, idx.l_seed)
-    res = aln.alnse_core1(opt, seqs, offs)
+    args, files = EXTRA_CASES[case]
+    paths = [os.path.join(LAMBDA, f) for f in files]
     want = open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
-    got = salt_amd.sam_text(idx, opt, names, seqs, offs, quals, res)
+    opt, _ = salt_amd.AlnOpt.from_argv(args, idx.l_seed)
+    if len(paths) == 1:
+        names, seqs, offs, quals = salt_amd.read_fastq(paths[0])
+        got = salt_amd.sam_text(idx, opt, names, seqs, offs, quals, aln.alnse_core1(opt, seqs, offs))
+    else:
+        names, seqs, offs, quals = salt_amd.interleave_pairs(salt_amd.read_fastq(paths[0]), salt_amd.read_fastq(paths[1]))
+        got = salt_amd.sam_text_pe(idx, opt, names, seqs, offs, quals, aln.alnpe_core1(opt, idx, seqs, offs))
     assert got == want
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     salt, salt_idx = os.path.join(root, "salt_amd", "bin", "salt"), os.path.join(root, "salt_amd", "bin", "salt-idx")
     prefix = str(tmp_path / "idx")
     subprocess.run([salt_idx, "-k", "19", os.path.join(LAMBDA, "genome.fa"), os.path.join(LAMBDA, "snps.txt"), prefix],
                    check=True, stderr=subprocess.DEVNULL)
-    out = subprocess.run([salt] + args + [prefix, os.path.join(LAMBDA, "reads_span.fq")], check=True, capture_output=True).stdout
+    out = subprocess.run([salt] + args + [prefix] + paths, check=True, capture_output=True).stdout
     assert b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG")) == want
 
 

@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import LAMBDA, GOLDEN, read_cases
+from conftest import EXTRA_CASES, LAMBDA, GOLDEN, read_cases
 
 SE_CASES = [c for c in read_cases() if c.startswith("se_")]
 
@@ -27,11 +27,12 @@ def test_oracle_sam_matches_reference(case, oracle_cli, tmp_path):
     assert out == want
 
 
-@pytest.mark.parametrize("case,args", [("span_default", ["-d", "-c"]), ("span_r5", ["-d", "-c", "-r", "5"])])
-def test_oracle_sam_matches_reference_on_contig_boundary_reads(case, args, oracle_cli):
-    """Reads straddling the contig boundary, hanging over the genome's start / end, and at contig ends
-    (tests/golden/make_span_fixture.py): the reference's own SAM for them."""
-    out = subprocess.run([oracle_cli] + args + [os.path.join(LAMBDA, "idx"), os.path.join(LAMBDA, "reads_span.fq")],
+@pytest.mark.parametrize("case", sorted(EXTRA_CASES))
+def test_oracle_sam_matches_reference_on_boundary_and_ragged_reads(case, oracle_cli):
+    """The reference's own SAM for reads straddling the contig boundary / hanging over the genome's ends
+    (make_span_fixture.py) and for mixed read lengths 19..300 bp, SE and PE (make_ragged_fixture.py)."""
+    args, files = EXTRA_CASES[case]
+    out = subprocess.run([oracle_cli] + args + [os.path.join(LAMBDA, "idx")] + [os.path.join(LAMBDA, f) for f in files],
                          check=True, capture_output=True).stdout
     assert out == open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
 
