@@ -156,6 +156,11 @@ int  salt_gpu_align_pe(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, const salt_
 /* Same on device-resident buffers (2 * n_pairs reads); only enqueues on `hip_stream`. */
 int  salt_gpu_align_pe_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, const salt_pe_opt_t *pe, uint32_t n_pairs,
                                 uint32_t max_read_len, const void *d_seqs, const void *d_offs, void *d_results, void *hip_stream);
+/* Mate rescues of the LAST paired batch that could not be finished as the reference would (their banded traceback needs
+ * a band wider than the build's row buffers: possible only for reads longer than ~270 bases with a gap of that size).
+ * salt_gpu_align_pe fails with SALT_E_CAPACITY when this is non-zero; callers of the resident entry check it themselves
+ * (it synchronises the device). */
+int  salt_gpu_ws_pe_overflow(salt_gpu_ws_t *ws, uint32_t *n);
 
 /* Same work on device-resident buffers; only enqueues on `hip_stream` (a hipStream_t, NULL = default). */
 int  salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, uint32_t n_reads,

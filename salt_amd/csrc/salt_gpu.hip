@@ -43,7 +43,7 @@ struct salt_gpu_ws {
     // paired end (allocated on first use)
     uint8_t *d_pe_scr = nullptr;                       // per persistent block: PE_LOCI_CAP loci + distances
     PePair *d_pairs = nullptr; PeSwReq *d_req = nullptr; PeSwRes *d_swres = nullptr; uint32_t *d_pctl = nullptr;
-    uint8_t *d_sw_scr = nullptr; uint32_t sw_blocks = 0; uint32_t pe_pairs_cap = 0;
+    uint8_t *d_sw_scr = nullptr; uint64_t sw_scr_bytes = 0; uint32_t sw_blocks = 0; uint32_t pe_pairs_cap = 0;
     uint32_t *d_pcq = nullptr;                         // k_cigar items of the gapped, not rescued mates
     uint32_t heavy_blocks = 2048;
     int all_heavy = 0;
@@ -578,13 +578,17 @@ extern "C" int salt_gpu_diag_ssw(uint32_t n_cases, const uint8_t *aware, const u
     HIPCHK(hipMalloc((void **)&d_offs, ((uint64_t)n_cases + 1) * 4)); HIPCHK(hipMemcpy(d_offs, read_offs, ((uint64_t)n_cases + 1) * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void **)&d_req, (uint64_t)n_cases * sizeof(PeSwReq))); HIPCHK(hipMemcpy(d_req, h_req.data(), (uint64_t)n_cases * sizeof(PeSwReq), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void **)&d_res, (uint64_t)n_cases * sizeof(PeSwRes)));
-    HIPCHK(hipMalloc((void **)&d_scr, (uint64_t)blocks * 8 * SW_SCRATCH_BYTES));
-    const uint32_t ctl[2] = { n_cases, 0 };
-    HIPCHK(hipMalloc((void **)&d_ctl, 8)); HIPCHK(hipMemcpy(d_ctl, ctl, 8, hipMemcpyHostToDevice));
+    uint64_t diag_max_win = 1;
+    for (uint32_t i = 0; i < n_cases; ++i) if (ref_offs[i + 1] - ref_offs[i] > diag_max_win) diag_max_win = ref_offs[i + 1] - ref_offs[i];
+    SwGeom geom = sw_geom(diag_max_len, diag_max_win, 1);
+    geom.n_blocks = blocks;
+    HIPCHK(hipMalloc((void **)&d_scr, (uint64_t)blocks * 8 * geom.group_bytes));
+    const uint32_t ctl[3] = { n_cases, 0, 0 };
+    HIPCHK(hipMalloc((void **)&d_ctl, 12)); HIPCHK(hipMemcpy(d_ctl, ctl, 12, hipMemcpyHostToDevice));
     IndexView v; memset(&v, 0, sizeof v);
     v.ref = d_ref; v.ref_len = (uint32_t)n_sym;
     if (diag_max_len > SALT_MAX_READ_LEN) return fail(SALT_E_INVAL, "read longer than SALT_MAX_READ_LEN");
-    launch_sw(v, d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 1, d_scr, blocks, diag_max_len, nullptr);
+    launch_sw(v, d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 1, d_ctl + 2, d_scr, geom, diag_max_len, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     std::vector<PeSwRes> h_res(n_cases);
@@ -694,6 +698,17 @@ extern "C" int salt_gpu_index_set_pac(salt_gpu_index_t *ix, const uint8_t *pac, 
     return SALT_OK;
 }
 
+extern "C" int salt_gpu_ws_pe_overflow(salt_gpu_ws_t *ws, uint32_t *n)
+{
+    if (!ws || !n) return fail(SALT_E_INVAL, "null argument");
+    *n = 0;
+    if (!ws->d_pctl) return SALT_OK;
+    HIPCHK(hipSetDevice(ws->ix->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(n, ws->d_pctl + 4, 4, hipMemcpyDeviceToHost));
+    return SALT_OK;
+}
+
 static int pe_prepare(salt_gpu_ws_t *ws, uint32_t n_pairs, hipStream_t st)
 {
     if (n_pairs > ws->pe_pairs_cap) {
@@ -709,8 +724,7 @@ static int pe_prepare(salt_gpu_ws_t *ws, uint32_t n_pairs, hipStream_t st)
         HIPCHK(hipMalloc((void **)&ws->d_pctl, 8 * 4));
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ws->ix->device));
-        ws->sw_blocks = (uint32_t)prop.multiProcessorCount;             // per block-per-CU; the scratch holds SW_MAX_BLOCKS_PER_CU of them
-        HIPCHK(hipMalloc((void **)&ws->d_sw_scr, (uint64_t)ws->sw_blocks * SW_MAX_BLOCKS_PER_CU * 8 * SW_SCRATCH_BYTES));
+        ws->sw_blocks = (uint32_t)prop.multiProcessorCount;             // CUs: k_sw runs up to SW_MAX_BLOCKS_PER_CU blocks on each
     }
     return SALT_OK;
 }
@@ -726,8 +740,21 @@ static int pe_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const sa
     HIPCHK(hipMemsetAsync(ws->d_pctl, 0, 32, st));
     launch_pair(n_pairs, pe->min_tlen, pe->max_tlen, (uint32_t)ws->ix->l_pac, static_cast<const uint32_t *>(d_offs), static_cast<salt_result_t *>(d_results),
                 ws->d_pairs, ws->d_req, ws->d_pctl, st);
+    // rescue windows are as long as the insert-size window plus a mate (alnpe.c:213-252, 395-480), whatever -a / -b say
+    const uint64_t l_pac = (uint64_t)ws->ix->l_pac;
+    uint64_t max_win = (uint64_t)pe->max_tlen + max_len + 2;
+    if (max_win > l_pac + 1) max_win = l_pac + 1;
+    const SwGeom geom = sw_geom(max_len, max_win, ws->sw_blocks);
+    const uint64_t need = (uint64_t)geom.n_blocks * 8 * geom.group_bytes;
+    if (need > ws->sw_scr_bytes) {
+        HIPCHK(hipStreamSynchronize(st));
+        hipFree(ws->d_sw_scr); ws->d_sw_scr = nullptr; ws->sw_scr_bytes = 0;
+        hipError_t e = hipMalloc((void **)&ws->d_sw_scr, need);
+        if (e != hipSuccess) return fail(SALT_E_NOMEM, std::string("hipMalloc(rescue scratch): ") + hipGetErrorString(e));
+        ws->sw_scr_bytes = need;
+    }
     launch_sw(ws->ix->view, ws->ix->d_pac, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_req, ws->d_pctl, ws->d_swres,
-              ws->d_pctl + 1, ws->d_sw_scr, ws->sw_blocks * sw_blocks_per_cu(max_len), max_len, st);
+              ws->d_pctl + 1, ws->d_pctl + 4, ws->d_sw_scr, geom, max_len, st);
     launch_pe_final(ws->ix->view, PackGeom::make(max_len), n_pairs, ws->d_pm, static_cast<salt_result_t *>(d_results), ws->d_pairs, ws->d_swres, ws->d_lvtab,
                     ws->d_pcq, ws->d_pctl + 2, ws->heavy_blocks, st);
     HIPCHK(hipGetLastError());
@@ -768,7 +795,14 @@ extern "C" int salt_gpu_align_pe(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, con
     HIPCHK(hipMemcpyAsync(ws->d_offs, offs, ((uint64_t)n_reads + 1) * 4, hipMemcpyHostToDevice, st));
     int rc = pe_resident_impl(ws, o, pe, n_pairs, max_len, ws->d_seqs, ws->d_offs, ws->d_results, st);
     if (rc) return rc;
-    return fetch_results(ws, n_reads, results, st);
+    rc = fetch_results(ws, n_reads, results, st);
+    if (rc) return rc;
+    uint32_t n_over = 0;
+    rc = salt_gpu_ws_pe_overflow(ws, &n_over);
+    if (rc) return rc;
+    if (n_over) return fail(SALT_E_CAPACITY, std::to_string(n_over) + " mate rescue(s) need a Smith-Waterman band wider than this build holds (SW_BAND_W): "
+                                             "the rows of this batch would differ from the reference's");
+    return SALT_OK;
 }
 
 extern "C" int salt_gpu_ws_counters(salt_gpu_ws_t *ws, uint64_t out[SALT_CTR_N])

@@ -109,7 +109,8 @@ __device__ void sw_word_pass(const IndexView &ix, const uint8_t *pac, bool aware
 }
 
 // banded_sw (ssw.c:549-727) by one lane; h_b/e_b/h_c and the direction bytes live in this group's global scratch.
-// Returns the number of ops written to cig (len<<4|op), 0 on failure (scratch too small / traceback error).
+// Returns the number of ops written to cig (len<<4|op), 0 on a traceback error (as the reference: no CIGAR), -1 when the
+// band or the direction bytes would not fit this group's scratch (the caller counts that as an overflow).
 __device__ int sw_banded(const IndexView &ix, const uint8_t *pac, bool aware, uint32_t ref0, const uint8_t *read, int refLen, int readLen,
                          int score, int band_width, int32_t *hb, int32_t *eb, int32_t *hc, int8_t *direction, uint32_t dir_cap,
                          uint16_t *cig, int cig_cap)
@@ -121,7 +122,7 @@ __device__ int sw_banded(const IndexView &ix, const uint8_t *pac, bool aware, ui
     int8_t *direction_line = direction;
     do {
         width = band_width * 2 + 3; width_d = band_width * 2 + 1;
-        if (width > SW_BAND_W || (uint64_t)width_d * (uint64_t)readLen * 3u + 8u > dir_cap) return 0;
+        if (width > (int)SW_BAND_W || (uint64_t)width_d * (uint64_t)readLen * 3u + 8u > dir_cap) return -1;
         for (j = 1; j < width - 1; ++j) hb[j] = 0;
         for (i = 0; i < readLen; ++i) {
             int beg = 0, end = refLen - 1, u = 0, edge;
@@ -186,7 +187,7 @@ __device__ int sw_banded(const IndexView &ix, const uint8_t *pac, bool aware, ui
 __global__ void __launch_bounds__(64)
 k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
      const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
-     uint8_t *__restrict__ scratch, uint32_t seg, int dbg_skip_tb)
+     uint32_t *__restrict__ overflow, uint8_t *__restrict__ scratch, uint32_t maxcol_bytes, uint32_t group_bytes, uint32_t seg, int dbg_skip_tb)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sw_lds[];
     const uint32_t grp = threadIdx.x >> 3, lane = threadIdx.x & 7u;
@@ -197,11 +198,11 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
         s.read = reinterpret_cast<uint8_t *>(s.Hmax + seg * 8);
     }
     const uint32_t n_req = pctl[0];
-    uint8_t *my = scratch + ((size_t)blockIdx.x * 8 + grp) * SW_SCRATCH_BYTES;
+    uint8_t *my = scratch + ((size_t)blockIdx.x * 8 + grp) * group_bytes;
     uint16_t *maxColumn = reinterpret_cast<uint16_t *>(my);
-    int32_t *hb = reinterpret_cast<int32_t *>(my + SW_MAXCOL_BYTES), *eb = hb + SW_BAND_W, *hc = eb + SW_BAND_W;
+    int32_t *hb = reinterpret_cast<int32_t *>(my + maxcol_bytes), *eb = hb + SW_BAND_W, *hc = eb + SW_BAND_W;
     int8_t *direction = reinterpret_cast<int8_t *>(hc + SW_BAND_W);
-    const uint32_t dir_cap = SW_SCRATCH_BYTES - SW_MAXCOL_BYTES - 3u * SW_BAND_W * 4u;
+    const uint32_t dir_cap = group_bytes - maxcol_bytes - 3u * SW_BAND_W * 4u;
     for (;;) {
         uint32_t it = 0;
         if (lane == 0) it = atomicAdd(head, 1u);
@@ -212,7 +213,9 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
         const uint32_t off = offs[rq.mate], L = offs[rq.mate + 1] - off;
         const int refLen = (int)(rq.end - rq.start + 1);
         const bool aware = rq.aware != 0;
-        const bool fits = rq.start < ix.ref_len && refLen > 0 && (uint32_t)refLen * 2u <= SW_MAXCOL_BYTES && L <= seg * 8u;
+        const bool sane = rq.start < ix.ref_len && refLen > 0;
+        const bool fits = sane && (uint64_t)refLen * 2u <= maxcol_bytes && L <= seg * 8u;
+        if (sane && !fits && lane == 0) atomicAdd(overflow, 1u);
         if (fits) {
             // the mate's bases on the requested strand
             for (uint32_t i = lane; i < L; i += 8) {
@@ -251,6 +254,7 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
                     n_cig = sw_banded(ix, pac, aware, rq.start + (uint32_t)beg_ref, s.read + read_begin, rfl, rdl, max1, bw, hb, eb, hc, direction,
                                       dir_cap, out.cigar, SALT_MAX_CIGAR_OPS);
             }
+            if (lane == 0 && n_cig < 0) { atomicAdd(overflow, 1u); n_cig = 0; }
             n_cig = __shfl(n_cig, 0, 8);
             out.n_cigar = (uint16_t)n_cig;
             out.ok = (uint16_t)((n_cig > 0 && end_read1 - read_begin + 1 >= 20) ? 1 : 0);   // alnpe.c:297 (filters = 0, filterd = 20)
@@ -346,11 +350,28 @@ uint32_t sw_blocks_per_cu(uint32_t max_len)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sw, 64, sw_lds_bytes(max_len)) != hipSuccess || n < 1) n = 1;
     return (uint32_t)(n > (int)SW_MAX_BLOCKS_PER_CU ? (int)SW_MAX_BLOCKS_PER_CU : n);
 }
+// Scratch geometry of one k_sw launch: the per-column maxima cover the longest window (max_window columns), the direction
+// bytes the widest band the row buffers hold; the grid is cut back before the groups' scratch passes SW_SCRATCH_TOTAL.
+SwGeom sw_geom(uint32_t max_len, uint64_t max_window, uint32_t cus)
+{
+    SwGeom g;
+    const uint64_t mc = (2 * max_window + 255) & ~255ull;
+    const uint64_t dir = (3ull * max_len * (SW_BAND_W - 3) + 8 + 255) & ~255ull;
+    const uint64_t grp = mc + 3ull * SW_BAND_W * 4 + dir;
+    g.maxcol_bytes = (uint32_t)mc; g.group_bytes = (uint32_t)grp;
+    uint64_t blocks = (uint64_t)cus * sw_blocks_per_cu(max_len);
+    const uint64_t cap = SW_SCRATCH_TOTAL / (8 * grp);
+    if (blocks > cap) blocks = cap;
+    g.n_blocks = (uint32_t)(blocks ? blocks : 1);
+    return g;
+}
+
 void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, const uint32_t *offs, const PeSwReq *req, const uint32_t *pctl,
-               PeSwRes *res, uint32_t *head, uint8_t *scratch, uint32_t n_blocks, uint32_t max_len, hipStream_t st)
+               PeSwRes *res, uint32_t *head, uint32_t *overflow, uint8_t *scratch, SwGeom g, uint32_t max_len, hipStream_t st)
 {
     const uint32_t seg = (max_len + 7) / 8;
-    hipLaunchKernelGGL(k_sw, dim3(n_blocks), dim3(64), sw_lds_bytes(max_len), st, ix, pac, seqs, offs, req, pctl, res, head, scratch, seg, (getenv("SALT_GPU_SW_SKIP_TB") && atoi(getenv("SALT_GPU_SW_SKIP_TB"))) ? 1 : 0);
+    hipLaunchKernelGGL(k_sw, dim3(g.n_blocks), dim3(64), sw_lds_bytes(max_len), st, ix, pac, seqs, offs, req, pctl, res, head, overflow, scratch,
+                       g.maxcol_bytes, g.group_bytes, seg, (getenv("SALT_GPU_SW_SKIP_TB") && atoi(getenv("SALT_GPU_SW_SKIP_TB"))) ? 1 : 0);
 }
 
 } // namespace salt

@@ -378,3 +378,32 @@ def test_gpu_attach_to_the_compact_image_rebuilds_the_kmer_table(lam):
     assert salt_amd.sam_text(idx, opt, names, seqs, offs, quals, a) == salt_amd.sam_text(idx, opt, names, seqs, offs, quals, b)
     with pytest.raises(salt_amd.SaltError):
         salt_amd.GpuAligner(None, device=0, max_reads=64, compact=(cptr, cbytes - 256))
+
+
+OPTION_MATRIX = [
+    "-g rg1 -d -c", "-g rg1", "-l 100 -d -c", "-M 2 -O 5 -E 2 -d -c", "-n 5 -d -c", "-e -d -c", "-s 1 -d -c", "-s 0 -d -c",
+    "-m 1 -d -c", "-m 3 -d -c", "-r 19 -d -c", "-r 40 -d -c", "-r 100 -d -c", "-r 2 -m 1000 -d -c", "-d", "-c", "-t 3 -d -c -v",
+    "-p -d -c", "-p -d -c -a 0 -b 100000", "-p -d -c -a 600 -b 500", "-p -c -g lib7 -t 2", "-p -d -c -v -r 3", "-p -d -c -m 5 -s 2",
+]
+
+
+def test_cli_option_matrix_equals_the_oracle(oracle_cli, tmp_path):
+    """Every option of the reference's optstring that reaches this path (aln.c:102-124), including the ones it parses and
+    ignores (-n -e -M -O -E -l) and degenerate values (-s 0, -m 1, overlap > read, an empty insert window): the C++ CLI's SAM
+    against the CPU oracle's.  The oracle itself was compared with the real reference on this same matrix in the build
+    container (identical on all rows; DESIGN.md 'oracle pinning')."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt, salt_idx = os.path.join(root, "salt_amd", "bin", "salt"), os.path.join(root, "salt_amd", "bin", "salt-idx")
+    prefix = str(tmp_path / "idx")
+    subprocess.run([salt_idx, "-k", "19", os.path.join(LAMBDA, "genome.fa"), os.path.join(LAMBDA, "snps.txt"), prefix],
+                   check=True, stderr=subprocess.DEVNULL)
+    strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    bad = []
+    for row in OPTION_MATRIX:
+        args = row.split()
+        files = [os.path.join(LAMBDA, f) for f in (("reads_pe_1.fq", "reads_pe_2.fq") if "-p" in args else ("reads_se.fq",))]
+        got = subprocess.run([salt] + args + [prefix] + files, capture_output=True)
+        want = subprocess.run([oracle_cli] + args + [prefix] + files, capture_output=True)
+        if got.returncode != want.returncode or strip(got.stdout) != strip(want.stdout):
+            bad.append((row, got.returncode, want.returncode, got.stderr[-300:]))
+    assert not bad, bad
