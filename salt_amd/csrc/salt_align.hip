@@ -1235,6 +1235,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                         c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
                         n = cs.n_cand;
                     }
+                    if (n > 1024u * LLV_N) { ok = false; break; }        // a work item names its chunk in 10 bits; PE lists can be longer
                     uint32_t o = 0;
                     if (lane == 0) o = atomicAdd(&g.gctl[8], n);
                     o = (uint32_t)__shfl((int)o, 0);

@@ -44,7 +44,7 @@ struct AlignParams {
                                     //    per-interval locate cap, gapped bound stays 3, > 5 N skips the mate
     uint32_t max_amb;               // reads with more N than this are left untouched (200 SE / 5 PE)
 };
-static const uint32_t PE_LOCI_CAP = 32768;      // loci per strand a PE mate may enumerate (global scratch)
+static const uint32_t PE_LOCI_CAP = 0x40000;    // loci per strand a PE mate may enumerate = MAX_LOC_POS (alnse.c:42,533); global scratch
 
 void launch_pack(const PackGeom &pg, uint32_t n_reads, const uint8_t *seqs, const uint32_t *offs, uint32_t *pm, uint32_t *tb, hipStream_t st);
 void launch_seed(const IndexView &ix, const SeedParams &sp, const uint32_t *tb, const uint8_t *seqs, const uint32_t *offs, uint4 *sai_c,

@@ -110,7 +110,7 @@ __device__ void sw_word_pass(const IndexView &ix, const uint8_t *pac, bool aware
 
 // banded_sw (ssw.c:549-727) by one lane; h_b/e_b/h_c and the direction bytes live in this group's global scratch.
 // Returns the number of ops written to cig (len<<4|op), 0 on a traceback error (as the reference: no CIGAR), -1 when the
-// band or the direction bytes would not fit this group's scratch (the caller counts that as an overflow).
+// band, the direction bytes or the CIGAR (SALT_MAX_CIGAR_OPS) would not fit (the caller counts that as an overflow).
 __device__ int sw_banded(const IndexView &ix, const uint8_t *pac, bool aware, uint32_t ref0, const uint8_t *read, int refLen, int readLen,
                          int score, int band_width, int32_t *hb, int32_t *eb, int32_t *hc, int8_t *direction, uint32_t dir_cap,
                          uint16_t *cig, int cig_cap)
@@ -170,11 +170,11 @@ __device__ int sw_banded(const IndexView &ix, const uint8_t *pac, bool aware, ui
         default: return 0;
         }
         if (f == max) ++e;
-        else { ++l; if (l > SALT_MAX_CIGAR_OPS) return 0; c[l - 1] = (uint16_t)(e << 4 | max); max = f; e = 1; }
+        else { ++l; if (l > SALT_MAX_CIGAR_OPS) return -1; c[l - 1] = (uint16_t)(e << 4 | max); max = f; e = 1; }
     }
-    if (f == 0) { ++l; if (l > SALT_MAX_CIGAR_OPS) return 0; c[l - 1] = (uint16_t)((e + 1) << 4); }
-    else { l += 2; if (l > SALT_MAX_CIGAR_OPS) return 0; c[l - 2] = (uint16_t)(e << 4 | f); c[l - 1] = 16; }
-    if (l > cig_cap) return 0;
+    if (f == 0) { ++l; if (l > SALT_MAX_CIGAR_OPS) return -1; c[l - 1] = (uint16_t)((e + 1) << 4); }
+    else { l += 2; if (l > SALT_MAX_CIGAR_OPS) return -1; c[l - 2] = (uint16_t)(e << 4 | f); c[l - 1] = 16; }
+    if (l > cig_cap) return -1;
     for (i = 0; i < l; ++i) cig[i] = c[l - 1 - i];
     return l;
 #undef SET_U

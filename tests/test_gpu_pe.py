@@ -165,3 +165,43 @@ def test_cli_salt_pe_matches_reference_golden(tmp_path):
         got = b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
         want = open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
         assert got == want, (case, _diff_report(got, want))
+
+
+def test_gpu_pe_locate_cap_is_the_references(tmp_path):
+    """alnse_locate (PE) stops at MAX_LOC_POS = 0x40000 loci per strand (alnse.c:42,533), far above the SE cap: on a tandem
+    repeat (40 000 diverged copies of a 30-bp unit) with -r 2 -s 100000 (no seed extension) a mate enumerates up to 65 seeds x
+    (max_locate + 1) rows = 65 000 distinct loci per strand.  Fields of both mates against the oracle."""
+    import sys
+    import salt_amd
+    from salt_amd import workload
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    rng = np.random.Generator(np.random.PCG64(77))
+    unit = rng.integers(0, 4, size=30).astype(np.uint8)
+    copies = np.tile(unit, 40000)
+    m = rng.random(len(copies)) < 0.01
+    copies[m] = (copies[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
+    genome = np.concatenate([rng.integers(0, 4, size=30000).astype(np.uint8), copies, rng.integers(0, 4, size=30000).astype(np.uint8)])
+    pos, mask = workload.make_snps(genome, 600, seed=5)
+    fa, snp, prefix = str(tmp_path / "g.fa"), str(tmp_path / "s.txt"), str(tmp_path / "idx")
+    workload.write_fasta(fa, "tandem", genome)
+    workload.write_snps(snp, "tandem", genome, pos, mask)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import subprocess
+    subprocess.run([os.path.join(root, "salt_amd", "bin", "salt-idx"), "-k", "21", fa, snp, prefix], check=True, stderr=subprocess.DEVNULL)
+    seqs, offs, _, _ = workload.make_pairs(genome, pos, mask, 100, 150, seed=9, insert_mean=400, insert_sd=40)
+    L = 150
+    idx = salt_amd.Index.reload(prefix)
+    opt, _ = salt_amd.AlnOpt.from_argv(["-p", "-r", "2", "-s", "100000"], idx.l_seed)
+    aln = salt_amd.GpuAligner(idx, device=0, max_reads=600, max_bases=600 * L)
+    res = aln.alnpe_core1(opt, idx, seqs, offs)
+    aln.close()
+    ora = oracle_py.Oracle(prefix)
+    oo = ora.opt(l_overlap=opt.l_overlap, max_seed=opt.max_seed, max_locate=opt.max_locate, seed_only_ref=opt.seed_only_ref)
+    want = ora.align_pe(oo, seqs, offs, opt.min_tlen, opt.max_tlen, n_threads=16)
+    ora.close()
+    idx.destroy()
+    bad = oracle_py.compare(res, want, pe=True)
+    detail = [(int(i), [(f, res[f][i].tolist(), want[f][i].tolist()) for f in ("pos", "strand", "n_diff", "is_gap", "mapq", "b0", "b1")]) for i in bad[:4]]
+    assert len(bad) == 0, (len(bad), detail)
+    assert (want["pos"] != 0xFFFFFFFF).mean() > 0.9
