@@ -41,6 +41,17 @@ def make_genome(n, seed=21):
     return g
 
 
+def make_tandem(unit_len=30, copies=40000, divergence=0.01, flank=30000, seed=77):
+    """Adversarial genome for the locate caps and the interval-size sort: `copies` diverged copies of one `unit_len`-base unit
+    between two random flanks -- every seed of a read from the block has hundreds to thousands of suffix-array rows."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    unit = rng.integers(0, 4, size=unit_len).astype(np.uint8)
+    block = np.tile(unit, copies)
+    m = rng.random(len(block)) < divergence
+    block[m] = (block[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
+    return np.concatenate([rng.integers(0, 4, size=flank).astype(np.uint8), block, rng.integers(0, 4, size=flank).astype(np.uint8)])
+
+
 def make_snps(genome, n_snps, seed=144):
     rng = np.random.Generator(np.random.PCG64(seed))
     pos = np.sort(rng.choice(len(genome), size=n_snps, replace=False))

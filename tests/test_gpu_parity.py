@@ -407,3 +407,43 @@ def test_cli_option_matrix_equals_the_oracle(oracle_cli, tmp_path):
         if got.returncode != want.returncode or strip(got.stdout) != strip(want.stdout):
             bad.append((row, got.returncode, want.returncode, got.stderr[-300:]))
     assert not bad, bad
+
+
+TANDEM_ROWS = ["-d -c", "-d -c -r 2", "-d -c -s 100000", "-d -c -m 50", "-d -c -r 2 -s 100000", "-d -c -r 1 -s 3 -m 200", "-d -c -v -s 100000",
+               "-p -d -c -r 2 -s 100000", "-p -d -c -m 200"]       # PE with -m below ~60 here subsamples R intervals with rand(): undefined
+
+
+def test_cli_on_a_tandem_repeat_equals_the_oracle(oracle_cli, tmp_path):
+    """40 000 diverged copies of a 30-base unit: every seed has hundreds to thousands of rows, so the global / per-interval
+    locate caps bite (alnse.c:678,719 SE; alnse.c:523,533 PE), the interval-size introsort decides which rows are seen
+    (alnse.c:307-308), seed extension runs long (-s) or not at all (-s 100000), and XA lists fill up.  SAM of the C++ CLI
+    against the CPU oracle's; the oracle equals the real reference on these rows (checked in the build container)."""
+    from salt_amd import workload
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt, salt_idx = os.path.join(root, "salt_amd", "bin", "salt"), os.path.join(root, "salt_amd", "bin", "salt-idx")
+    genome = workload.make_tandem()
+    pos, mask = workload.make_snps(genome, 600, seed=5)
+    fa, snp, prefix = str(tmp_path / "g.fa"), str(tmp_path / "s.txt"), str(tmp_path / "idx")
+    workload.write_fasta(fa, "tandem", genome)
+    workload.write_snps(snp, "tandem", genome, pos, mask)
+    subprocess.run([salt_idx, "-k", "21", fa, snp, prefix], check=True, stderr=subprocess.DEVNULL)
+    seqs, offs, _, _ = workload.make_reads(genome, pos, mask, 400, 100, seed=13)
+    se = str(tmp_path / "se.fq")
+    workload.write_fastq(se, seqs, offs)
+    ps, po, _, _ = workload.make_pairs(genome, pos, mask, 100, 150, seed=9, insert_mean=400, insert_sd=40)
+    o1 = np.arange(101, dtype=np.uint32) * 150
+    p1, p2 = str(tmp_path / "p1.fq"), str(tmp_path / "p2.fq")
+    workload.write_fastq(p1, np.concatenate([ps[po[2 * i]:po[2 * i + 1]] for i in range(100)]), o1)
+    workload.write_fastq(p2, np.concatenate([ps[po[2 * i + 1]:po[2 * i + 2]] for i in range(100)]), o1)
+    strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    bad = []
+    for row in TANDEM_ROWS:
+        args = row.split()
+        files = [p1, p2] if "-p" in args else [se]
+        got = subprocess.run([salt] + args + [prefix] + files, capture_output=True)
+        want = subprocess.run([oracle_cli] + args + [prefix] + files, capture_output=True)
+        if got.returncode != want.returncode or strip(got.stdout) != strip(want.stdout):
+            g, w = strip(got.stdout).split(b"\n"), strip(want.stdout).split(b"\n")
+            d = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]
+            bad.append((row, got.returncode, want.returncode, len(d), [(g[i][:160], w[i][:160]) for i in d[:2]], got.stderr[-200:]))
+    assert not bad, bad

@@ -176,12 +176,7 @@ def test_gpu_pe_locate_cap_is_the_references(tmp_path):
     from salt_amd import workload
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import oracle_py
-    rng = np.random.Generator(np.random.PCG64(77))
-    unit = rng.integers(0, 4, size=30).astype(np.uint8)
-    copies = np.tile(unit, 40000)
-    m = rng.random(len(copies)) < 0.01
-    copies[m] = (copies[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
-    genome = np.concatenate([rng.integers(0, 4, size=30000).astype(np.uint8), copies, rng.integers(0, 4, size=30000).astype(np.uint8)])
+    genome = workload.make_tandem()
     pos, mask = workload.make_snps(genome, 600, seed=5)
     fa, snp, prefix = str(tmp_path / "g.fa"), str(tmp_path / "s.txt"), str(tmp_path / "idx")
     workload.write_fasta(fa, "tandem", genome)
