@@ -50,11 +50,85 @@ inline uint8_t nt4(int c)
                  case 'T': case 't': return 3; default: return 4; }
 }
 
+// True when every complete record in the first 256 KiB of the (possibly gzipped) file is strict 4-line FASTQ:
+// '@' line, one sequence line, '+' line, one quality line of the same length.
+static bool sniff_four_line(const char *fn)
+{
+    gzFile f = gzopen(fn, "r");
+    if (!f) return true;
+    std::vector<char> b(256u << 10);
+    int n = gzread(f, b.data(), (unsigned)b.size());
+    gzclose(f);
+    if (n <= 0) return true;
+    size_t p = 0; const size_t e = (size_t)n;
+    if (b[0] != '@') return false;
+    for (;;) {
+        size_t st[5]; st[0] = p; bool whole = true;
+        for (int k = 0; k < 4; ++k) {
+            const char *nl = (const char *)memchr(b.data() + st[k], '\n', e - st[k]);
+            if (!nl) { whole = false; break; }
+            st[k + 1] = (size_t)(nl - b.data()) + 1;
+        }
+        if (!whole) return true;
+        auto len = [&](int k) { size_t l = st[k + 1] - st[k] - 1; while (l > 0 && b[st[k] + l - 1] == '\r') --l; return l; };
+        if (b[st[0]] != '@' || b[st[2]] != '+' || len(1) != len(3)) return false;
+        p = st[4];
+        if (p >= e) return true;
+    }
+}
+
 // Raw text of up to N_SEQS FASTQ records.  The reader thread only finds record boundaries (4 lines per
 // record, like the 4-line FASTQ the reference's test data uses); parsing runs on the worker threads.
+// The general mode (chosen when the head of the file is not strict 4-line FASTQ, sniff_four_line) reads records the way
+// the reference's kseq.h does -- sequence and quality may span lines -- and hands them on re-written as 4 lines.
 struct RawReader {
-    gzFile fp; std::vector<char> buf; size_t have = 0, pos = 0; bool eof = false;
-    explicit RawReader(gzFile f) : fp(f), buf(8u << 20) {}
+    gzFile fp; std::vector<char> buf; size_t have = 0, pos = 0; bool eof = false; bool general = false;
+    explicit RawReader(gzFile f, bool general_ = false) : fp(f), buf(8u << 20), general(general_) {}
+    // kseq_read (kseq.h): '@name comment' line; sequence lines up to a line starting with '+'; that line; quality lines
+    // until as many characters as the sequence has.  A '>' record (FASTA) has no quality: the reference cannot print it.
+    int take_general(std::vector<char> &out, int n_rec, std::vector<uint32_t> &rec)
+    {
+        int got = 0;
+        rec.clear();
+        std::string line, seq, qual;
+        auto getline = [&](std::string &l) -> bool {
+            l.clear();
+            int c;
+            while ((c = gzgetc(fp)) != -1 && c != '\n') l.push_back((char)c);
+            if (c == -1 && l.empty()) return false;
+            while (!l.empty() && l.back() == '\r') l.pop_back();
+            return true;
+        };
+        while (got < n_rec) {
+            int c;
+            while ((c = gzgetc(fp)) != -1 && c != '@' && c != '>') {}          // to the next header, as kseq does
+            if (c == -1) { eof = true; break; }
+            if (c == '>') { fprintf(stderr, "[salt] FASTA input has no base qualities: the reference cannot print SAM for it either\n"); exit(1); }
+            if (!getline(line)) { eof = true; break; }
+            const std::string head = line;
+            seq.clear(); qual.clear();
+            bool plus = false;
+            for (;;) {
+                c = gzgetc(fp);
+                if (c == -1) break;
+                if (c == '+') { getline(line); plus = true; break; }
+                if (c == '>' || c == '@') { gzungetc(c, fp); break; }
+                gzungetc(c, fp);
+                if (!getline(line)) break;
+                for (char ch : line) if (!isspace((unsigned char)ch)) seq.push_back(ch);
+            }
+            if (!plus) { fprintf(stderr, "[salt] record '%s' has no quality line\n", head.c_str()); exit(1); }
+            while (qual.size() < seq.size() && getline(line)) for (char ch : line) if (!isspace((unsigned char)ch)) qual.push_back(ch);
+            if (qual.size() != seq.size()) { fprintf(stderr, "[salt] record '%s': %zu bases but %zu qualities\n", head.c_str(), seq.size(), qual.size()); exit(1); }
+            rec.push_back((uint32_t)out.size());
+            out.push_back('@'); out.insert(out.end(), head.begin(), head.end()); out.push_back('\n');
+            out.insert(out.end(), seq.begin(), seq.end()); out.push_back('\n');
+            out.push_back('+'); out.push_back('\n');
+            out.insert(out.end(), qual.begin(), qual.end()); out.push_back('\n');
+            ++got;
+        }
+        return got;
+    }
     bool fill()
     {
         if (eof) return false;
@@ -68,6 +142,7 @@ struct RawReader {
     // appends whole records to out until n_rec records or end of file; returns records appended
     int take(std::vector<char> &out, int n_rec, std::vector<uint32_t> &rec)
     {
+        if (general) return take_general(out, n_rec, rec);
         int got = 0;
         rec.clear();
         for (;;) {
@@ -200,6 +275,11 @@ void parse_batch(std::vector<char> &raw, Batch &b, Pool &pool)
             size_t q0 = e2 + 1, q1 = line_end(q0);
             while (q1 > q0 && raw[q1 - 1] == '\r') --q1;
             b.qual[(size_t)i] = (uint32_t)q0;
+            if (raw[p] != '@' || p2 >= raw.size() || raw[p2] != '+' || q1 - q0 != se - s0) {
+                fprintf(stderr, "[salt] input is not 4-line FASTQ at record %d of a batch ('%.60s'): multi-line records are only read when "
+                                "the head of the file shows them\n", i, raw.data() + p);
+                exit(1);
+            }
             raw[name_end] = 0;                               // terminate in place (after every read of these lines)
             if (q1 < raw.size()) raw[q1] = 0;
         }
@@ -334,8 +414,8 @@ int main(int argc, char **argv)
     std::atomic<double> t_parse{ 0 }, t_gpu{ 0 }, t_fmt{ 0 };
     double t_write = 0, t_read = 0;
     std::thread reader([&]() {
-        RawReader rr(fp);
-        std::unique_ptr<RawReader> rr2(pe ? new RawReader(fp2) : nullptr);
+        RawReader rr(fp, !sniff_four_line(fn_reads));
+        std::unique_ptr<RawReader> rr2(pe ? new RawReader(fp2, !sniff_four_line(fn_mates)) : nullptr);
         const int per_batch = pe ? N_SEQS / 2 : N_SEQS;    // pairs per batch: N_SEQS mates (query_read_multiPairedSeqs, query.c:252-268)
         long seq_no = 0;
         for (;;) {

@@ -76,5 +76,29 @@ def main():
     print("%d reads" % len(reads))
 
 
+def make_wrapped():
+    """reads_wrapped.fq: the first 60 reads of reads_se.fq with sequence and quality wrapped at 37 characters and CRLF line
+    ends on every third record (kseq.h reads such records; the reference's SAM for them is the fixture)."""
+    lines = open(os.path.join(OUT, "reads_se.fq")).read().split("\n")
+    fq = os.path.join(OUT, "reads_wrapped.fq")
+    with open(fq, "w", newline="") as f:
+        for i in range(60):
+            name, seq, _, qual = lines[4 * i:4 * i + 4]
+            nl = "\r\n" if i % 3 == 2 else "\n"
+            wrap = lambda x: nl.join(x[j:j + 37] for j in range(0, len(x), 37))
+            f.write(name + nl + wrap(seq) + nl + "+" + nl + wrap(qual) + nl)
+    with tempfile.TemporaryDirectory() as tmp:
+        idx = os.path.join(tmp, "idx")
+        subprocess.run([os.path.join(REF_BIN, "salt-idx"), "-k", str(K), os.path.join(OUT, "genome.fa"), os.path.join(OUT, "snps.txt"), idx],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        sam = os.path.join(tmp, "o.sam")
+        with open(sam, "w") as g:
+            subprocess.run([os.path.join(REF_BIN, "salt"), "-d", "-c", idx, fq], check=True, stdout=g, stderr=subprocess.DEVNULL)
+        strip_pg(sam, os.path.join(OUT, "expect_wrapped.sam"))
+
+
 if __name__ == "__main__":
-    main()
+    if "--wrapped" in sys.argv:
+        make_wrapped()
+    else:
+        main()

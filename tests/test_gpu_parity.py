@@ -447,3 +447,30 @@ def test_cli_on_a_tandem_repeat_equals_the_oracle(oracle_cli, tmp_path):
             d = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]
             bad.append((row, got.returncode, want.returncode, len(d), [(g[i][:160], w[i][:160]) for i in d[:2]], got.stderr[-200:]))
     assert not bad, bad
+
+
+def test_cli_reads_the_fastq_shapes_kseq_reads(tmp_path):
+    """query_read_seq goes through kseq.h (query.c:146-239): gzip'ed input, CRLF line ends, and records whose sequence and
+    quality span several lines are all legal.  Expected SAMs are the real reference's (tests/golden/make_span_fixture.py)."""
+    import gzip
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt, salt_idx = os.path.join(root, "salt_amd", "bin", "salt"), os.path.join(root, "salt_amd", "bin", "salt-idx")
+    prefix = str(tmp_path / "idx")
+    subprocess.run([salt_idx, "-k", "19", os.path.join(LAMBDA, "genome.fa"), os.path.join(LAMBDA, "snps.txt"), prefix],
+                   check=True, stderr=subprocess.DEVNULL)
+    strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    span = open(os.path.join(LAMBDA, "reads_span.fq"), "rb").read()
+    gz, crlf = str(tmp_path / "span.fq.gz"), str(tmp_path / "span_crlf.fq")
+    with gzip.open(gz, "wb") as f:
+        f.write(span)
+    open(crlf, "wb").write(span.replace(b"\n", b"\r\n"))
+    want_span = open(os.path.join(LAMBDA, "expect_span_default.sam"), "rb").read()
+    for fq, want in ((gz, want_span), (crlf, want_span),
+                     (os.path.join(LAMBDA, "reads_wrapped.fq"), open(os.path.join(LAMBDA, "expect_wrapped.sam"), "rb").read())):
+        out = subprocess.run([salt, "-d", "-c", prefix, fq], check=True, capture_output=True).stdout
+        assert strip(out) == want, fq
+    # FASTA has no qualities: the reference crashes on it, this CLI says so
+    fa = str(tmp_path / "r.fa")
+    open(fa, "w").write(">r1\nACGTACGTACGTACGTACGTACGTACGT\n")
+    r = subprocess.run([salt, "-d", "-c", prefix, fa], capture_output=True)
+    assert r.returncode != 0 and b"FASTA" in r.stderr
