@@ -119,7 +119,7 @@ void salt_gpu_index_detach(salt_gpu_index_t *ix);
  * driver can broadcast it (RCCL) instead of re-packing on every rank. */
 int  salt_gpu_index_image(const salt_gpu_index_t *ix, void **dev_ptr, uint64_t *bytes);
 int  salt_gpu_index_attach_image(void *dev_ptr, uint64_t bytes, int device, salt_gpu_index_t **out);
-/* The image ends with the W-mer table (16 B x 4^W: 16 GiB at the default W = 15), which is a pure function of what
+/* The image ends with the W-mer table (16 B x 4^W: 64 GiB at W = 16, the default on a free MI355X), a pure function of what
  * precedes it.  The part before it is the COMPACT image -- what a multi-GPU driver needs to move: broadcast
  * [dev_ptr, dev_ptr + bytes) of salt_gpu_index_image_compact, then salt_gpu_index_attach_compact on each receiver
  * allocates the full image, copies the compact part in and tabulates the W-mer table there (it owns the result;

@@ -99,8 +99,12 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     hd.lkt_len = h->lkt_len; hd.lkt_n = h->lkt_n;
     hd.r_text_len = h->r_text_len; hd.r_inv_sa0 = h->r_inv_sa0; memcpy(hd.r_cum, h->r_cum, sizeof hd.r_cum);
     hd.ref_len = h->ref_len;
-    {   // width of the device k-mer tables: 16 B x 4^W (W=15 default: 16 GiB; 14: 4 GiB, 16: 64 GiB)
-        uint32_t w = 15;
+    {   // width of the device k-mer table: 16 B x 4^W (14: 4 GiB, 15: 16 GiB, 16: 64 GiB).  Every extra base saves each seed
+        // one C and one R backward-search step (k_seed: -9 % per base), so the widest table that leaves most of the HBM free
+        // is taken: W = 16 on a 288 GB MI355X.
+        uint32_t w = 14;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) w = free_b >= (176ull << 30) ? 16 : free_b >= (48ull << 30) ? 15 : 14;
         if (const char *e = getenv("SALT_GPU_LKT_LEN")) w = (uint32_t)atoi(e);
         if (h->l_seed > 0 && w > (uint32_t)h->l_seed) w = (uint32_t)h->l_seed;
         if (h->l_seed <= 0) w = h->lkt_len;
