@@ -161,6 +161,9 @@ int  salt_gpu_align_pe_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, co
  * salt_gpu_align_pe fails with SALT_E_CAPACITY when this is non-zero; callers of the resident entry check it themselves
  * (it synchronises the device). */
 int  salt_gpu_ws_pe_overflow(salt_gpu_ws_t *ws, uint32_t *n);
+/* Counters of the LAST paired batch (diagnostics): out[0] = Smith-Waterman rescue requests, out[2] = CIGAR items queued by
+ * k_pe_final, out[4] = the overflow count above; the rest is internal. */
+int  salt_gpu_ws_pe_counts(salt_gpu_ws_t *ws, uint32_t out[8]);
 
 /* Same work on device-resident buffers; only enqueues on `hip_stream` (a hipStream_t, NULL = default). */
 int  salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, uint32_t n_reads,

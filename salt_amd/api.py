@@ -131,6 +131,7 @@ def gpu_lib():
         lib.salt_gpu_align_pe_resident.argtypes = [ctypes.c_void_p, ctypes.POINTER(_AlnOpt), ctypes.POINTER(_PeOpt), ctypes.c_uint32, ctypes.c_uint32,
                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.salt_gpu_ws_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        lib.salt_gpu_ws_pe_counts.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         lib.salt_gpu_index_image_compact.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
         lib.salt_gpu_index_attach_compact.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         lib.salt_gpu_index_image_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
@@ -305,6 +306,12 @@ class GpuAligner:
         p, n = ctypes.c_void_p(), ctypes.c_uint64()
         _gpu_check(gpu_lib().salt_gpu_index_image(self._ix, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
+
+    def pe_counts(self):
+        """Counters of the last paired batch: [0] rescue requests, [2] CIGAR items, [4] overflowed rescues."""
+        out = (ctypes.c_uint32 * 8)()
+        _gpu_check(gpu_lib().salt_gpu_ws_pe_counts(self._ws, out))
+        return list(out)
 
     def image_compact(self):
         """(device pointer, bytes) of the part of the image a multi-GPU driver broadcasts (everything but the W-mer table)."""

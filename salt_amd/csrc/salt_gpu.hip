@@ -713,6 +713,17 @@ extern "C" int salt_gpu_ws_pe_overflow(salt_gpu_ws_t *ws, uint32_t *n)
     return SALT_OK;
 }
 
+extern "C" int salt_gpu_ws_pe_counts(salt_gpu_ws_t *ws, uint32_t out[8])
+{
+    if (!ws || !out) return fail(SALT_E_INVAL, "null argument");
+    memset(out, 0, 32);
+    if (!ws->d_pctl) return SALT_OK;
+    HIPCHK(hipSetDevice(ws->ix->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, ws->d_pctl, 32, hipMemcpyDeviceToHost));
+    return SALT_OK;
+}
+
 static int pe_prepare(salt_gpu_ws_t *ws, uint32_t n_pairs, hipStream_t st)
 {
     if (n_pairs > ws->pe_pairs_cap) {

@@ -108,21 +108,137 @@ __device__ void sw_word_pass(const IndexView &ix, const uint8_t *pac, bool aware
     out_max = max; out_end_ref = end_ref; out_end_read = end_read;
 }
 
+// cross-lane moves inside an 8-lane group as DPP modifiers (no LDS crossbar round trip): shift towards higher lanes within the
+// 16-lane row (the callers zero the lanes that would read across the group's boundary), and an 8-lane max by two quad
+// permutes and the half-row mirror
+template <int N> __device__ __forceinline__ int dpp_row_shr(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x110 + N, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_max8(int x)
+{
+    int t = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); x = x > t ? x : t;        // quad_perm [1,0,3,2]
+    t = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); x = x > t ? x : t;            // quad_perm [2,3,0,1]
+    t = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true); return x > t ? x : t;        // row_half_mirror
+}
+
+// The same pass with the stripe rows in REGISTERS (SEG = compile-time bound on segLen, every loop fully unrolled): the LDS
+// version spends a column in ~5 dependent LDS round trips per stripe with two waves per SIMD to hide them; here a column is
+// ~25 VALU instructions per stripe and nothing else.  One buffer suffices for H: the old H[j] is read (it feeds stripe j+1)
+// right before the new one overwrites it.  Same operations in the same order as above, so the same lazy-F behaviour.
+template <int SEG, class ReadAt>
+__device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint8_t *pac, bool aware, uint32_t ref0, int ref_dir, int refLen,
+                                                 int readLen, ReadAt rd, int terminate, uint16_t *maxColumn, uint16_t *maxColumnLds,
+                                                 int &out_max, int &out_end_ref, int &out_end_read, uint32_t *dbg_cols = nullptr)
+{
+    uint32_t n_cols = 0, n_lazy = 0;
+    const int lane = (int)(threadIdx.x & 7u);
+    const uint64_t gmask = 0xFFull << (threadIdx.x & 56u);
+    const int segLen = (readLen + 7) / 8, go = 3, ge = 1;      // aln.h:137-138
+    int H[SEG], E[SEG], Hm[SEG]; uint32_t code[SEG];
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+        H[j] = 0; E[j] = 0; Hm[j] = 0;
+        const int q = j + lane * segLen;
+        code[j] = (j < segLen && q < readLen) ? rd(q) : 5u;      // 5: past the read (profile 0)
+    }
+    int max = 0, end_ref = 0, vMaxScore = 0, vMaxMark = 0;
+    const int begin = ref_dir ? refLen - 1 : 0, end = ref_dir ? -1 : refLen, step = ref_dir ? -1 : 1;
+    // the window's symbols come from 32-bit words (8 masks of the mixRef, or 16 bases of the 2-bit genome); the word after the
+    // one in use is already on its way, so a column never waits for memory
+    const uint32_t *words = aware ? ix.ref : reinterpret_cast<const uint32_t *>(pac);
+    const uint32_t wshift = aware ? 3u : 4u;
+    uint32_t w_idx = (ref0 + (uint32_t)begin) >> wshift;
+    uint32_t w_cur = words[w_idx], w_next = words[(int64_t)w_idx + step < 0 ? 0 : w_idx + step];
+    for (int i = begin; i != end; i += step) {
+        const uint32_t p = ref0 + (uint32_t)i;
+        if ((p >> wshift) != w_idx) { w_idx = p >> wshift; w_cur = w_next; w_next = words[(int64_t)w_idx + step < 0 ? 0 : w_idx + step]; }
+        const uint32_t sym = aware ? (w_cur >> (4u * (p & 7u))) & 15u
+                                   : (((w_cur >> (8u * ((p >> 2) & 3u))) & 0xFFu) >> ((~p & 3u) << 1)) & 3u;
+        int vF = 0, vMaxColumn = 0;
+        int last = 0;
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) if (j == segLen - 1) last = H[j];
+        int vH = dpp_row_shr<1>(last);
+        if (lane == 0) vH = 0;
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) {
+            if (j < segLen) {
+                const int prof = code[j] > 4u ? 0 : sw_score(aware, sym, code[j]);
+                int h = sat16(vH + prof);
+                int e = E[j];
+                h = h > e ? h : e; h = h > vF ? h : vF;
+                vMaxColumn = vMaxColumn > h ? vMaxColumn : h;
+                vH = H[j];                                       // the previous column's value: input of stripe j+1
+                H[j] = h;
+                h = subu16(h, go);
+                e = subu16(e, ge); e = e > h ? e : h; E[j] = e;
+                vF = subu16(vF, ge); vF = vF > h ? vF : h;
+            }
+        }
+        ++n_cols;
+        // lazy F (ssw.c:487-497) in closed form.  The reference shifts vF one lane up and sweeps the stripes (H = max(H, vF); vF -= ge),
+        // up to 8 times, leaving early once no lane has vF - ge > H - go.  The sweeps only EXTEND gaps (no new F is opened), so what
+        // stripe j of lane l can receive is max over k of (vF at the end of lane l-1-k's column) - k * segLen - j, floored at 0 by the
+        // saturating subtraction; and after the reference's early exit no H changes any more (from there on the lane's own F chain of
+        // the main loop, >= H[j] - go - ..., dominates the carried one), so taking the full maximum gives the same H.  A max-plus scan
+        // over the 8 lanes and one pass over the stripes replace the sweeps (which the 8 requests of a wave would each stretch to
+        // the longest of them).  E and the column maximum are not touched by the lazy pass there either.
+        {
+            int c = dpp_row_shr<1>(vF);
+            if (lane == 0) c = 0;
+            const int seg_ge = segLen * ge;
+            { int t = dpp_row_shr<1>(c); t = lane >= 1 ? t - seg_ge : 0; t = t > 0 ? t : 0; c = c > t ? c : t; }
+            { int t = dpp_row_shr<2>(c); t = lane >= 2 ? t - 2 * seg_ge : 0; t = t > 0 ? t : 0; c = c > t ? c : t; }
+            { int t = dpp_row_shr<4>(c); t = lane >= 4 ? t - 4 * seg_ge : 0; t = t > 0 ? t : 0; c = c > t ? c : t; }
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) {
+                if (j < segLen) { int f = c - j * ge; f = f > 0 ? f : 0; H[j] = H[j] > f ? H[j] : f; }
+            }
+            n_lazy += (uint32_t)segLen;
+        }
+        vMaxScore = vMaxScore > vMaxColumn ? vMaxScore : vMaxColumn;
+        if (__ballot(vMaxMark != vMaxScore) & gmask) {
+            vMaxMark = vMaxScore;
+            const int temp = dpp_max8(vMaxScore);
+            if (temp > max) {
+                max = temp; end_ref = i;
+#pragma unroll
+                for (int j = 0; j < SEG; ++j) Hm[j] = H[j];
+            }
+        }
+        const int mc = dpp_max8(vMaxColumn);
+        if (lane == 0) { if (maxColumnLds) maxColumnLds[i] = (uint16_t)mc; else if (maxColumn) maxColumn[i] = (uint16_t)mc; }
+        if (mc == terminate) break;
+    }
+    int end_read = readLen - 1;
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) if (j < segLen && Hm[j] == max) { int t = j + lane * segLen; if (t < end_read) end_read = t; }
+    for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(end_read, o, 8); end_read = end_read < t ? end_read : t; }
+    out_max = max; out_end_ref = end_ref; out_end_read = end_read;
+    if (dbg_cols && lane == 0) { atomicAdd(dbg_cols, n_cols); atomicAdd(dbg_cols + 1, n_lazy); }
+}
+
 // banded_sw (ssw.c:549-727) by one lane; h_b/e_b/h_c and the direction bytes live in this group's global scratch.
 // Returns the number of ops written to cig (len<<4|op), 0 on a traceback error (as the reference: no CIGAR), -1 when the
 // band, the direction bytes or the CIGAR (SALT_MAX_CIGAR_OPS) would not fit (the caller counts that as an overflow).
+// lrows / lref: this group's LDS copies -- three rows of SW_LDS_BAND ints for bands that fit, and the alignment's reference
+// symbols (one per byte) when refLen <= SW_LDS_REF; the global scratch serves wider bands.  Inside a row every value a cell needs
+// again (the left neighbour's H, the upper-left H, this cell's E / F directions) stays in a register: the only loads are the two
+// upper-row values, so the lane never waits for its own stores to come back from memory.
+static constexpr int SW_LDS_BAND = 128, SW_LDS_REF = 512;
 __device__ int sw_banded(const IndexView &ix, const uint8_t *pac, bool aware, uint32_t ref0, const uint8_t *read, int refLen, int readLen,
-                         int score, int band_width, int32_t *hb, int32_t *eb, int32_t *hc, int8_t *direction, uint32_t dir_cap,
-                         uint16_t *cig, int cig_cap)
+                         int score, int band_width, int32_t *ghb, int32_t *geb, int32_t *ghc, int32_t *lrows, const uint8_t *lref,
+                         int8_t *direction, uint32_t dir_cap, uint16_t *cig, int cig_cap)
 {
 #define SET_U(u, w, i, j) { int x_ = (i) - (w); x_ = x_ > 0 ? x_ : 0; (u) = (j) - x_ + 1; }
 #define SET_D(u, w, i, j, p) { int x_ = (i) - (w); x_ = x_ > 0 ? x_ : 0; x_ = (j) - x_; (u) = x_ * 3 + p; }
     const int go = 3, ge = 1;
     int i, j, e = 0, f, temp1, temp2, l, max = 0, width, width_d;
     int8_t *direction_line = direction;
+    const bool ref_in_lds = lref != nullptr && refLen <= SW_LDS_REF;
     do {
         width = band_width * 2 + 3; width_d = band_width * 2 + 1;
         if (width > (int)SW_BAND_W || (uint64_t)width_d * (uint64_t)readLen * 3u + 8u > dir_cap) return -1;
+        const bool in_lds = lrows != nullptr && width <= SW_LDS_BAND;
+        int32_t *hb = in_lds ? lrows : ghb, *eb = in_lds ? lrows + SW_LDS_BAND : geb, *hc = in_lds ? lrows + 2 * SW_LDS_BAND : ghc;
         for (j = 1; j < width - 1; ++j) hb[j] = 0;
         for (i = 0; i < readLen; ++i) {
             int beg = 0, end = refLen - 1, u = 0, edge;
@@ -132,25 +248,32 @@ __device__ int sw_banded(const IndexView &ix, const uint8_t *pac, bool aware, ui
             f = hb[0] = eb[0] = hb[edge] = eb[edge] = hc[0] = 0;
             direction_line = direction + width_d * i * 3;
             const uint32_t rc = read[i];
+            int hc_left = 0, hb_diag = 0;                        // hc[b] (= hc[0] for the first cell) and hb[d]
+            if (beg <= end) { int d; SET_U(d, band_width, i - 1, beg - 1); hb_diag = hb[d]; }
             for (j = beg; j <= end; ++j) {
-                int b, e1, f1, d, de, df, dh;
+                int e1, f1, de, df, dh;
                 SET_U(u, band_width, i, j); SET_U(e, band_width, i - 1, j);
-                SET_U(b, band_width, i, j - 1); SET_U(d, band_width, i - 1, j - 1);
                 SET_D(de, band_width, i, j, 0); SET_D(df, band_width, i, j, 1); SET_D(dh, band_width, i, j, 2);
-                temp1 = i == 0 ? -go : hb[e] - go;
-                temp2 = i == 0 ? -ge : eb[e] - ge;
-                eb[u] = temp1 > temp2 ? temp1 : temp2;
-                direction_line[de] = temp1 > temp2 ? 3 : 2;
-                temp1 = hc[b] - go; temp2 = f - ge;
+                const int hb_up = hb[e], eb_up = eb[e];
+                temp1 = i == 0 ? -go : hb_up - go;
+                temp2 = i == 0 ? -ge : eb_up - ge;
+                const int eb_u = temp1 > temp2 ? temp1 : temp2;
+                eb[u] = eb_u;
+                const int8_t dir_e = temp1 > temp2 ? 3 : 2;
+                direction_line[de] = dir_e;
+                temp1 = hc_left - go; temp2 = f - ge;
                 f = temp1 > temp2 ? temp1 : temp2;
-                direction_line[df] = temp1 > temp2 ? 5 : 4;
-                e1 = eb[u] > 0 ? eb[u] : 0; f1 = f > 0 ? f : 0;
+                const int8_t dir_f = temp1 > temp2 ? 5 : 4;
+                direction_line[df] = dir_f;
+                e1 = eb_u > 0 ? eb_u : 0; f1 = f > 0 ? f : 0;
                 temp1 = e1 > f1 ? e1 : f1;
-                temp2 = hb[d] + sw_score(aware, ref_symbol(ix, pac, aware, ref0 + (uint32_t)j), rc);
-                hc[u] = temp1 > temp2 ? temp1 : temp2;
-                if (hc[u] > max) max = hc[u];
-                if (temp1 <= temp2) direction_line[dh] = 1;
-                else direction_line[dh] = e1 > f1 ? direction_line[de] : direction_line[df];
+                const uint32_t sym = ref_in_lds ? (uint32_t)lref[j] : ref_symbol(ix, pac, aware, ref0 + (uint32_t)j);
+                temp2 = hb_diag + sw_score(aware, sym, rc);
+                const int hc_u = temp1 > temp2 ? temp1 : temp2;
+                hc[u] = hc_u;
+                if (hc_u > max) max = hc_u;
+                direction_line[dh] = temp1 <= temp2 ? (int8_t)1 : (e1 > f1 ? dir_e : dir_f);
+                hc_left = hc_u; hb_diag = hb_up;                 // next cell: b = this u, d = this e
             }
             for (j = 1; j <= u; ++j) hb[j] = hc[j];
         }
@@ -184,19 +307,30 @@ __device__ int sw_banded(const IndexView &ix, const uint8_t *pac, bool aware, ui
 // ---------------------------------------------------------------------------------------------
 // k_sw: persistent groups of 8 lanes pull rescue requests
 // ---------------------------------------------------------------------------------------------
+template <int SEG>                     // 0: stripe rows in LDS (any read length); > 0: in registers, segLen <= SEG
 __global__ void __launch_bounds__(64)
 k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
      const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
-     uint32_t *__restrict__ overflow, uint8_t *__restrict__ scratch, uint32_t maxcol_bytes, uint32_t group_bytes, uint32_t seg, int dbg_skip_tb)
+     uint32_t *__restrict__ overflow, uint8_t *__restrict__ scratch, uint32_t maxcol_bytes, uint32_t group_bytes, uint32_t seg, uint32_t mc_cols,
+     int dbg_skip_tb)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sw_lds[];
     const uint32_t grp = threadIdx.x >> 3, lane = threadIdx.x & 7u;
     SwLds s;
-    {
+    if (SEG == 0) {
         uint8_t *base = sw_lds + (size_t)grp * sw_group_bytes(seg);
         s.H[0] = reinterpret_cast<short *>(base); s.H[1] = s.H[0] + seg * 8; s.E = s.H[1] + seg * 8; s.Hmax = s.E + seg * 8;
         s.read = reinterpret_cast<uint8_t *>(s.Hmax + seg * 8);
+    } else {
+        s.H[0] = s.H[1] = s.E = s.Hmax = nullptr;
+        s.read = sw_lds + (size_t)grp * ((8u * seg + 15u) & ~15u);
     }
+    // windows of up to mc_cols columns keep their per-column maxima in LDS (no global store inside the column loop)
+    uint16_t *const mc_lds = reinterpret_cast<uint16_t *>(sw_lds + 8u * ((8u * seg + 15u) & ~15u)) + (size_t)grp * mc_cols;
+    // banded traceback (register variants): three band rows and the alignment's reference symbols per group
+    uint8_t *const tb_base = sw_lds + 8u * ((8u * seg + 15u) & ~15u) + 8u * mc_cols * 2u + (size_t)grp * (3u * SW_LDS_BAND * 4u + SW_LDS_REF);
+    int32_t *const tb_rows = SEG ? reinterpret_cast<int32_t *>(tb_base) : nullptr;
+    uint8_t *const tb_ref = SEG ? tb_base + 3u * SW_LDS_BAND * 4u : nullptr;
     const uint32_t n_req = pctl[0];
     uint8_t *my = scratch + ((size_t)blockIdx.x * 8 + grp) * group_bytes;
     uint16_t *maxColumn = reinterpret_cast<uint16_t *>(my);
@@ -224,37 +358,55 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
                 s.read[i] = (uint8_t)(c > 4 ? 4 : c);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            const unsigned long long t0 = dbg_skip_tb & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
             int max1, end_ref1, end_read1;
+            const bool mc_in_lds = SEG != 0 && (uint32_t)refLen <= mc_cols;
             auto fwd = [&](int q) -> uint32_t { return s.read[q]; };
-            sw_word_pass(ix, pac, aware, s, rq.start, 0, refLen, (int)L, fwd, 0xFFFF, maxColumn, max1, end_ref1, end_read1);
+            if (SEG == 0) sw_word_pass(ix, pac, aware, s, rq.start, 0, refLen, (int)L, fwd, 0xFFFF, maxColumn, max1, end_ref1, end_read1);
+            else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, aware, rq.start, 0, refLen, (int)L, fwd, 0xFFFF, maxColumn, mc_in_lds ? mc_lds : (uint16_t *)nullptr,
+                                                   max1, end_ref1, end_read1, (dbg_skip_tb & 4) ? overflow + 1 : nullptr);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
             // second best outside +-maskLen around the end column (ssw.c:529-542), maskLen = L/2 >= 15 or none
             int score2 = 0;
             const int maskLen = (int)L / 2;
             if (maskLen >= 15) {
                 int edge = end_ref1 - maskLen > 0 ? end_ref1 - maskLen : 0;
-                for (int i = (int)lane; i < edge; i += 8) { int v = maxColumn[i]; score2 = score2 > v ? score2 : v; }
+                for (int i = (int)lane; i < edge; i += 8) { int v = mc_in_lds ? mc_lds[i] : maxColumn[i]; score2 = score2 > v ? score2 : v; }
                 edge = end_ref1 + maskLen > refLen ? refLen : end_ref1 + maskLen;
-                for (int i = edge + (int)lane; i < refLen; i += 8) { int v = maxColumn[i]; score2 = score2 > v ? score2 : v; }
+                for (int i = edge + (int)lane; i < refLen; i += 8) { int v = mc_in_lds ? mc_lds[i] : maxColumn[i]; score2 = score2 > v ? score2 : v; }
                 for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(score2, o, 8); score2 = score2 > t ? score2 : t; }
             }
+            const unsigned long long t1 = dbg_skip_tb & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
             // reverse pass from the end point to find the beginning (ssw.c:817-830)
             int max2, beg_ref, beg_read_rev;
             auto rev = [&](int q) -> uint32_t { return s.read[end_read1 - q]; };
-            sw_word_pass(ix, pac, aware, s, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, max2, beg_ref, beg_read_rev);
+            if (SEG == 0) sw_word_pass(ix, pac, aware, s, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, max2, beg_ref, beg_read_rev);
+            else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, aware, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, (uint16_t *)nullptr,
+                                                   max2, beg_ref, beg_read_rev, (dbg_skip_tb & 8) ? overflow + 1 : nullptr);
             const int read_begin = end_read1 - beg_read_rev;
             out.score1 = max1; out.score2 = score2; out.ref_begin = beg_ref; out.ref_end = end_ref1; out.read_begin = read_begin; out.read_end = end_read1;
+            const unsigned long long t2 = dbg_skip_tb & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
             // banded traceback for the CIGAR (ssw.c:837-848)
             int n_cig = 0;
+            if (SEG != 0 && !(dbg_skip_tb & 1)) {                      // the alignment's reference symbols, by all 8 lanes
+                const int rfl = end_ref1 - beg_ref + 1;
+                if (rfl > 0 && rfl <= SW_LDS_REF)
+                    for (int t = (int)lane; t < rfl; t += 8) tb_ref[t] = (uint8_t)ref_symbol(ix, pac, aware, rq.start + (uint32_t)beg_ref + (uint32_t)t);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            }
             if (lane == 0) {
                 const int rfl = end_ref1 - beg_ref + 1, rdl = end_read1 - read_begin + 1;
                 int bw = rfl - rdl; bw = (bw < 0 ? -bw : bw) + 1;
-                if (dbg_skip_tb) { out.cigar[0] = (uint16_t)(rdl << 4); n_cig = 1; }
+                if (dbg_skip_tb & 1) { out.cigar[0] = (uint16_t)(rdl << 4); n_cig = 1; }
                 else if (rfl > 0 && rdl > 0)
-                    n_cig = sw_banded(ix, pac, aware, rq.start + (uint32_t)beg_ref, s.read + read_begin, rfl, rdl, max1, bw, hb, eb, hc, direction,
-                                      dir_cap, out.cigar, SALT_MAX_CIGAR_OPS);
+                    n_cig = sw_banded(ix, pac, aware, rq.start + (uint32_t)beg_ref, s.read + read_begin, rfl, rdl, max1, bw, hb, eb, hc, tb_rows, tb_ref,
+                                      direction, dir_cap, out.cigar, SALT_MAX_CIGAR_OPS);
             }
             if (lane == 0 && n_cig < 0) { atomicAdd(overflow, 1u); n_cig = 0; }
+            if ((dbg_skip_tb & 2) && lane == 0) {                                       // phase clocks (10 ns ticks), diagnostics only
+                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+                atomicAdd(overflow + 1, (uint32_t)(t1 - t0)); atomicAdd(overflow + 2, (uint32_t)(t2 - t1)); atomicAdd(overflow + 3, (uint32_t)(t3 - t2));
+            }
             n_cig = __shfl(n_cig, 0, 8);
             out.n_cigar = (uint16_t)n_cig;
             out.ok = (uint16_t)((n_cig > 0 && end_read1 - read_begin + 1 >= 20) ? 1 : 0);   // alnpe.c:297 (filters = 0, filterd = 20)
@@ -343,11 +495,25 @@ void launch_pair(uint32_t n_pairs, uint32_t min_tlen, uint32_t max_tlen, uint32_
 
 // Blocks per CU are bounded by the dynamic LDS (8 groups x sw_group_bytes), i.e. by the longest read of the batch:
 // 150-bp mates fit 8 blocks per CU where 512-bp reads fit 4.
-uint32_t sw_lds_bytes(uint32_t max_len) { const uint32_t seg = (max_len + 7) / 8; return 8u * (4u * seg * 16u + ((8u * seg + 15u) & ~15u)); }
+// stripe rows in registers for reads up to 256 bases (13 / 19 / 32 stripes of 8), in LDS beyond
+static int sw_seg_variant(uint32_t max_len)
+{
+    static const bool lds_only = getenv("SALT_GPU_SW_LDS") && atoi(getenv("SALT_GPU_SW_LDS"));
+    const uint32_t seg = (max_len + 7) / 8;
+    return lds_only ? 0 : seg <= 13 ? 13 : seg <= 19 ? 19 : seg <= 32 ? 32 : 0;
+}
+static const uint32_t SW_MC_COLS = 0;               // per-column maxima in LDS for windows up to this many columns: measured, no gain -> off
+uint32_t sw_lds_bytes(uint32_t max_len)
+{
+    const uint32_t seg = (max_len + 7) / 8, rd = (8u * seg + 15u) & ~15u;
+    return sw_seg_variant(max_len) ? 8u * rd + 8u * SW_MC_COLS * 2u + 8u * (3u * SW_LDS_BAND * 4u + SW_LDS_REF) : 8u * (4u * seg * 16u + rd);
+}
 uint32_t sw_blocks_per_cu(uint32_t max_len)
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sw, 64, sw_lds_bytes(max_len)) != hipSuccess || n < 1) n = 1;
+    const int v = sw_seg_variant(max_len);
+    const void *f = v == 13 ? (const void *)k_sw<13> : v == 19 ? (const void *)k_sw<19> : v == 32 ? (const void *)k_sw<32> : (const void *)k_sw<0>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64, sw_lds_bytes(max_len)) != hipSuccess || n < 1) n = 1;
     return (uint32_t)(n > (int)SW_MAX_BLOCKS_PER_CU ? (int)SW_MAX_BLOCKS_PER_CU : n);
 }
 // Scratch geometry of one k_sw launch: the per-column maxima cover the longest window (max_window columns), the direction
@@ -370,8 +536,16 @@ void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, con
                PeSwRes *res, uint32_t *head, uint32_t *overflow, uint8_t *scratch, SwGeom g, uint32_t max_len, hipStream_t st)
 {
     const uint32_t seg = (max_len + 7) / 8;
-    hipLaunchKernelGGL(k_sw, dim3(g.n_blocks), dim3(64), sw_lds_bytes(max_len), st, ix, pac, seqs, offs, req, pctl, res, head, overflow, scratch,
-                       g.maxcol_bytes, g.group_bytes, seg, (getenv("SALT_GPU_SW_SKIP_TB") && atoi(getenv("SALT_GPU_SW_SKIP_TB"))) ? 1 : 0);
+    const int skip_tb = getenv("SALT_GPU_SW_SKIP_TB") ? atoi(getenv("SALT_GPU_SW_SKIP_TB")) : 0;     // diagnostics: 1 = no traceback, 2 = phase clocks
+#define SALT_LAUNCH_SW(V) hipLaunchKernelGGL(k_sw<V>, dim3(g.n_blocks), dim3(64), sw_lds_bytes(max_len), st, ix, pac, seqs, offs, req, pctl, res, head, \
+                                             overflow, scratch, g.maxcol_bytes, g.group_bytes, seg, (V) ? SW_MC_COLS : 0u, skip_tb)
+    switch (sw_seg_variant(max_len)) {
+    case 13: SALT_LAUNCH_SW(13); break;
+    case 19: SALT_LAUNCH_SW(19); break;
+    case 32: SALT_LAUNCH_SW(32); break;
+    default: SALT_LAUNCH_SW(0); break;
+    }
+#undef SALT_LAUNCH_SW
 }
 
 } // namespace salt

@@ -43,6 +43,12 @@ for _ in range(K):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 same = np.array_equal(d_res.cpu().numpy().view(salt_amd.RESULT_DTYPE)[["pos", "strand", "mapq"]], res[["pos", "strand", "mapq"]])
+pc = aln.pe_counts()
+print("rescue requests %d (%.1f %% of the mates), overflowed %d" % (pc[0], 100.0 * pc[0] / (2 * n_pairs), pc[4]))
+if os.environ.get("SALT_GPU_SW_SKIP_TB") in ("4", "8"):
+    print("k_sw columns per request %.1f, lazy-F stripe steps per column %.1f" % (pc[5] / max(pc[0], 1), pc[6] / max(pc[5], 1)))
+elif pc[5]:
+    print("k_sw phase clocks per request (us): forward %.1f, reverse %.1f, traceback %.1f" % tuple(x / max(pc[0], 1) / 100.0 for x in pc[5:8]))
 print("GPU PE resident: %.3f ms per %d pairs = %.1f Mreads/s (mates/s), rows equal to the host-call rows: %s" % (dt * 1e3, n_pairs, 2 * n_pairs / dt / 1e6, same))
 ora = oracle_py.Oracle(w["prefix"])
 oo = ora.opt()
