@@ -132,12 +132,16 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
     const int lane = (int)(threadIdx.x & 7u);
     const uint64_t gmask = 0xFFull << (threadIdx.x & 56u);
     const int segLen = (readLen + 7) / 8, go = 3, ge = 1;      // aln.h:137-138
-    int H[SEG], E[SEG], Hm[SEG]; uint32_t code[SEG];
+    // Every H, E and F here lies in [0, 32767] (scores are at most the read length), where the SSE2 operations reduce to plain
+    // integer ones: adds_epi16(vH, profile) = vH + profile, subs_epu16(x, g) = max(x - g, 0).  The profile of a column is six
+    // 4-bit fields (value + 3 per read code 0..3, N, "past the read"), so a cell's lookup is one bit-field extract.
+    int H[SEG], E[SEG], Hm[SEG]; uint32_t sh[SEG];
 #pragma unroll
     for (int j = 0; j < SEG; ++j) {
         H[j] = 0; E[j] = 0; Hm[j] = 0;
         const int q = j + lane * segLen;
-        code[j] = (j < segLen && q < readLen) ? rd(q) : 5u;      // 5: past the read (profile 0)
+        const uint32_t code = (j < segLen && q < readLen) ? rd(q) : 5u;      // 5: past the read (profile 0)
+        sh[j] = 4u * (code > 5u ? 4u : code);
     }
     int max = 0, end_ref = 0, vMaxScore = 0, vMaxMark = 0;
     const int begin = ref_dir ? refLen - 1 : 0, end = ref_dir ? -1 : refLen, step = ref_dir ? -1 : 1;
@@ -152,6 +156,10 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
         if ((p >> wshift) != w_idx) { w_idx = p >> wshift; w_cur = w_next; w_next = words[(int64_t)w_idx + step < 0 ? 0 : w_idx + step]; }
         const uint32_t sym = aware ? (w_cur >> (4u * (p & 7u))) & 15u
                                    : (((w_cur >> (8u * ((p >> 2) & 3u))) & 0xFFu) >> ((~p & 3u) << 1)) & 3u;
+        // profile fields of this column (sw_score for the six codes, + 3)
+        uint32_t prof4 = 3u << 20;
+        if (aware) { if (sym == 1u || sym == 2u || sym == 4u || sym == 8u) prof4 |= 4u << (4u * (uint32_t)(__ffs((int)sym) - 1)); }
+        else prof4 |= sym > 3u ? 0x22222u : ((2u << 16) | (4u << (4u * sym)));
         int vF = 0, vMaxColumn = 0;
         int last = 0;
 #pragma unroll
@@ -161,16 +169,15 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
 #pragma unroll
         for (int j = 0; j < SEG; ++j) {
             if (j < segLen) {
-                const int prof = code[j] > 4u ? 0 : sw_score(aware, sym, code[j]);
-                int h = sat16(vH + prof);
+                int h = vH + (int)((prof4 >> sh[j]) & 15u) - 3;
                 int e = E[j];
                 h = h > e ? h : e; h = h > vF ? h : vF;
                 vMaxColumn = vMaxColumn > h ? vMaxColumn : h;
                 vH = H[j];                                       // the previous column's value: input of stripe j+1
                 H[j] = h;
-                h = subu16(h, go);
-                e = subu16(e, ge); e = e > h ? e : h; E[j] = e;
-                vF = subu16(vF, ge); vF = vF > h ? vF : h;
+                h -= go; h = h > 0 ? h : 0;
+                e -= ge; e = e > h ? e : h; E[j] = e;
+                vF -= ge; vF = vF > h ? vF : h;
             }
         }
         ++n_cols;
