@@ -410,14 +410,26 @@ class GpuAligner:
         _gpu_check(gpu_lib().salt_gpu_ws_counters(self._ws, out))
         return dict(zip(CTR_NAMES, [int(x) for x in out]))
 
+    def fork(self, max_reads=None, max_bases=None):
+        """Another workspace on the SAME device index (one per host thread / stream, as `salt` runs several per GPU).
+        Close the forks before the aligner they came from."""
+        other = GpuAligner.__new__(GpuAligner)
+        other._ix, other._owns_ix = self._ix, False
+        other._ws = ctypes.c_void_p()
+        other.max_reads = max_reads or self.max_reads
+        other.max_bases = max_bases or self.max_bases
+        other.device = self.device
+        _gpu_check(gpu_lib().salt_gpu_ws_create(self._ix, other.max_reads, other.max_bases, ctypes.byref(other._ws)))
+        return other
+
     def close(self):
         lib = gpu_lib()
         if self._ws:
             lib.salt_gpu_ws_destroy(self._ws)
             self._ws = None
-        if self._ix:
+        if self._ix and getattr(self, "_owns_ix", True):
             lib.salt_gpu_index_detach(self._ix)
-            self._ix = None
+        self._ix = None
 
 
 _NT4 = np.full(256, 4, dtype=np.uint8)

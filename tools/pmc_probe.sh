@@ -8,7 +8,7 @@ i=0
 while read -r grp; do
   [ -z "$grp" ] && continue
   i=$((i+1))
-  timeout -k 5 150 rocprofv3 --pmc $grp --output-format csv -d "$OUT/p$i" -o pmc -- python3 "$ROOT/bench.py" --no-cpu --steps 3 --warmup 2 > /dev/null 2>> "$OUT/log.txt" || echo "group $i failed: $grp"
+  timeout -k 5 150 rocprofv3 --pmc $grp --output-format csv -d "$OUT/p$i" -o pmc -- python3 "$ROOT/bench.py" --no-cpu --streams 1 --steps 3 --warmup 2 > /dev/null 2>> "$OUT/log.txt" || echo "group $i failed: $grp"
   find "$OUT/p$i" -name '*counter_collection.csv' -exec cp {} "$OUT/pmc_${i}_counter_collection.csv" \;
   rm -rf "$OUT/p$i"
   echo "[probe] group $i done: $grp"
