@@ -218,133 +218,193 @@ void launch_pack(const PackGeom &pg, uint32_t n_reads, const uint8_t *seqs, cons
 // ---------------------------------------------------------------------------------------------
 // k_seed
 // ---------------------------------------------------------------------------------------------
+// One seed = (read, strand, slot).  Every seed needs the W-mer table gather; after it most C intervals are ONE row and are
+// finished on the spot against the genome text, while the seeds that still have to walk -- C intervals with several rows
+// (repeats) and seeds alive in the R index (k-mers around SNPs, ~1 in 6) -- are minorities.  A wave pays for the longest of
+// its 64 lanes, so those walks are not done where they arise: the block collects them in LDS and its first lanes adopt them,
+// densely packed (typically one wave of the four keeps walking and the other three retire).
+struct SeedCtx {
+    const uint32_t *t2, *tn;           // 2-bit codes / N flags of this strand in the tb record
+    uint32_t L, k, W, s, wb, nb, w0, w1, w2, n0, n1;
+    bool inreg;                        // seeds of up to 33 bases sit in 3 + 2 registers (bases wb*16 .. wb*16+47)
+    __device__ __forceinline__ void init(const SeedParams &sp, const uint32_t *tb, uint32_t item, uint32_t lkt_len)
+    {
+        const uint32_t slot = item % sp.spr, rs = item / sp.spr, strand = rs & 1u, r = rs >> 1;
+        // the read as k_pack left it: 2-bit codes (first base in the high bits) and 'is N' bits of this strand
+        const uint32_t *rec = tb + (uint64_t)r * sp.pg.tb_stride;
+        t2 = rec + strand * sp.pg.nw16; tn = rec + 2 * sp.pg.nw16 + strand * sp.pg.nw32;
+        L = rec[2 * sp.pg.nw16 + 2 * sp.pg.nw32];
+        k = (uint32_t)sp.l_seed; W = lkt_len; s = slot * (uint32_t)sp.l_overlap; inreg = k <= 33;
+        wb = s >> 4; nb = s >> 5;
+        w0 = w1 = w2 = n0 = n1 = 0;
+        if (valid()) { w0 = t2[wb]; w1 = t2[wb + 1]; w2 = t2[wb + 2]; n0 = tn[nb]; n1 = tn[nb + 1]; }     // stays inside the record (PackGeom)
+    }
+    __device__ __forceinline__ bool valid() const { return L >= k && s + k <= L; }
+    __device__ __forceinline__ uint32_t base2(uint32_t i) const
+    {
+        if (inreg && i >= s) { const uint32_t rel = i - (wb << 4); const uint32_t ws = rel < 16 ? w0 : rel < 32 ? w1 : w2; return (ws >> (30 - 2 * (rel & 15u))) & 3u; }
+        return (t2[i >> 4] >> (30 - 2 * (i & 15u))) & 3u;
+    }
+    __device__ __forceinline__ bool is_n(uint32_t i) const
+    {
+        if (inreg && i >= s) { const uint32_t rel = i - (nb << 5); const uint32_t ns = rel < 32 ? n0 : n1; return (ns >> (31 - (rel & 31u))) & 1u; }
+        return (tn[i >> 5] >> (31 - (i & 31u))) & 1u;
+    }
+};
+
+// The rest of a C search (bwt.c:281-309) from interval [kc, lc] with head bases s .. s+i_top still to consume, newest first,
+// then the interval-shrinking extension (alnse.c:246-258).  A C interval of ONE row cannot branch any more: the search
+// succeeds iff the read's remaining bases equal the text in front of that suffix, so one suffix-array load and one text load
+// replace the remaining Occ steps and the seed leaves already located (.w = 2: .x = .y = the genome position).
+__device__ __forceinline__ uint4 seed_c_rest(const IndexView &ix, const SeedParams &sp, const SeedCtx &c, uint32_t kc, uint32_t lc, int i_top,
+                                             uint32_t &n_occ_c)
+{
+    const uint32_t s = c.s;
+    const bool uniq = c.inreg && sp.resolve_unique;
+    bool alive = true, located = false;
+    auto resolve_unique = [&](int it) {                      // bases s .. s+it are still to be consumed, newest first
+        const uint32_t m = (uint32_t)it + 1u;
+        const uint32_t reln = s - (c.nb << 5);
+        const uint64_t vn = ((uint64_t)c.n0 << 32) | c.n1;
+        uint32_t p0 = ix.c_sa[kc];
+        if (p0 == 0xFFFFFFFFu) p0 = ix.c_seq_len;            // row 0: the empty suffix
+        bool ok = ((vn >> (64 - reln - m)) & ((1ull << m) - 1ull)) == 0 && p0 >= m;
+        uint32_t steps = m;
+        for (uint32_t done = 0; done < m && ok; ) {          // at most two pieces of up to 16 bases, the later bases (consumed first) first
+            const uint32_t cnt = (m - done) > 16u ? 16u : (m - done);
+            const uint32_t r0 = s + (m - done - cnt), t0 = p0 - done - cnt;       // read bases r0 .. r0+cnt-1 against text t0 ..
+            const uint32_t rel = r0 - (c.wb << 4), rr = rel & 15u;
+            const uint64_t vr = rel < 16 ? (((uint64_t)c.w0 << 32) | c.w1) : (((uint64_t)c.w1 << 32) | c.w2);
+            const uint32_t xr = (uint32_t)((vr >> (64 - 2 * rr - 2 * cnt)) & ((1ull << (2 * cnt)) - 1ull));
+            const uint32_t tj = t0 >> 4, tr = t0 & 15u;
+            const uint64_t vt = ((uint64_t)ix.text[tj] << 32) | ix.text[tj + 1];
+            const uint32_t xt = (uint32_t)((vt >> (64 - 2 * tr - 2 * cnt)) & ((1ull << (2 * cnt)) - 1ull));
+            const uint32_t diff = xr ^ xt;
+            if (diff) { ok = false; steps = done + ((uint32_t)__ffs((int)diff) - 1u) / 2u + 1u; }
+            done += cnt;
+        }
+        n_occ_c += 2 * steps;
+        alive = ok;
+        if (ok) { kc = lc = p0 - m; located = true; }
+    };
+    if (uniq && kc == lc && i_top >= 0) resolve_unique(i_top);
+    for (int i = i_top; i >= 0 && alive && !located; --i) {
+        if (c.is_n(s + (uint32_t)i)) { alive = false; break; }
+        const uint32_t b = c.base2(s + (uint32_t)i);
+        uint32_t ok, ol; c_occ2(ix, kc - 1, lc, b, ok, ol);
+        { const uint32_t l2 = pick4(ix.c_L2, b); kc = l2 + ok + 1; lc = l2 + ol; } alive = kc <= lc; n_occ_c += 2;
+        if (uniq && alive && kc == lc && i > 0) resolve_unique(i - 1);
+    }
+    if (!alive) return make_uint4(1, 0, 0, 0);
+    if (located) return make_uint4(kc, kc, s, 2);
+    uint32_t ext = 0;                                         // shrink big intervals leftwards (alnse.c:246-258)
+    while (lc - kc > sp.max_seed && ext < s) {
+        if (c.is_n(s - ext - 1)) break;
+        const uint32_t b = c.base2(s - ext - 1);
+        uint32_t ok, ol; c_occ2(ix, kc - 1, lc, b, ok, ol);
+        n_occ_c += 2;
+        if (ok + 1 > ol) break;
+        { const uint32_t l2 = pick4(ix.c_L2, b); kc = l2 + ok + 1; lc = l2 + ol; } ++ext;
+        if (lc - kc <= sp.max_seed) break;
+    }
+    return make_uint4(kc, lc, s - ext, 1);
+}
+
+// The rest of an R search (rbwt.c:619-648) and its extension, which has no N guard (alnse.c:279-291)
+__device__ __forceinline__ uint4 seed_r_rest(const IndexView &ix, const SeedParams &sp, const SeedCtx &c, uint32_t kr, uint32_t lr, int i_top,
+                                             uint32_t &n_occ_r)
+{
+    const uint32_t s = c.s;
+    bool alive = true;
+    for (int i = i_top; i >= 0 && alive; --i) {
+        if (c.is_n(s + (uint32_t)i)) { alive = false; break; }
+        const uint32_t b = c.base2(s + (uint32_t)i);
+        uint32_t ok, ol; r_occ2(ix, kr, lr + 1, b, ok, ol);
+        { const uint32_t cm = pick5(ix.r_cum, b); kr = cm + ok + 1; lr = cm + ol; } alive = kr <= lr; n_occ_r += 2;
+    }
+    if (!alive) return make_uint4(1, 0, 0, 0);
+    uint32_t ext = 0;
+    while (lr - kr > sp.max_seed && ext < s) {
+        const uint32_t b = c.is_n(s - ext - 1) ? 4u : c.base2(s - ext - 1);               // an N walks the '#' column
+        uint32_t ok, ol; r_occ2(ix, kr, lr + 1, b, ok, ol);
+        n_occ_r += 2;
+        if (ok + 1 > ol) break;
+        { const uint32_t cm = pick5(ix.r_cum, b); kr = cm + ok + 1; lr = cm + ol; } ++ext;
+        if (lr - kr <= sp.max_seed) break;
+    }
+    return make_uint4(kr, lr, s - ext, 1);
+}
+
 __global__ void __launch_bounds__(256)
 k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
        uint4 *__restrict__ sai_c, uint4 *__restrict__ sai_r, unsigned long long *__restrict__ ctr)
 {
-    const uint64_t item = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // walks still to do, collected per block: [0][..] R searches, [1][..] C searches: (lane of the block that owns the seed, k, l)
+    __shared__ uint32_t q_who[2][256], q_k[2][256], q_l[2][256];
+    __shared__ uint32_t q_n[2];
+    const uint64_t block_item0 = (uint64_t)blockIdx.x * blockDim.x;
+    const uint64_t item = block_item0 + threadIdx.x, n_items = (uint64_t)sp.n_reads * 2u * sp.spr;
+    const uint64_t lt = (1ull << lane_id()) - 1ull;
     uint32_t n_lkt = 0, n_occ_c = 0, n_occ_r = 0;
-    if (item < (uint64_t)sp.n_reads * 2u * sp.spr) {
-        const uint32_t slot = (uint32_t)(item % sp.spr);
-        const uint32_t rs = (uint32_t)(item / sp.spr);
-        const int strand = (int)(rs & 1u);
-        const uint32_t r = rs >> 1;
-        // the read as k_pack left it: 2-bit codes (first base in the high bits) and 'is N' bits of this strand
-        const uint32_t *rec = tb + (uint64_t)r * sp.pg.tb_stride;
-        const uint32_t *t2 = rec + (uint32_t)strand * sp.pg.nw16, *tn = rec + 2 * sp.pg.nw16 + (uint32_t)strand * sp.pg.nw32;
-        const uint32_t L = rec[2 * sp.pg.nw16 + 2 * sp.pg.nw32];
-        const uint32_t k = (uint32_t)sp.l_seed, s = slot * (uint32_t)sp.l_overlap;
+    if (threadIdx.x < 2) q_n[threadIdx.x] = 0;
+    __syncthreads();
+    bool pend_c = false, pend_r = false;
+    uint32_t pk_c = 0, pl_c = 0, pk_r = 0, pl_r = 0;
+    if (item < n_items) {
+        SeedCtx c; c.init(sp, tb, (uint32_t)item, ix.r_lkt_len);
         uint4 oc = make_uint4(1, 0, 0, 0), orr = make_uint4(1, 0, 0, 0);
-        if (L >= k && s + k <= L) {
-            const uint32_t e = s + k - 1, W = ix.r_lkt_len;
-            // seeds of up to 33 bases sit in 3 + 2 registers (bases wb*16 .. wb*16+47); longer ones read the record
-            const bool inreg = k <= 33, uniq = inreg && sp.resolve_unique;
-            const uint32_t wb = s >> 4, nb = s >> 5;
-            const uint32_t w0 = t2[wb], w1 = t2[wb + 1], w2 = t2[wb + 2];       // stays inside the record (PackGeom)
-            const uint32_t n0 = tn[nb], n1 = tn[nb + 1];
-            auto base2 = [&](uint32_t i) -> uint32_t {
-                if (inreg && i >= s) { const uint32_t rel = i - (wb << 4); const uint32_t ws = rel < 16 ? w0 : rel < 32 ? w1 : w2; return (ws >> (30 - 2 * (rel & 15u))) & 3u; }
-                return (t2[i >> 4] >> (30 - 2 * (i & 15u))) & 3u;
-            };
-            auto is_n = [&](uint32_t i) -> bool {
-                if (inreg && i >= s) { const uint32_t rel = i - (nb << 5); const uint32_t ns = rel < 32 ? n0 : n1; return (ns >> (31 - (rel & 31u))) & 1u; }
-                return (tn[i >> 5] >> (31 - (i & 31u))) & 1u;
-            };
+        if (c.valid()) {
+            const uint32_t e = c.s + c.k - 1, W = c.W;
             // W-mer at the seed tail: both searches start from their tabulated interval
             // (LKT_seq2LktItem / LKT_lookup_sa lookup.c:163-177 + the first steps of bwt.c:281-309, rbwt.c:619-648)
             uint32_t x = 0; bool has_n = false;
             const uint32_t a0 = e - W + 1;
-            if (inreg) {
-                const uint32_t rel = a0 - (wb << 4), rr = rel & 15u;
-                const uint64_t v = rel < 16 ? (((uint64_t)w0 << 32) | w1) : rel < 32 ? (((uint64_t)w1 << 32) | w2) : ((uint64_t)w2 << 32);
+            if (c.inreg) {
+                const uint32_t rel = a0 - (c.wb << 4), rr = rel & 15u;
+                const uint64_t v = rel < 16 ? (((uint64_t)c.w0 << 32) | c.w1) : rel < 32 ? (((uint64_t)c.w1 << 32) | c.w2) : ((uint64_t)c.w2 << 32);
                 x = (uint32_t)((v >> (64 - 2 * rr - 2 * W)) & ((1ull << (2 * W)) - 1ull));
-                const uint32_t reln = a0 - (nb << 5);
-                const uint64_t vn = ((uint64_t)n0 << 32) | n1;
+                const uint32_t reln = a0 - (c.nb << 5);
+                const uint64_t vn = ((uint64_t)c.n0 << 32) | c.n1;
                 has_n = ((vn >> (64 - reln - W)) & ((1ull << W) - 1ull)) != 0;
             } else {
-                for (uint32_t t = 0; t < W; ++t) { has_n |= is_n(a0 + t); x = (x << 2) | base2(a0 + t); }
+                for (uint32_t t = 0; t < W; ++t) { has_n |= c.is_n(a0 + t); x = (x << 2) | c.base2(a0 + t); }
             }
-            uint32_t kc = 1, lc = 0, kr = 1, lr = 0;
-            bool alive_c = !has_n, alive_r = !has_n && !sp.seed_only_ref;
-            if (alive_c) {
+            if (!has_n) {
                 const uint4 v = ix.wlkt[x];                  // one 16-byte gather: C interval in .x/.y, R interval in .z/.w
-                kc = v.x; lc = v.y; alive_c = kc <= lc; ++n_lkt; n_occ_c += 2 * (W - ix.lkt_len);
-                if (alive_r) { kr = v.z; lr = v.w; alive_r = kr <= lr; n_occ_r += 2 * W; }
-            }
-            const int i_r_start = (int)(k - W) - 1;         // first head index still to consume
-            bool c_located = false;                          // the C interval is one row and has been resolved to its text position
-            // A C interval of ONE row cannot branch any more: the rest of its backward search (bwt.c:281-309) succeeds iff the
-            // read's remaining bases equal the text in front of that suffix.  One suffix-array load and one text load replace up
-            // to k - W Occ steps, and the seed leaves k_seed already located (flag 2: .x = .y = the genome position).
-            auto resolve_unique = [&](int i_top) {           // bases s .. s+i_top are still to be consumed, newest first
-                const uint32_t m = (uint32_t)i_top + 1u;
-                const uint32_t reln = s - (nb << 5);
-                const uint64_t vn = ((uint64_t)n0 << 32) | n1;
-                uint32_t p0 = ix.c_sa[kc];
-                if (p0 == 0xFFFFFFFFu) p0 = ix.c_seq_len;    // row 0: the empty suffix
-                bool ok = ((vn >> (64 - reln - m)) & ((1ull << m) - 1ull)) == 0 && p0 >= m;
-                uint32_t steps = m;
-                for (uint32_t done = 0; done < m && ok; ) {  // at most two pieces of up to 16 bases, the later bases (consumed first) first
-                    const uint32_t cnt = (m - done) > 16u ? 16u : (m - done);
-                    const uint32_t r0 = s + (m - done - cnt), t0 = p0 - done - cnt;       // read bases r0 .. r0+cnt-1 against text t0 ..
-                    const uint32_t rel = r0 - (wb << 4), rr = rel & 15u;
-                    const uint64_t vr = rel < 16 ? (((uint64_t)w0 << 32) | w1) : (((uint64_t)w1 << 32) | w2);
-                    const uint32_t xr = (uint32_t)((vr >> (64 - 2 * rr - 2 * cnt)) & ((1ull << (2 * cnt)) - 1ull));
-                    const uint32_t tj = t0 >> 4, tr = t0 & 15u;
-                    const uint64_t vt = ((uint64_t)ix.text[tj] << 32) | ix.text[tj + 1];
-                    const uint32_t xt = (uint32_t)((vt >> (64 - 2 * tr - 2 * cnt)) & ((1ull << (2 * cnt)) - 1ull));
-                    const uint32_t diff = xr ^ xt;
-                    if (diff) { ok = false; steps = done + ((uint32_t)__ffs((int)diff) - 1u) / 2u + 1u; }
-                    done += cnt;
+                ++n_lkt; n_occ_c += 2 * (W - ix.lkt_len);
+                const int i_top = (int)(c.k - W) - 1;        // head bases s .. s+i_top are still to consume
+                if (v.x <= v.y) {
+                    if ((v.x == v.y && c.inreg && sp.resolve_unique) || i_top < 0) oc = seed_c_rest(ix, sp, c, v.x, v.y, i_top, n_occ_c);   // no walk left (or only the extension)
+                    else { pend_c = true; pk_c = v.x; pl_c = v.y; }
                 }
-                n_occ_c += 2 * steps;
-                alive_c = ok;
-                if (ok) { kc = lc = p0 - m; c_located = true; }
-            };
-            if (uniq && alive_c && kc == lc && i_r_start >= 0) resolve_unique(i_r_start);
-            // joint backward search over the seed head, newest base last (bwt.c:281-309, rbwt.c:619-648)
-            for (int i = i_r_start; i >= 0 && ((alive_c && !c_located) || alive_r); --i) {
-                if (is_n(s + (uint32_t)i)) { if (!c_located) alive_c = false; alive_r = false; break; }
-                const uint32_t c = base2(s + (uint32_t)i);
-                if (alive_c && !c_located) {
-                    uint32_t ok, ol; c_occ2(ix, kc - 1, lc, c, ok, ol);
-                    { const uint32_t l2 = pick4(ix.c_L2, c); kc = l2 + ok + 1; lc = l2 + ol; } alive_c = kc <= lc; n_occ_c += 2;
-                    if (uniq && alive_c && kc == lc && i > 0) resolve_unique(i - 1);
+                if (!sp.seed_only_ref) {
+                    n_occ_r += 2 * W;
+                    if (v.z <= v.w) { pend_r = true; pk_r = v.z; pl_r = v.w; }
                 }
-                if (alive_r) {
-                    uint32_t ok, ol; r_occ2(ix, kr, lr + 1, c, ok, ol);
-                    { const uint32_t cm = pick5(ix.r_cum, c); kr = cm + ok + 1; lr = cm + ol; } alive_r = kr <= lr; n_occ_r += 2;
-                }
-            }
-            if (c_located) oc = make_uint4(kc, kc, s, 2);
-            if (alive_c && !c_located) {                      // shrink big intervals leftwards (alnse.c:246-258)
-                uint32_t ext = 0;
-                while (lc - kc > sp.max_seed && ext < s) {
-                    if (is_n(s - ext - 1)) break;
-                    const uint32_t c = base2(s - ext - 1);
-                    uint32_t ok, ol; c_occ2(ix, kc - 1, lc, c, ok, ol);
-                    n_occ_c += 2;
-                    if (ok + 1 > ol) break;
-                    { const uint32_t l2 = pick4(ix.c_L2, c); kc = l2 + ok + 1; lc = l2 + ol; } ++ext;
-                    if (lc - kc <= sp.max_seed) break;
-                }
-                oc = make_uint4(kc, lc, s - ext, 1);
-            }
-            if (alive_r) {                                    // same, without the N guard (alnse.c:279-291)
-                uint32_t ext = 0;
-                while (lr - kr > sp.max_seed && ext < s) {
-                    const uint32_t c = is_n(s - ext - 1) ? 4u : base2(s - ext - 1);       // an N walks the '#' column
-                    uint32_t ok, ol; r_occ2(ix, kr, lr + 1, c, ok, ol);
-                    n_occ_r += 2;
-                    if (ok + 1 > ol) break;
-                    { const uint32_t cm = pick5(ix.r_cum, c); kr = cm + ok + 1; lr = cm + ol; } ++ext;
-                    if (lr - kr <= sp.max_seed) break;
-                }
-                orr = make_uint4(kr, lr, s - ext, 1);
             }
         }
-        sai_c[item] = oc;
-        sai_r[item] = orr;
+        if (!pend_c) sai_c[item] = oc;
+        if (!pend_r) sai_r[item] = orr;
+    }
+    // collect: one LDS atomic per wave and list
+    {
+        const uint64_t mr = __ballot(pend_r), mc = __ballot(pend_c);
+        uint32_t br = 0, bc = 0;
+        if (lane_id() == 0) { if (mr) br = atomicAdd(&q_n[0], (uint32_t)__popcll(mr)); if (mc) bc = atomicAdd(&q_n[1], (uint32_t)__popcll(mc)); }
+        br = (uint32_t)__shfl((int)br, 0); bc = (uint32_t)__shfl((int)bc, 0);
+        if (pend_r) { const uint32_t at = br + (uint32_t)__popcll(mr & lt); q_who[0][at] = threadIdx.x; q_k[0][at] = pk_r; q_l[0][at] = pl_r; }
+        if (pend_c) { const uint32_t at = bc + (uint32_t)__popcll(mc & lt); q_who[1][at] = threadIdx.x; q_k[1][at] = pk_c; q_l[1][at] = pl_c; }
+    }
+    __syncthreads();
+    // adopt: lane t takes walk t of the concatenated lists (R first)
+    const uint32_t nr = q_n[0], nc = q_n[1];
+    for (uint32_t t = threadIdx.x; t < nr + nc; t += blockDim.x) {
+        const uint32_t which = t < nr ? 0u : 1u, at = which ? t - nr : t;
+        const uint64_t it = block_item0 + q_who[which][at];
+        SeedCtx c; c.init(sp, tb, (uint32_t)it, ix.r_lkt_len);
+        const int i_top = (int)(c.k - c.W) - 1;
+        if (which == 0) sai_r[it] = seed_r_rest(ix, sp, c, q_k[0][at], q_l[0][at], i_top, n_occ_r);
+        else sai_c[it] = seed_c_rest(ix, sp, c, q_k[1][at], q_l[1][at], i_top, n_occ_c);
     }
     if (ctr) {                                                // one atomic per wave and counter
         for (int o = 32; o > 0; o >>= 1) {
