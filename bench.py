@@ -50,7 +50,7 @@ def algorithmic_bytes(ctr, L):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("SALT_BENCH_WORKLOAD", "chr21"))
     ap.add_argument("--cpu-sample", type=int, default=200000, help="reads given to the CPU baseline")
