@@ -32,6 +32,13 @@ static_assert(offsetof(salt_result_t, strand) == 4 && offsetof(salt_result_t, ma
               offsetof(salt_result_t, n_hits) == 20 && offsetof(salt_result_t, n_cigar) == 22 && offsetof(salt_result_t, skipped) == 23 &&
               offsetof(salt_result_t, hits) == 24 && sizeof(salt_hit_t) == 8, "salt_result_t header layout");
 static constexpr int NHIT = 6;                  // first hits kept per strand (5 + the primary)
+// gen_mapq's quotient 255 * x / b0 (query.c:270-281; x = |b0 - b1| <= 100000, so the product fits 32 bits).  b0 <= 3 whenever the
+// best hit is gap-free: constant divisors there instead of a runtime division (a 64-bit one costs ~100 instructions per read).
+__device__ __forceinline__ uint32_t mapq_quot(uint32_t x, uint32_t b0)
+{
+    const uint32_t v = 255u * x;
+    return b0 == 1u ? v : b0 == 2u ? v / 2u : b0 == 3u ? v / 3u : v / b0;
+}
 static constexpr uint32_t INF = 255;
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -1403,7 +1410,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     uint32_t mapq = 0;
     if (b0 != 0) {                                            // integer form of 255*|b0-b1|/b0, identical for all inputs
         uint32_t x = (uint32_t)(b0 > b1 ? b0 - b1 : b1 - b0);
-        uint64_t q = (uint64_t)255 * x / (uint32_t)b0;
+        uint64_t q = mapq_quot(x, (uint32_t)b0);
         mapq = q < 254 ? (uint32_t)q : 254u;
     }
     if (lane == 0) {
@@ -1592,7 +1599,7 @@ k_gapfin(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, salt_res
         uint32_t mapq = 0;
         if (b0 != 0) {
             const uint32_t x = (uint32_t)(b0 > b1 ? b0 - b1 : b1 - b0);
-            const uint64_t q = (uint64_t)255 * x / (uint32_t)b0;
+            const uint64_t q = mapq_quot(x, (uint32_t)b0);
             mapq = q < 254 ? (uint32_t)q : 254u;
         }
         const uint32_t n_cig_items = q_pos != 0xFFFFFFFFu ? 1u + nh[0] + nh[1] : 0u;
@@ -1846,7 +1853,7 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
                 uint32_t mapq = 0;
                 if (b0 != 0) {
                     const uint32_t x = (uint32_t)(b0 > b1 ? b0 - b1 : b1 - b0);
-                    const uint64_t q = (uint64_t)255 * x / (uint32_t)b0;
+                    const uint64_t q = mapq_quot(x, (uint32_t)b0);
                     mapq = q < 254 ? (uint32_t)q : 254u;
                 }
                 salt_result_t *out = results + r;
@@ -2130,7 +2137,7 @@ k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
                 uint32_t mapq = 0;
                 if (b0 != 0) {
                     const uint32_t x = (uint32_t)(b0 > b1 ? b0 - b1 : b1 - b0);
-                    const uint64_t qq = (uint64_t)255 * x / (uint32_t)b0;
+                    const uint64_t qq = mapq_quot(x, (uint32_t)b0);
                     mapq = qq < 254 ? (uint32_t)qq : 254u;
                 }
                 salt_result_t *out = results + r;
@@ -2177,7 +2184,7 @@ k_pe_final(PackGeom pg, uint32_t n_pairs, const uint32_t *__restrict__ pm,
         salt_result_t *q = res + 2 * p + rescued;
         const int b0 = r.score1, b1 = r.score2;
         uint32_t mapq = 0;
-        if (b0 != 0) { const uint32_t x = (uint32_t)(b0 > b1 ? b0 - b1 : b1 - b0); const uint64_t v = (uint64_t)255 * x / (uint32_t)b0; mapq = v < 254 ? (uint32_t)v : 254u; }
+        if (b0 != 0) { const uint32_t x = (uint32_t)(b0 > b1 ? b0 - b1 : b1 - b0); const uint64_t v = mapq_quot(x, (uint32_t)b0); mapq = v < 254 ? (uint32_t)v : 254u; }
         q->b0 = b0; q->b1 = b1; q->mapq = (uint8_t)mapq;
         q->pos = (uint32_t)r.ref_begin + r.start; q->strand = (uint8_t)r.strand;
         q->seq_start = (uint16_t)r.read_begin; q->seq_end = (uint16_t)r.read_end;
