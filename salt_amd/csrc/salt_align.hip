@@ -685,6 +685,9 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
 // ---- masked Hamming distance, capped: returns 0..3 or INF (ed_mismatch, editdistance.c:88-163) ----
 __device__ __forceinline__ uint32_t mismatch_capped(const IndexView &ix, const uint32_t *pm, uint32_t L, uint32_t pos)
 {
+    // a locate whose `pos - offset` wrapped below 0 survives the range check the way it does in the reference (alnse.c:672-673) and is
+    // only dropped by the candidate rule (pos >= mixRef.l, alnse.c:762): it must not be used as an address
+    if (pos >= ix.ref_len) return INF;
     const uint32_t nw = (L + 7) >> 3, w0 = pos >> 3, sh = (pos & 7u) * 4u;
     const uint32_t *ref = ix.ref + w0;
     uint32_t lo = ref[0], mism = 0;
@@ -765,7 +768,7 @@ __device__ __forceinline__ uint32_t quad_mismatch(const u32x4_a4 x, const uint32
 }
 
 template <int G>                                                         // groups of 16 candidates whose loads are in flight together
-__device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, const uint32_t *pm, uint32_t L,
+__device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, uint32_t ref_len, const uint32_t *pm, uint32_t L,
                                              const uint32_t *cand, uint32_t n, uint8_t *out)
 {
     const uint32_t lane = lane_id(), sub = lane & 3u, q = lane >> 2;
@@ -782,19 +785,20 @@ __device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, c
             const uint32_t c = c0 + 16u * g + q;
             act[g] = c < n;
             pos[g] = act[g] ? cand[c] : 0u;
-            x[g] = *reinterpret_cast<const u32x4_a4 *>(ref + (pos[g] >> 3) + 4 * sub);
+            if (pos[g] >= ref_len) pos[g] = 0xFFFFFFFFu;                 // wrapped below 0 (see mismatch_capped): no load, INF
+            x[g] = *reinterpret_cast<const u32x4_a4 *>(ref + ((pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) + 4 * sub);
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (c0 + 16u * g >= n) break;
             const uint32_t mism = quad_mismatch(x[g], pos[g], pmw, nvalid);
-            if (act[g] && sub == 0) out[c0 + 16u * g + q] = (uint8_t)(mism > 3 ? INF : mism);
+            if (act[g] && sub == 0) out[c0 + 16u * g + q] = (uint8_t)((mism > 3 || pos[g] == 0xFFFFFFFFu) ? INF : mism);
         }
     }
 }
 
 // Both strands of one read in the same trips (k_light): candidates c0[0..n0) use pm0, c1[0..n1) use pm1.
-__device__ __forceinline__ void verify_quads_2(const uint32_t *__restrict__ ref, const uint32_t *pm0, const uint32_t *pm1, uint32_t L,
+__device__ __forceinline__ void verify_quads_2(const uint32_t *__restrict__ ref, uint32_t ref_len, const uint32_t *pm0, const uint32_t *pm1, uint32_t L,
                                                const uint32_t *c0, uint32_t n0, const uint32_t *c1, uint32_t n1, uint8_t *o0, uint8_t *o1)
 {
     const uint32_t lane = lane_id(), sub = lane & 3u, q = lane >> 2;
@@ -811,7 +815,8 @@ __device__ __forceinline__ void verify_quads_2(const uint32_t *__restrict__ ref,
             const uint32_t c = b + 16u * g + q;
             act[g] = c < n; rev[g] = c >= n0;
             pos[g] = act[g] ? (rev[g] ? c1[c - n0] : c0[c]) : 0u;
-            x[g] = *reinterpret_cast<const u32x4_a4 *>(ref + (pos[g] >> 3) + 4 * sub);
+            if (pos[g] >= ref_len) pos[g] = 0xFFFFFFFFu;
+            x[g] = *reinterpret_cast<const u32x4_a4 *>(ref + ((pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) + 4 * sub);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -820,7 +825,7 @@ __device__ __forceinline__ void verify_quads_2(const uint32_t *__restrict__ ref,
             const uint32_t mism = quad_mismatch(x[g], pos[g], pw, nvalid);
             if (act[g] && sub == 0) {
                 const uint32_t c = b + 16u * g + q;
-                const uint8_t v = (uint8_t)(mism > 3 ? INF : mism);
+                const uint8_t v = (uint8_t)((mism > 3 || pos[g] == 0xFFFFFFFFu) ? INF : mism);
                 if (rev[g]) o1[c - n0] = v; else o0[c] = v;
             }
         }
@@ -1257,7 +1262,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         const uint32_t n_loc = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
         uint32_t call_best_n = INF, call_best_pos = 0;
         auto verify_all = [&](uint32_t n) {                   // cand_e[i] = min(mismatches, INF) of loci[i], loads of 128 candidates in flight
-            if (L <= 120) verify_quads<8>(ix.ref, w.pm[strand], L, loci, n, cand_e);
+            if (L <= 120) verify_quads<8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
             else for (uint32_t i = lane; i < n; i += 64) cand_e[i] = (uint8_t)mismatch_capped(ix, w.pm[strand], L, loci[i]);
             WSYNC();
         };
@@ -1813,7 +1818,7 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
             uint32_t n_hits_s[2] = { 0, 0 }, a0[2] = { 0, 0 };
             bool found[2] = { false, false };
             {
-                if (L <= 120) verify_quads_2(ix.ref, w.pm[0], w.pm[1], L, w.loci[0], n_s[0], w.loci[1], n_s[1], w.val[0], w.val[1]);
+                if (L <= 120) verify_quads_2(ix.ref, ix.ref_len, w.pm[0], w.pm[1], L, w.loci[0], n_s[0], w.loci[1], n_s[1], w.val[0], w.val[1]);
                 else
                     for (int s = 0; s < 2; ++s)
                         for (uint32_t i = lane; i < n_s[s]; i += 64) w.val[s][i] = (uint8_t)mismatch_capped(ix, w.pm[s], L, w.loci[s][i]);
@@ -2090,7 +2095,8 @@ k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
                         const uint32_t c = b + 8u * g + q;
                         act[g] = c < n; rev[g] = c >= n_s[0];
                         pos[g] = act[g] ? (rev[g] ? w.loci[1][c - n_s[0]] : w.loci[0][c]) : 0u;
-                        x[g] = *reinterpret_cast<const u32x4_a4 *>(ix.ref + (pos[g] >> 3) + 4 * sub);
+                        if (pos[g] >= ix.ref_len) pos[g] = 0xFFFFFFFFu;      // wrapped below 0 (see mismatch_capped): no load, INF
+                        x[g] = *reinterpret_cast<const u32x4_a4 *>(ix.ref + ((pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) + 4 * sub);
                     }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -2099,7 +2105,7 @@ k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
                         const uint32_t mism = quad_mismatch(x[g], pos[g], pw, nvalid);
                         if (act[g] && sub == 0) {
                             const uint32_t c = b + 8u * g + q;
-                            const uint8_t v = (uint8_t)(mism > 3 ? INF : mism);
+                            const uint8_t v = (uint8_t)((mism > 3 || pos[g] == 0xFFFFFFFFu) ? INF : mism);
                             if (rev[g]) w.val[1][c - n_s[0]] = v; else w.val[0][c] = v;
                         }
                     }

@@ -474,3 +474,26 @@ def test_cli_reads_the_fastq_shapes_kseq_reads(tmp_path):
     open(fa, "w").write(">r1\nACGTACGTACGTACGTACGTACGTACGT\n")
     r = subprocess.run([salt, "-d", "-c", prefix, fa], capture_output=True)
     assert r.returncode != 0 and b"FASTA" in r.stderr
+
+
+@pytest.mark.parametrize("k", [12, 16, 25, 33, 34, 40])
+def test_cli_seed_lengths_equal_the_oracle(k, oracle_cli, tmp_path):
+    """The seed length is the INDEX's (`salt-idx -k`, default 25; `.R.seedLen`): k = 12 and 16 end inside the W-mer table (no walk
+    at all), 25 is the indexer's default, 33 / 34 straddle the in-register seed limit of k_seed, 40 takes its per-base path.  SAM
+    of the C++ CLI against the CPU oracle's, SE with two strides and PE; the oracle equals the real reference on the SE rows for
+    all six k (checked in the build container)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt, salt_idx = os.path.join(root, "salt_amd", "bin", "salt"), os.path.join(root, "salt_amd", "bin", "salt-idx")
+    prefix = str(tmp_path / "idx")
+    subprocess.run([salt_idx, "-k", str(k), os.path.join(LAMBDA, "genome.fa"), os.path.join(LAMBDA, "snps.txt"), prefix],
+                   check=True, stderr=subprocess.DEVNULL)
+    strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    se = [os.path.join(LAMBDA, "reads_ragged.fq")]
+    pe = [os.path.join(LAMBDA, "reads_pe_1.fq"), os.path.join(LAMBDA, "reads_pe_2.fq")]
+    for args, files in ((["-d", "-c"], se), (["-d", "-c", "-r", "7"], se), (["-d", "-c", "-p", "-a", "350", "-b", "650"], pe)):
+        got = subprocess.run([salt] + args + [prefix] + files, capture_output=True)
+        want = subprocess.run([oracle_cli] + args + [prefix] + files, capture_output=True)
+        assert got.returncode == want.returncode == 0, (k, args, got.stderr[-300:])
+        g, w = strip(got.stdout).split(b"\n"), strip(want.stdout).split(b"\n")
+        bad = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]
+        assert not bad and len(g) == len(w), (k, args, len(bad), [(g[i][:200], w[i][:200]) for i in bad[:2]])
