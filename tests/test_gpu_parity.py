@@ -497,3 +497,22 @@ def test_cli_seed_lengths_equal_the_oracle(k, oracle_cli, tmp_path):
         g, w = strip(got.stdout).split(b"\n"), strip(want.stdout).split(b"\n")
         bad = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]
         assert not bad and len(g) == len(w), (k, args, len(bad), [(g[i][:200], w[i][:200]) for i in bad[:2]])
+
+
+def test_cli_with_the_smallest_kmer_table_has_no_wild_loads(tmp_path):
+    """A locate whose `pos - offset` wraps below 0 passes the reference's range check (alnse.c:672-673) and is only dropped by
+    the candidate rule; used as an address it reads ~2 GiB past the mixRef, which the 64 GiB W-mer table behind it hides.  With
+    SALT_GPU_LKT_LEN=12 (268 MB table) such a load faults: the reads hanging over the genome's start must still give the
+    reference's SAM."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt, salt_idx = os.path.join(root, "salt_amd", "bin", "salt"), os.path.join(root, "salt_amd", "bin", "salt-idx")
+    prefix = str(tmp_path / "idx")
+    subprocess.run([salt_idx, "-k", "19", os.path.join(LAMBDA, "genome.fa"), os.path.join(LAMBDA, "snps.txt"), prefix],
+                   check=True, stderr=subprocess.DEVNULL)
+    env = dict(os.environ, SALT_GPU_LKT_LEN="12")
+    for case in ("span_default", "ragged_r7_s10"):
+        args, files = EXTRA_CASES[case]
+        out = subprocess.run([salt] + args + [prefix] + [os.path.join(LAMBDA, f) for f in files], capture_output=True, env=env)
+        assert out.returncode == 0, out.stderr[-300:]
+        got = b"".join(l for l in out.stdout.splitlines(keepends=True) if not l.startswith(b"@PG"))
+        assert got == open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read(), case
