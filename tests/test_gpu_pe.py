@@ -200,3 +200,32 @@ def test_gpu_pe_locate_cap_is_the_references(tmp_path):
     detail = [(int(i), [(f, res[f][i].tolist(), want[f][i].tolist()) for f in ("pos", "strand", "n_diff", "is_gap", "mapq", "b0", "b1")]) for i in bad[:4]]
     assert len(bad) == 0, (len(bad), detail)
     assert (want["pos"] != 0xFFFFFFFF).mean() > 0.9
+
+
+@pytest.mark.parametrize("L,window", [(100, ("250", "550")), (200, ("400", "1100")), (300, ("600", "1500")), (500, ("1000", "2400"))])
+def test_gpu_pe_long_mates_match_oracle(tiny_pe, L, window):
+    """k_sw has one variant per stripe count (13 / 19 / 32 stripes of 8 in registers, rows in LDS beyond 256 bases) and the seed /
+    verify / LV kernels have their own length classes: mates of 100, 200, 300 and 500 bases against the oracle, every field."""
+    import sys
+    import salt_amd
+    from salt_amd import workload
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    w, _, _ = tiny_pe
+    seqs, offs, _, _ = workload.make_pairs(w["genome"], w["snp_pos"], w["snp_mask"], 1200, L, seed=21 + L,
+                                           insert_mean=int(window[0]) + 3 * L // 2, insert_sd=30)
+    idx = salt_amd.Index.reload(w["prefix"])
+    opt, _ = salt_amd.AlnOpt.from_argv(["-p", "-a", window[0], "-b", window[1]], idx.l_seed)
+    aln = salt_amd.GpuAligner(idx, device=0, max_reads=len(offs) - 1, max_bases=int(offs[-1]) + 64)
+    res = aln.alnpe_core1(opt, idx, seqs, offs)
+    pc = aln.pe_counts()
+    aln.close()
+    ora = oracle_py.Oracle(w["prefix"])
+    oo = ora.opt(l_overlap=opt.l_overlap, max_seed=opt.max_seed, max_locate=opt.max_locate, seed_only_ref=opt.seed_only_ref)
+    want = ora.align_pe(oo, seqs, offs, opt.min_tlen, opt.max_tlen, n_threads=16)
+    ora.close()
+    idx.destroy()
+    bad = oracle_py.compare(res, want, pe=True)
+    detail = [(int(i), [(f, res[f][i].tolist(), want[f][i].tolist()) for f in ("pos", "strand", "n_diff", "is_gap", "mapq", "b0", "b1", "seq_start", "seq_end")]) for i in bad[:4]]
+    assert len(bad) == 0, (len(bad), detail)
+    assert pc[0] > 50 and pc[4] == 0, pc                # rescues ran, none overflowed
