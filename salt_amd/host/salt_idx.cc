@@ -413,6 +413,9 @@ extern "C" int salt_idx_build(const char *fn_fa, const char *fn_snp, const char 
                 for (int c = 0; c < 5; ++c) {
                     uint32_t v = run[c] - base[c];
                     if (e % 2 == 0) occ[(size_t)(e / 2) * 5 + c] |= v << 16; else occ[(size_t)(e / 2) * 5 + c] |= v & 0xFFFFu;
+                    // the last word always gets both halves (4bit_bwt_gen.c:1146-1163): with an odd number of values its low half
+                    // repeats the high one
+                    if (e + 1 == n_val && e % 2 == 0) occ[(size_t)(e / 2) * 5 + c] |= v & 0xFFFFu;
                 }
                 for (uint32_t q = 0; q < 256; ++q) {
                     uint64_t p = (uint64_t)e * 256 + q;
@@ -460,7 +463,10 @@ extern "C" int salt_idx_build(const char *fn_fa, const char *fn_snp, const char 
         for (auto &c : fa) {
             for (size_t i = 0; i < c.seq.size(); ++i) {
                 uint32_t p = tot_l + (uint32_t)i;
-                ref[p >> 3] |= (uint32_t)M[nt4((unsigned char)c.seq[i])] << (4 * (p & 7u));
+                // __clear_pac + __set_pac (mixRef.c:143-146): the i-th SNP GROUP is applied to the i-th contig whatever its name
+                // (mixRef.c:149-152), so a contig without SNPs shifts the later groups one contig down; what such a group writes
+                // past its contig's end is wiped here when the next contig is laid down
+                ref[p >> 3] = (ref[p >> 3] & ~(15u << (4 * (p & 7u)))) | ((uint32_t)M[nt4((unsigned char)c.seq[i])] << (4 * (p & 7u)));
             }
             int rc = hm.next_group();
             if (rc == 0)

@@ -36,6 +36,37 @@ def test_builder_writes_reference_identical_files(tmp_path):
     assert sha == open(os.path.join(LAMBDA, "idx.C.lkt.sha256")).read().strip()
 
 
+import pytest                                             # noqa: E402
+from conftest import GOLDEN                               # noqa: E402
+INDEX_CASES = sorted(os.listdir(os.path.join(GOLDEN, "index_cases")))
+
+
+@pytest.mark.parametrize("case", INDEX_CASES)
+def test_builder_on_stress_cases(case, tmp_path):
+    """tests/golden/make_index_fixture.py: contigs with and without SNPs (the reference matches SNP groups to contigs by ORDER),
+    multi-allelic and contig-end SNPs, a SNP every ~7 bases.  Every file byte-identical to the real reference's, except the two
+    documented spots where the reference writes memory it does not own: the dead high nibbles of the last .ref word and ONE entry of
+    .R.backward.sa (`sharp2Ri_array[n]`, rbwt.c:377,461) that it reads one past its malloc."""
+    import salt_amd
+    lib = salt_amd.host_lib()
+    lib.salt_idx_build.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+    lib.salt_idx_last_error.restype = ctypes.c_char_p
+    d = os.path.join(GOLDEN, "index_cases", case)
+    prefix = str(tmp_path / "idx")
+    rc = lib.salt_idx_build(os.path.join(d, "genome.fa").encode(), os.path.join(d, "snps.txt").encode(), prefix.encode(), 19)
+    assert rc == 0, lib.salt_idx_last_error()
+    for sfx in (".R.seedLen", ".C.pac", ".C.ann", ".C.amb", ".C.bwt", ".C.sa", ".lp", ".R.backward.bwt", ".R.backward.occ"):
+        assert open(prefix + sfx, "rb").read() == open(os.path.join(d, "idx" + sfx), "rb").read(), sfx
+    got, want = np.fromfile(prefix + ".R.backward.sa", dtype=np.uint32), np.fromfile(os.path.join(d, "idx.R.backward.sa"), dtype=np.uint32)
+    assert len(got) == len(want) and int((got != want).sum()) <= 1, int((got != want).sum())
+    got, want = np.fromfile(prefix + ".ref", dtype=np.uint32), np.fromfile(os.path.join(d, "idx.ref"), dtype=np.uint32)
+    assert len(got) == len(want) and got[0] == want[0] and (got[1:-1] == want[1:-1]).all()
+    l = int(got[0])
+    live = (1 << (4 * (l % 8))) - 1 if l % 8 else 0xFFFFFFFF
+    assert (int(got[-1]) & live) == (int(want[-1]) & live)
+    assert hashlib.sha256(open(prefix + ".C.lkt", "rb").read()).hexdigest() == open(os.path.join(d, "idx.C.lkt.sha256")).read().strip()
+
+
 def test_host_loader_and_abi_symbols():
     """The C-ABI libraries load without a GPU and export every symbol include/*.h declares."""
     import re
