@@ -516,3 +516,45 @@ def test_cli_with_the_smallest_kmer_table_has_no_wild_loads(tmp_path):
         assert out.returncode == 0, out.stderr[-300:]
         got = b"".join(l for l in out.stdout.splitlines(keepends=True) if not l.startswith(b"@PG"))
         assert got == open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read(), case
+
+
+@pytest.mark.parametrize("rate,edge", [(0.15, False), (0.5, False), (0.01, True)])
+def test_cli_on_snp_dense_indexes_equals_the_oracle(rate, edge, oracle_cli, tmp_path):
+    """The lambda genome with a SNP at 15 % / 50 % of the positions (1-3 alternative alleles; windows with more than 5 SNPs are
+    skipped by the indexer, localPattern.c:246-250, so the R index thins out again at 50 %) and with SNPs packed into the first and
+    last 30 bases of both contigs: the R searches, the 4-bit masks in verify / LV / SW and XV tags carry the load.  SAM of the C++
+    CLI against the CPU oracle's (SE two strides, PE); the oracle equals the real reference on these rows (build container)."""
+    import random
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt, salt_idx = os.path.join(root, "salt_amd", "bin", "salt"), os.path.join(root, "salt_amd", "bin", "salt-idx")
+    rng = random.Random(int(rate * 1000) + edge)
+    conts, name, seq = [], None, []
+    for l in open(os.path.join(LAMBDA, "genome.fa")):
+        if l.startswith(">"):
+            if name:
+                conts.append((name, "".join(seq)))
+            name, seq = l[1:].strip(), []
+        else:
+            seq.append(l.strip())
+    conts.append((name, "".join(seq)))
+    lines = []
+    for cn, s in conts:
+        for p, c in enumerate(s):
+            if c == "N" or not (rng.random() < rate or (edge and (p < 30 or p >= len(s) - 30))):
+                continue
+            r = rng.random()
+            al = sorted([c] + rng.sample([x for x in "ACGT" if x != c], 1 if r < 0.7 else 2 if r < 0.9 else 3))
+            lines.append("%s\t%d\t%s\t%s\n" % (cn, p + 1, "/".join(al), c))
+    snp, prefix = str(tmp_path / "snps.txt"), str(tmp_path / "idx")
+    open(snp, "w").write("".join(lines))
+    subprocess.run([salt_idx, "-k", "19", os.path.join(LAMBDA, "genome.fa"), snp, prefix], check=True, stderr=subprocess.DEVNULL)
+    strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    se = [os.path.join(LAMBDA, "reads_se.fq")]
+    pe = [os.path.join(LAMBDA, "reads_pe_1.fq"), os.path.join(LAMBDA, "reads_pe_2.fq")]
+    for args, files in ((["-d", "-c"], se), (["-d", "-c", "-r", "5"], se), (["-d", "-c", "-p", "-a", "350", "-b", "650"], pe)):
+        got = subprocess.run([salt] + args + [prefix] + files, capture_output=True)
+        want = subprocess.run([oracle_cli] + args + [prefix] + files, capture_output=True)
+        assert got.returncode == want.returncode == 0, (args, got.stderr[-300:])
+        g, w = strip(got.stdout).split(b"\n"), strip(want.stdout).split(b"\n")
+        bad = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]
+        assert not bad and len(g) == len(w), (args, len(bad), [(g[i][:200], w[i][:200]) for i in bad[:2]])
