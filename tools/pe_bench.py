@@ -42,6 +42,22 @@ for _ in range(K):
     aln.align_pe_resident(opt, idx, n_pairs, L, d_seqs.data_ptr(), d_offs.data_ptr(), d_res.data_ptr(), st)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
+# the same batches dealt to 3 workspaces on 3 streams (as bench.py does for SE)
+NS = 3
+forks = [aln] + [aln.fork() for _ in range(NS - 1)]
+streams = [torch.cuda.Stream() for _ in range(NS)]
+d_ress = [d_res] + [torch.zeros_like(d_res) for _ in range(NS - 1)]
+for rep in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(3 * K):
+        forks[i % NS].align_pe_resident(opt, idx, n_pairs, L, d_seqs.data_ptr(), d_offs.data_ptr(), d_ress[i % NS].data_ptr(), streams[i % NS].cuda_stream)
+    torch.cuda.synchronize()
+    dt3 = (time.perf_counter() - t0) / (3 * K)
+print("GPU PE resident, %d streams: %.3f ms per %d pairs = %.1f Mreads/s (mates/s), equal results: %s" % (
+      NS, dt3 * 1e3, n_pairs, 2 * n_pairs / dt3 / 1e6, all(torch.equal(d_ress[0], x) for x in d_ress[1:])))
+for f in forks[1:]:
+    f.close()
 same = np.array_equal(d_res.cpu().numpy().view(salt_amd.RESULT_DTYPE)[["pos", "strand", "mapq"]], res[["pos", "strand", "mapq"]])
 pc = aln.pe_counts()
 print("rescue requests %d (%.1f %% of the mates), overflowed %d" % (pc[0], 100.0 * pc[0] / (2 * n_pairs), pc[4]))
