@@ -230,84 +230,91 @@ void launch_pack(const PackGeom &pg, uint32_t n_reads, const uint8_t *seqs, cons
 // (repeats) and seeds alive in the R index (k-mers around SNPs, ~1 in 6) -- are minorities.  A wave pays for the longest of
 // its 64 lanes, so those walks are not done where they arise: the block collects them in LDS and its first lanes adopt them,
 // densely packed (typically one wave of the four keeps walking and the other three retire).
-struct SeedCtx {
+struct SeedCtx {                       // passed BY VALUE everywhere: anything reached through `this` or a reference stays in scratch memory
     const uint32_t *t2, *tn;           // 2-bit codes / N flags of this strand in the tb record
     uint32_t L, k, W, s, wb, nb, w0, w1, w2, n0, n1;
     bool inreg;                        // seeds of up to 33 bases sit in 3 + 2 registers (bases wb*16 .. wb*16+47)
-    __device__ __forceinline__ void init(const SeedParams &sp, const uint32_t *tb, uint32_t item, uint32_t lkt_len)
-    {
-        const uint32_t slot = item % sp.spr, rs = item / sp.spr, strand = rs & 1u, r = rs >> 1;
-        // the read as k_pack left it: 2-bit codes (first base in the high bits) and 'is N' bits of this strand
-        const uint32_t *rec = tb + (uint64_t)r * sp.pg.tb_stride;
-        t2 = rec + strand * sp.pg.nw16; tn = rec + 2 * sp.pg.nw16 + strand * sp.pg.nw32;
-        L = rec[2 * sp.pg.nw16 + 2 * sp.pg.nw32];
-        k = (uint32_t)sp.l_seed; W = lkt_len; s = slot * (uint32_t)sp.l_overlap; inreg = k <= 33;
-        wb = s >> 4; nb = s >> 5;
-        w0 = w1 = w2 = n0 = n1 = 0;
-        if (valid()) { w0 = t2[wb]; w1 = t2[wb + 1]; w2 = t2[wb + 2]; n0 = tn[nb]; n1 = tn[nb + 1]; }     // stays inside the record (PackGeom)
-    }
-    __device__ __forceinline__ bool valid() const { return L >= k && s + k <= L; }
-    __device__ __forceinline__ uint32_t base2(uint32_t i) const
-    {
-        if (inreg && i >= s) { const uint32_t rel = i - (wb << 4); const uint32_t ws = rel < 16 ? w0 : rel < 32 ? w1 : w2; return (ws >> (30 - 2 * (rel & 15u))) & 3u; }
-        return (t2[i >> 4] >> (30 - 2 * (i & 15u))) & 3u;
-    }
-    __device__ __forceinline__ bool is_n(uint32_t i) const
-    {
-        if (inreg && i >= s) { const uint32_t rel = i - (nb << 5); const uint32_t ns = rel < 32 ? n0 : n1; return (ns >> (31 - (rel & 31u))) & 1u; }
-        return (tn[i >> 5] >> (31 - (i & 31u))) & 1u;
-    }
 };
-
-// The rest of a C search (bwt.c:281-309) from interval [kc, lc] with head bases s .. s+i_top still to consume, newest first,
-// then the interval-shrinking extension (alnse.c:246-258).  A C interval of ONE row cannot branch any more: the search
-// succeeds iff the read's remaining bases equal the text in front of that suffix, so one suffix-array load and one text load
-// replace the remaining Occ steps and the seed leaves already located (.w = 2: .x = .y = the genome position).
-__device__ __forceinline__ uint4 seed_c_rest(const IndexView &ix, const SeedParams &sp, const SeedCtx &c, uint32_t kc, uint32_t lc, int i_top,
-                                             uint32_t &n_occ_c)
+__device__ __forceinline__ bool seed_valid(const SeedCtx c) { return c.L >= c.k && c.s + c.k <= c.L; }
+__device__ __forceinline__ SeedCtx seed_ctx(const SeedParams &sp, const uint32_t *tb, uint32_t item, uint32_t lkt_len)
 {
-    const uint32_t s = c.s;
-    const bool uniq = c.inreg && sp.resolve_unique;
-    bool alive = true, located = false;
-    auto resolve_unique = [&](int it) {                      // bases s .. s+it are still to be consumed, newest first
+    SeedCtx c;
+    const uint32_t slot = item % sp.spr, rs = item / sp.spr, strand = rs & 1u, r = rs >> 1;
+    // the read as k_pack left it: 2-bit codes (first base in the high bits) and 'is N' bits of this strand
+    const uint32_t *rec = tb + (uint64_t)r * sp.pg.tb_stride;
+    c.t2 = rec + strand * sp.pg.nw16; c.tn = rec + 2 * sp.pg.nw16 + strand * sp.pg.nw32;
+    c.L = rec[2 * sp.pg.nw16 + 2 * sp.pg.nw32];
+    c.k = (uint32_t)sp.l_seed; c.W = lkt_len; c.s = slot * (uint32_t)sp.l_overlap; c.inreg = c.k <= 33;
+    c.wb = c.s >> 4; c.nb = c.s >> 5;
+    c.w0 = c.w1 = c.w2 = c.n0 = c.n1 = 0;
+    if (seed_valid(c)) { c.w0 = c.t2[c.wb]; c.w1 = c.t2[c.wb + 1]; c.w2 = c.t2[c.wb + 2]; c.n0 = c.tn[c.nb]; c.n1 = c.tn[c.nb + 1]; }     // stays inside the record (PackGeom)
+    return c;
+}
+__device__ __forceinline__ uint32_t seed_base2(const SeedCtx c, uint32_t i)
+{
+    if (c.inreg && i >= c.s) { const uint32_t rel = i - (c.wb << 4); const uint32_t ws = rel < 16 ? c.w0 : rel < 32 ? c.w1 : c.w2; return (ws >> (30 - 2 * (rel & 15u))) & 3u; }
+    return (c.t2[i >> 4] >> (30 - 2 * (i & 15u))) & 3u;
+}
+__device__ __forceinline__ bool seed_is_n(const SeedCtx c, uint32_t i)
+{
+    if (c.inreg && i >= c.s) { const uint32_t rel = i - (c.nb << 5); const uint32_t ns = rel < 32 ? c.n0 : c.n1; return (ns >> (31 - (rel & 31u))) & 1u; }
+    return (c.tn[i >> 5] >> (31 - (i & 31u))) & 1u;
+}
+
+// One-row C interval `row` with head bases s .. s+it still to consume (newest first): the located position, or 0xFFFFFFFF when the
+// read and the text in front of that suffix differ.  Everything by value: what a lambda captures by reference ends up in scratch.
+__device__ __forceinline__ uint32_t seed_resolve_unique(const uint32_t *__restrict__ c_sa, const uint32_t *__restrict__ text, uint32_t c_seq_len,
+                                                        uint32_t s, uint32_t wb, uint32_t nb, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t n0, uint32_t n1,
+                                                        int it, uint32_t row, uint32_t &n_occ_c)
+{
         const uint32_t m = (uint32_t)it + 1u;
-        const uint32_t reln = s - (c.nb << 5);
-        const uint64_t vn = ((uint64_t)c.n0 << 32) | c.n1;
-        uint32_t p0 = ix.c_sa[kc];
-        if (p0 == 0xFFFFFFFFu) p0 = ix.c_seq_len;            // row 0: the empty suffix
+        const uint32_t reln = s - (nb << 5);
+        const uint64_t vn = ((uint64_t)n0 << 32) | n1;
+        uint32_t p0 = c_sa[row];
+        if (p0 == 0xFFFFFFFFu) p0 = c_seq_len;            // row 0: the empty suffix
         bool ok = ((vn >> (64 - reln - m)) & ((1ull << m) - 1ull)) == 0 && p0 >= m;
         uint32_t steps = m;
         for (uint32_t done = 0; done < m && ok; ) {          // at most two pieces of up to 16 bases, the later bases (consumed first) first
             const uint32_t cnt = (m - done) > 16u ? 16u : (m - done);
             const uint32_t r0 = s + (m - done - cnt), t0 = p0 - done - cnt;       // read bases r0 .. r0+cnt-1 against text t0 ..
-            const uint32_t rel = r0 - (c.wb << 4), rr = rel & 15u;
-            const uint64_t vr = rel < 16 ? (((uint64_t)c.w0 << 32) | c.w1) : (((uint64_t)c.w1 << 32) | c.w2);
+            const uint32_t rel = r0 - (wb << 4), rr = rel & 15u;
+            const uint64_t vr = rel < 16 ? (((uint64_t)w0 << 32) | w1) : (((uint64_t)w1 << 32) | w2);
             const uint32_t xr = (uint32_t)((vr >> (64 - 2 * rr - 2 * cnt)) & ((1ull << (2 * cnt)) - 1ull));
             const uint32_t tj = t0 >> 4, tr = t0 & 15u;
-            const uint64_t vt = ((uint64_t)ix.text[tj] << 32) | ix.text[tj + 1];
+            const uint64_t vt = ((uint64_t)text[tj] << 32) | text[tj + 1];
             const uint32_t xt = (uint32_t)((vt >> (64 - 2 * tr - 2 * cnt)) & ((1ull << (2 * cnt)) - 1ull));
             const uint32_t diff = xr ^ xt;
             if (diff) { ok = false; steps = done + ((uint32_t)__ffs((int)diff) - 1u) / 2u + 1u; }
             done += cnt;
         }
         n_occ_c += 2 * steps;
-        alive = ok;
-        if (ok) { kc = lc = p0 - m; located = true; }
-    };
-    if (uniq && kc == lc && i_top >= 0) resolve_unique(i_top);
+        return ok ? p0 - m : 0xFFFFFFFFu;
+    }
+
+// The rest of a C search (bwt.c:281-309) from interval [kc, lc] with head bases s .. s+i_top still to consume, newest first,
+// then the interval-shrinking extension (alnse.c:246-258).  A C interval of ONE row cannot branch any more: the search
+// succeeds iff the read's remaining bases equal the text in front of that suffix, so one suffix-array load and one text load
+// replace the remaining Occ steps and the seed leaves already located (.w = 2: .x = .y = the genome position).
+__device__ __forceinline__ uint4 seed_c_rest(const IndexView &ix, const SeedParams &sp, const SeedCtx c, uint32_t kc, uint32_t lc, int i_top,
+                                             uint32_t &n_occ_c)
+{
+    const uint32_t s = c.s;
+    const bool uniq = c.inreg && sp.resolve_unique;
+    bool alive = true, located = false;
+    if (uniq && kc == lc && i_top >= 0) { const uint32_t p = seed_resolve_unique(ix.c_sa, ix.text, ix.c_seq_len, s, c.wb, c.nb, c.w0, c.w1, c.w2, c.n0, c.n1, i_top, kc, n_occ_c); alive = p != 0xFFFFFFFFu; located = alive; if (alive) kc = lc = p; }
     for (int i = i_top; i >= 0 && alive && !located; --i) {
-        if (c.is_n(s + (uint32_t)i)) { alive = false; break; }
-        const uint32_t b = c.base2(s + (uint32_t)i);
+        if (seed_is_n(c, s + (uint32_t)i)) { alive = false; break; }
+        const uint32_t b = seed_base2(c, s + (uint32_t)i);
         uint32_t ok, ol; c_occ2(ix, kc - 1, lc, b, ok, ol);
         { const uint32_t l2 = pick4(ix.c_L2, b); kc = l2 + ok + 1; lc = l2 + ol; } alive = kc <= lc; n_occ_c += 2;
-        if (uniq && alive && kc == lc && i > 0) resolve_unique(i - 1);
+        if (uniq && alive && kc == lc && i > 0) { const uint32_t p = seed_resolve_unique(ix.c_sa, ix.text, ix.c_seq_len, s, c.wb, c.nb, c.w0, c.w1, c.w2, c.n0, c.n1, i - 1, kc, n_occ_c); alive = p != 0xFFFFFFFFu; located = alive; if (alive) kc = lc = p; }
     }
     if (!alive) return make_uint4(1, 0, 0, 0);
     if (located) return make_uint4(kc, kc, s, 2);
     uint32_t ext = 0;                                         // shrink big intervals leftwards (alnse.c:246-258)
     while (lc - kc > sp.max_seed && ext < s) {
-        if (c.is_n(s - ext - 1)) break;
-        const uint32_t b = c.base2(s - ext - 1);
+        if (seed_is_n(c, s - ext - 1)) break;
+        const uint32_t b = seed_base2(c, s - ext - 1);
         uint32_t ok, ol; c_occ2(ix, kc - 1, lc, b, ok, ol);
         n_occ_c += 2;
         if (ok + 1 > ol) break;
@@ -318,21 +325,21 @@ __device__ __forceinline__ uint4 seed_c_rest(const IndexView &ix, const SeedPara
 }
 
 // The rest of an R search (rbwt.c:619-648) and its extension, which has no N guard (alnse.c:279-291)
-__device__ __forceinline__ uint4 seed_r_rest(const IndexView &ix, const SeedParams &sp, const SeedCtx &c, uint32_t kr, uint32_t lr, int i_top,
+__device__ __forceinline__ uint4 seed_r_rest(const IndexView &ix, const SeedParams &sp, const SeedCtx c, uint32_t kr, uint32_t lr, int i_top,
                                              uint32_t &n_occ_r)
 {
     const uint32_t s = c.s;
     bool alive = true;
     for (int i = i_top; i >= 0 && alive; --i) {
-        if (c.is_n(s + (uint32_t)i)) { alive = false; break; }
-        const uint32_t b = c.base2(s + (uint32_t)i);
+        if (seed_is_n(c, s + (uint32_t)i)) { alive = false; break; }
+        const uint32_t b = seed_base2(c, s + (uint32_t)i);
         uint32_t ok, ol; r_occ2(ix, kr, lr + 1, b, ok, ol);
         { const uint32_t cm = pick5(ix.r_cum, b); kr = cm + ok + 1; lr = cm + ol; } alive = kr <= lr; n_occ_r += 2;
     }
     if (!alive) return make_uint4(1, 0, 0, 0);
     uint32_t ext = 0;
     while (lr - kr > sp.max_seed && ext < s) {
-        const uint32_t b = c.is_n(s - ext - 1) ? 4u : c.base2(s - ext - 1);               // an N walks the '#' column
+        const uint32_t b = seed_is_n(c, s - ext - 1) ? 4u : seed_base2(c, s - ext - 1);               // an N walks the '#' column
         uint32_t ok, ol; r_occ2(ix, kr, lr + 1, b, ok, ol);
         n_occ_r += 2;
         if (ok + 1 > ol) break;
@@ -358,9 +365,9 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
     bool pend_c = false, pend_r = false;
     uint32_t pk_c = 0, pl_c = 0, pk_r = 0, pl_r = 0;
     if (item < n_items) {
-        SeedCtx c; c.init(sp, tb, (uint32_t)item, ix.r_lkt_len);
+        const SeedCtx c = seed_ctx(sp, tb, (uint32_t)item, ix.r_lkt_len);
         uint4 oc = make_uint4(1, 0, 0, 0), orr = make_uint4(1, 0, 0, 0);
-        if (c.valid()) {
+        if (seed_valid(c)) {
             const uint32_t e = c.s + c.k - 1, W = c.W;
             // W-mer at the seed tail: both searches start from their tabulated interval
             // (LKT_seq2LktItem / LKT_lookup_sa lookup.c:163-177 + the first steps of bwt.c:281-309, rbwt.c:619-648)
@@ -374,7 +381,7 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
                 const uint64_t vn = ((uint64_t)c.n0 << 32) | c.n1;
                 has_n = ((vn >> (64 - reln - W)) & ((1ull << W) - 1ull)) != 0;
             } else {
-                for (uint32_t t = 0; t < W; ++t) { has_n |= c.is_n(a0 + t); x = (x << 2) | c.base2(a0 + t); }
+                for (uint32_t t = 0; t < W; ++t) { has_n |= seed_is_n(c, a0 + t); x = (x << 2) | seed_base2(c, a0 + t); }
             }
             if (!has_n) {
                 const uint4 v = ix.wlkt[x];                  // one 16-byte gather: C interval in .x/.y, R interval in .z/.w
@@ -408,7 +415,7 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
     for (uint32_t t = threadIdx.x; t < nr + nc; t += blockDim.x) {
         const uint32_t which = t < nr ? 0u : 1u, at = which ? t - nr : t;
         const uint64_t it = block_item0 + q_who[which][at];
-        SeedCtx c; c.init(sp, tb, (uint32_t)it, ix.r_lkt_len);
+        const SeedCtx c = seed_ctx(sp, tb, (uint32_t)it, ix.r_lkt_len);
         const int i_top = (int)(c.k - c.W) - 1;
         if (which == 0) sai_r[it] = seed_r_rest(ix, sp, c, q_k[0][at], q_l[0][at], i_top, n_occ_r);
         else sai_c[it] = seed_c_rest(ix, sp, c, q_k[1][at], q_l[1][at], i_top, n_occ_c);
