@@ -349,7 +349,7 @@ __device__ __forceinline__ uint4 seed_r_rest(const IndexView &ix, const SeedPara
     return make_uint4(kr, lr, s - ext, 1);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
        uint4 *__restrict__ sai_c, uint4 *__restrict__ sai_r, unsigned long long *__restrict__ ctr)
 {
