@@ -452,6 +452,7 @@ struct WaveLds {                                 // ~10.7 KB: 14-15 one-wave blo
     uint8_t  hit_nd[2][NHIT], hit_gap[2][NHIT];
     uint16_t cig[SALT_MAX_CIGAR_OPS];
     int      n_cig;
+    alignas(8) uint8_t cargs[128];                          // build_candidates' arguments (CandArgs): see there
 };
 
 // ---- klib introsort replica on the (sp,ep,off) triple arrays (ksort.h:159-228) ------------------
@@ -573,9 +574,13 @@ struct CandArgs {                      // everything by value: a by-reference In
     uint32_t *loci; uint32_t loci_cap; int pe;
     bool finish;                   // false: stop after locate (unsorted, duplicates and out-of-range loci still in)
 };
+// Not inlined (three call sites, ~1 400 instructions).  Its arguments are the same for all 64 lanes: passed by value they would be
+// written to and read back from scratch memory once per lane and call (~6 KB per call, measured as 430 MB of writes per launch), so the
+// caller leaves ONE copy in the wave's LDS.
 template <bool PE>
-__device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, WaveLds &w)
+__device__ __attribute__((noinline)) CandStats build_candidates(WaveLds &w)
 {
+    const CandArgs a = *reinterpret_cast<const CandArgs *>(w.cargs);
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t L = a.L, r = a.r; const int strand = a.strand; const bool gap_mode = a.gap_mode;
@@ -687,6 +692,16 @@ __device__ __attribute__((noinline)) CandStats build_candidates(CandArgs a, Wave
     const uint32_t n_out = dedup_loci(loci, n, gap_mode, L, ix.ref_len);
     pc.stamp(SALT_CTR_T_DEDUP);
     return CandStats{ n_out, n_sa_c, n_sa_r, n_loci_out };
+}
+
+template <bool PE>
+__device__ __forceinline__ CandStats build_candidates_call(const CandArgs a, WaveLds &w)
+{
+    static_assert(sizeof(CandArgs) <= sizeof(w.cargs), "CandArgs outgrew its LDS slot");
+    WSYNC();
+    if (lane_id() == 0) *reinterpret_cast<CandArgs *>(w.cargs) = a;
+    WSYNC();
+    return build_candidates<PE>(w);
 }
 
 // ---- masked Hamming distance, capped: returns 0..3 or INF (ed_mismatch, editdistance.c:88-163) ----
@@ -1264,7 +1279,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         // Located rows first, unsorted: only loci that can pass (<= 3 mismatches, inside the reference) matter to the
         // sequential rule, so the sort (alnse.c:726-729), the duplicate filter (alnse.c:758-762) and the rule run on
         // those few; the result is the one the full sorted list gives.
-        const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, loci, loci_cap, ap.pe, false }, w);
+        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, loci, loci_cap, ap.pe, false }, w);
         pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
         const uint32_t n_loc = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
         uint32_t call_best_n = INF, call_best_pos = 0;
@@ -1310,7 +1325,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                     uint32_t n = n_loc_s[1];
                     if (strand == 0) {
                         WSYNC();
-                        const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, 0, true, phase, loci, loci_cap, ap.pe, false }, w);
+                        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, 0, true, phase, loci, loci_cap, ap.pe, false }, w);
                         c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
                         n = cs.n_cand;
                     }
@@ -1350,7 +1365,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         }
         for (int strand = 0; strand < 2; ++strand) {
             pc.stamp(SALT_CTR_T_GAP);
-            const CandStats cs = build_candidates<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, loci, loci_cap, ap.pe, true }, w);
+            const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, loci, loci_cap, ap.pe, true }, w);
             pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
             const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
             bool any = false;
