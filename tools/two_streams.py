@@ -15,7 +15,7 @@ aln0 = salt_amd.GpuAligner(idx, max_reads=n, max_bases=n * L)
 opt = salt_amd.AlnOpt(l_seed=w["k"])
 dev = torch.device("cuda:0")
 d_seqs = torch.from_numpy(seqs).to(dev); d_offs = torch.from_numpy(offs.view(np.int32)).to(dev)
-for NS in (1, 2, 3, 4):
+for NS in (1, 2, 3, 4, 5, 6, 8):
     alns = [aln0] + [aln0.fork() for _ in range(NS - 1)]
     streams = [torch.cuda.Stream() for _ in range(NS)]
     res = [torch.zeros(n * salt_amd.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(NS)]
