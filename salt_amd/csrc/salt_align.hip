@@ -771,6 +771,8 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 // pmw: the read's one-hot words of this lane (zero past the read's end), nvalid: bases of the read inside them.
 // A base matches when (reference mask & one-hot) != 0 (ed_mismatch, editdistance.c:88-163); matches are counted
 // per nibble with one add (bit 3 of (n & 7) + 7 | n is set iff the nibble n is non-zero) and subtracted from nvalid.
+// LN = 4 lanes per candidate cover 16 window words (reads up to 120 bases), LN = 8 cover 32 (up to 248 bases: 150-bp mates).
+template <int LN = 4>
 __device__ __forceinline__ uint32_t quad_mismatch(const u32x4_a4 x, const uint32_t pos, const uint32_t (&pmw)[4], const uint32_t nvalid)
 {
     const uint32_t sh = (pos & 7u) * 4u;
@@ -786,25 +788,27 @@ __device__ __forceinline__ uint32_t quad_mismatch(const u32x4_a4 x, const uint32
     uint32_t mism = nvalid - match;
     mism += (uint32_t)__shfl_xor((int)mism, 1);
     mism += (uint32_t)__shfl_xor((int)mism, 2);
+    if (LN == 8) mism += (uint32_t)__shfl_xor((int)mism, 4);
     return mism;
 }
 
-template <int G>                                                         // groups of 16 candidates whose loads are in flight together
+template <int G, int LN = 4>                                             // groups of 64 / LN candidates whose loads are in flight together
 __device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, uint32_t ref_len, const uint32_t *pm, uint32_t L,
                                              const uint32_t *cand, uint32_t n, uint8_t *out)
 {
-    const uint32_t lane = lane_id(), sub = lane & 3u, q = lane >> 2;
+    constexpr uint32_t CPW = 64u / LN;                                   // candidates per wave-wide load
+    const uint32_t lane = lane_id(), sub = lane & (uint32_t)(LN - 1), q = lane / (uint32_t)LN;
     const uint32_t nw = (L + 7) >> 3;
     const uint32_t nvalid = L > 32u * sub ? (L - 32u * sub < 32u ? L - 32u * sub : 32u) : 0u;
     uint32_t pmw[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) pmw[t] = (4 * sub + t) < nw ? pm[4 * sub + t] : 0u;
-    for (uint32_t c0 = 0; c0 < n; c0 += 16u * G) {                      // up to G groups of 16 candidates per trip
+    for (uint32_t c0 = 0; c0 < n; c0 += CPW * G) {                      // up to G groups of CPW candidates per trip
         uint32_t pos[G]; u32x4_a4 x[G]; bool act[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            if (c0 + 16u * g >= n) break;                                // (uniform) nothing left for this group
-            const uint32_t c = c0 + 16u * g + q;
+            if (c0 + CPW * g >= n) break;                                // (uniform) nothing left for this group
+            const uint32_t c = c0 + CPW * g + q;
             act[g] = c < n;
             pos[g] = act[g] ? cand[c] : 0u;
             if (pos[g] >= ref_len) pos[g] = 0xFFFFFFFFu;                 // wrapped below 0 (see mismatch_capped): no load, INF
@@ -812,29 +816,31 @@ __device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, u
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            if (c0 + 16u * g >= n) break;
-            const uint32_t mism = quad_mismatch(x[g], pos[g], pmw, nvalid);
-            if (act[g] && sub == 0) out[c0 + 16u * g + q] = (uint8_t)((mism > 3 || pos[g] == 0xFFFFFFFFu) ? INF : mism);
+            if (c0 + CPW * g >= n) break;
+            const uint32_t mism = quad_mismatch<LN>(x[g], pos[g], pmw, nvalid);
+            if (act[g] && sub == 0) out[c0 + CPW * g + q] = (uint8_t)((mism > 3 || pos[g] == 0xFFFFFFFFu) ? INF : mism);
         }
     }
 }
 
 // Both strands of one read in the same trips (k_light): candidates c0[0..n0) use pm0, c1[0..n1) use pm1.
+template <int LN = 4>
 __device__ __forceinline__ void verify_quads_2(const uint32_t *__restrict__ ref, uint32_t ref_len, const uint32_t *pm0, const uint32_t *pm1, uint32_t L,
                                                const uint32_t *c0, uint32_t n0, const uint32_t *c1, uint32_t n1, uint8_t *o0, uint8_t *o1)
 {
-    const uint32_t lane = lane_id(), sub = lane & 3u, q = lane >> 2;
+    constexpr uint32_t CPW = 64u / LN;
+    const uint32_t lane = lane_id(), sub = lane & (uint32_t)(LN - 1), q = lane / (uint32_t)LN;
     const uint32_t nw = (L + 7) >> 3, n = n0 + n1;
     const uint32_t nvalid = L > 32u * sub ? (L - 32u * sub < 32u ? L - 32u * sub : 32u) : 0u;
     uint32_t pa[4], pb[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { const bool in = (4 * sub + t) < nw; pa[t] = in ? pm0[4 * sub + t] : 0u; pb[t] = in ? pm1[4 * sub + t] : 0u; }
-    for (uint32_t b = 0; b < n; b += 64) {
+    for (uint32_t b = 0; b < n; b += 4u * CPW) {
         uint32_t pos[4]; u32x4_a4 x[4]; bool act[4], rev[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (b + 16u * g >= n) break;
-            const uint32_t c = b + 16u * g + q;
+            if (b + CPW * g >= n) break;
+            const uint32_t c = b + CPW * g + q;
             act[g] = c < n; rev[g] = c >= n0;
             pos[g] = act[g] ? (rev[g] ? c1[c - n0] : c0[c]) : 0u;
             if (pos[g] >= ref_len) pos[g] = 0xFFFFFFFFu;
@@ -842,11 +848,11 @@ __device__ __forceinline__ void verify_quads_2(const uint32_t *__restrict__ ref,
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (b + 16u * g >= n) break;
+            if (b + CPW * g >= n) break;
             const uint32_t pw[4] = { rev[g] ? pb[0] : pa[0], rev[g] ? pb[1] : pa[1], rev[g] ? pb[2] : pa[2], rev[g] ? pb[3] : pa[3] };
-            const uint32_t mism = quad_mismatch(x[g], pos[g], pw, nvalid);
+            const uint32_t mism = quad_mismatch<LN>(x[g], pos[g], pw, nvalid);
             if (act[g] && sub == 0) {
-                const uint32_t c = b + 16u * g + q;
+                const uint32_t c = b + CPW * g + q;
                 const uint8_t v = (uint8_t)((mism > 3 || pos[g] == 0xFFFFFFFFu) ? INF : mism);
                 if (rev[g]) o1[c - n0] = v; else o0[c] = v;
             }
@@ -1285,6 +1291,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         uint32_t call_best_n = INF, call_best_pos = 0;
         auto verify_all = [&](uint32_t n) {                   // cand_e[i] = min(mismatches, INF) of loci[i], loads of 128 candidates in flight
             if (L <= 120) verify_quads<8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
+            else if (L <= 248) verify_quads<8, 8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
             else for (uint32_t i = lane; i < n; i += 64) cand_e[i] = (uint8_t)mismatch_capped(ix, w.pm[strand], L, loci[i]);
             WSYNC();
         };
@@ -1841,6 +1848,7 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
             bool found[2] = { false, false };
             {
                 if (L <= 120) verify_quads_2(ix.ref, ix.ref_len, w.pm[0], w.pm[1], L, w.loci[0], n_s[0], w.loci[1], n_s[1], w.val[0], w.val[1]);
+                else if (L <= 248) verify_quads_2<8>(ix.ref, ix.ref_len, w.pm[0], w.pm[1], L, w.loci[0], n_s[0], w.loci[1], n_s[1], w.val[0], w.val[1]);
                 else
                     for (int s = 0; s < 2; ++s)
                         for (uint32_t i = lane; i < n_s[s]; i += 64) w.val[s][i] = (uint8_t)mismatch_capped(ix, w.pm[s], L, w.loci[s][i]);
