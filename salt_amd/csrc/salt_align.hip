@@ -567,7 +567,7 @@ __device__ __forceinline__ uint32_t dedup_loci(uint32_t *loci, uint32_t n, bool 
 // ---- candidates of one strand: gather seeds, order them, locate, sort, dedup ----------------------
 // Leaves the candidate positions in w.loci[0..return).  gap_mode selects the range filter of
 // alnse_check_withgap (alnse.c:894) instead of alnse_check_nogap's (alnse.c:762).
-struct CandStats { uint32_t n_cand, n_sa_c, n_sa_r, n_loci; };
+struct CandStats { uint32_t n_cand, n_sa_c, n_sa_r, n_loci; uint32_t in_lds; };     // in_lds: the loci went to w.loci (PE lists that fit)
 struct CandArgs {                      // everything by value: a by-reference IndexView would live in scratch memory
     const uint32_t *c_sa, *r_pos; const uint4 *sai_c, *sai_r;
     uint32_t ref_len, spr, max_locate, r, L; int strand; bool gap_mode; unsigned long long *phase;
@@ -588,7 +588,7 @@ __device__ __attribute__((noinline)) CandStats build_candidates(WaveLds &w)
     struct { gp_u32 c_sa, r_pos; uint32_t ref_len; } ix = { as_global(a.c_sa), as_global(a.r_pos), a.ref_len };
     struct { uint32_t spr, max_locate; } ap = { a.spr, a.max_locate };
     uint32_t n_sa_c = 0, n_sa_r = 0, n_loci_out = 0;
-    uint32_t *const loci = PE ? a.loci : w.loci;
+    uint32_t *loci = PE ? a.loci : w.loci;                   // PE: decided below, once the number of rows is known
     PhaseClock pc(a.phase);
     const uint64_t base_item = ((uint64_t)r * 2u + (uint32_t)strand) * ap.spr;
     uint32_t n_list[2] = { 0, 0 };
@@ -612,6 +612,8 @@ __device__ __attribute__((noinline)) CandStats build_candidates(WaveLds &w)
                 uint32_t at = n + (uint32_t)__popcll(m & lt); w.u.sai.sp[which][at] = v.x; w.u.sai.ep[which][at] = v.y; w.u.sai.off[which][at] = v.z | (v.w == 2 ? 0x80000000u : 0u);
                 sz = v.y - v.x + 1u;
                 if (which == 1 && !PE) { uint32_t skip = sz / 0x40000u; if (skip > 1) sz = (sz + skip - 1) / skip; }
+                if (PE && which == 0 && sz > ap.max_locate + 1u) sz = ap.max_locate + 1u;              // rows the per-interval cap lets through (alnse.c:523)
+                if (PE && which == 1 && v.y - v.x > ap.max_locate) sz = (v.y - v.x) / ((v.y - v.x) / ap.max_locate) + 1u;   // rows the subsampling visits
                 if (sz > cap_total) sz = cap_total + 1u;
             }
             for (int o = 32; o > 0; o >>= 1) sz += (uint32_t)__shfl_xor((int)sz, o);
@@ -624,6 +626,10 @@ __device__ __attribute__((noinline)) CandStats build_candidates(WaveLds &w)
     // rows are located before a cap stops the loops; when every row is located the loci are the same set, and they
     // are sorted right after -- so the (serial) replica of the sort runs only when the cap can bite.
     if (rows > cap_total && lane < 2) sai_introsort(w.u.sai, (int)lane, (int)n_list[lane]);
+    // a PE mate may enumerate 0x40000 loci, which need the global scratch; the usual few hundred stay in LDS like an SE read's (the
+    // verify and rule passes then pay one memory round trip per trip instead of two or three)
+    const bool pe_in_lds = PE && rows <= (uint32_t)MAXLOC;
+    if (pe_in_lds) loci = w.loci;
     WSYNC();
     pc.stamp(SALT_CTR_T_GATHER);
     // locate: SE under the global max_locate cap (alnse_locate_alt, alnse.c:633-731); PE with the per-interval cap
@@ -685,13 +691,13 @@ __device__ __attribute__((noinline)) CandStats build_candidates(WaveLds &w)
     n_loci_out += n;
     WSYNC();
     pc.stamp(SALT_CTR_T_LOCATE);
-    if (!a.finish) return CandStats{ n, n_sa_c, n_sa_r, n_loci_out };
+    if (!a.finish) return CandStats{ n, n_sa_c, n_sa_r, n_loci_out, pe_in_lds ? 1u : 0u };
     sort_loci(loci, n);
     WSYNC();
     pc.stamp(SALT_CTR_T_SORT);
     const uint32_t n_out = dedup_loci(loci, n, gap_mode, L, ix.ref_len);
     pc.stamp(SALT_CTR_T_DEDUP);
-    return CandStats{ n_out, n_sa_c, n_sa_r, n_loci_out };
+    return CandStats{ n_out, n_sa_c, n_sa_r, n_loci_out, pe_in_lds ? 1u : 0u };
 }
 
 template <bool PE>
@@ -1245,8 +1251,8 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_lv = 0, c_loci = 0;
     PhaseClock pc(phase);
     const uint64_t rt0 = phase ? __builtin_amdgcn_s_memrealtime() : 0;
-    uint32_t *const loci = PE ? pe_loci : w.loci;             // candidate loci: LDS, or global scratch for PE mates
-    uint8_t *const cand_e = PE ? pe_cand : w.cand_e;
+    uint32_t *loci = PE ? pe_loci : w.loci;                   // candidate loci: LDS; for PE mates the global scratch when a list outgrows it
+    uint8_t *cand_e = PE ? pe_cand : w.cand_e;                // (set after every build_candidates call from what it reports)
     const uint32_t loci_cap = PE ? PE_LOCI_CAP : (uint32_t)MAXLOC;
 
     // ---- the read: one-hot masks of both strands, 8 bases per word, LSB first like the mixRef (editdistance.c:40) ----
@@ -1285,7 +1291,8 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         // Located rows first, unsorted: only loci that can pass (<= 3 mismatches, inside the reference) matter to the
         // sequential rule, so the sort (alnse.c:726-729), the duplicate filter (alnse.c:758-762) and the rule run on
         // those few; the result is the one the full sorted list gives.
-        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, loci, loci_cap, ap.pe, false }, w);
+        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, false }, w);
+        if (PE) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
         pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
         const uint32_t n_loc = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
         uint32_t call_best_n = INF, call_best_pos = 0;
@@ -1332,7 +1339,8 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                     uint32_t n = n_loc_s[1];
                     if (strand == 0) {
                         WSYNC();
-                        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, 0, true, phase, loci, loci_cap, ap.pe, false }, w);
+                        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, 0, true, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, false }, w);
+                        if (PE) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
                         c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
                         n = cs.n_cand;
                     }
@@ -1372,7 +1380,8 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         }
         for (int strand = 0; strand < 2; ++strand) {
             pc.stamp(SALT_CTR_T_GAP);
-            const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, loci, loci_cap, ap.pe, true }, w);
+            const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, true }, w);
+            if (PE) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
             pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
             const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
             bool any = false;
