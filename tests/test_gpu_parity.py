@@ -11,6 +11,9 @@ from conftest import EXTRA_CASES, LAMBDA, read_cases
 pytestmark = pytest.mark.gpu
 
 SE_CASES = [c for c in read_cases() if c.startswith("se_")]
+# The many-row CLI tests (option / tandem / seed-length / SNP-density matrices) compare semantics, not table widths: their `salt`
+# processes use a 4 GiB W-mer table (W = 14) instead of tabulating 64 GiB each; the golden-fixture tests run at the default.
+MATRIX_ENV = dict(os.environ, SALT_GPU_LKT_LEN=os.environ.get("SALT_GPU_LKT_LEN", "14"))
 
 
 @pytest.fixture(scope="module")
@@ -402,7 +405,7 @@ def test_cli_option_matrix_equals_the_oracle(oracle_cli, tmp_path):
     for row in OPTION_MATRIX:
         args = row.split()
         files = [os.path.join(LAMBDA, f) for f in (("reads_pe_1.fq", "reads_pe_2.fq") if "-p" in args else ("reads_se.fq",))]
-        got = subprocess.run([salt] + args + [prefix] + files, capture_output=True)
+        got = subprocess.run([salt] + args + [prefix] + files, capture_output=True, env=MATRIX_ENV)
         want = subprocess.run([oracle_cli] + args + [prefix] + files, capture_output=True)
         if got.returncode != want.returncode or strip(got.stdout) != strip(want.stdout):
             bad.append((row, got.returncode, want.returncode, got.stderr[-300:]))
@@ -440,7 +443,7 @@ def test_cli_on_a_tandem_repeat_equals_the_oracle(oracle_cli, tmp_path):
     for row in TANDEM_ROWS:
         args = row.split()
         files = [p1, p2] if "-p" in args else [se]
-        got = subprocess.run([salt] + args + [prefix] + files, capture_output=True)
+        got = subprocess.run([salt] + args + [prefix] + files, capture_output=True, env=MATRIX_ENV)
         want = subprocess.run([oracle_cli] + args + [prefix] + files, capture_output=True)
         if got.returncode != want.returncode or strip(got.stdout) != strip(want.stdout):
             g, w = strip(got.stdout).split(b"\n"), strip(want.stdout).split(b"\n")
@@ -491,7 +494,7 @@ def test_cli_seed_lengths_equal_the_oracle(k, oracle_cli, tmp_path):
     se = [os.path.join(LAMBDA, "reads_ragged.fq")]
     pe = [os.path.join(LAMBDA, "reads_pe_1.fq"), os.path.join(LAMBDA, "reads_pe_2.fq")]
     for args, files in ((["-d", "-c"], se), (["-d", "-c", "-r", "7"], se), (["-d", "-c", "-p", "-a", "350", "-b", "650"], pe)):
-        got = subprocess.run([salt] + args + [prefix] + files, capture_output=True)
+        got = subprocess.run([salt] + args + [prefix] + files, capture_output=True, env=MATRIX_ENV)
         want = subprocess.run([oracle_cli] + args + [prefix] + files, capture_output=True)
         assert got.returncode == want.returncode == 0, (k, args, got.stderr[-300:])
         g, w = strip(got.stdout).split(b"\n"), strip(want.stdout).split(b"\n")
@@ -552,7 +555,7 @@ def test_cli_on_snp_dense_indexes_equals_the_oracle(rate, edge, oracle_cli, tmp_
     se = [os.path.join(LAMBDA, "reads_se.fq")]
     pe = [os.path.join(LAMBDA, "reads_pe_1.fq"), os.path.join(LAMBDA, "reads_pe_2.fq")]
     for args, files in ((["-d", "-c"], se), (["-d", "-c", "-r", "5"], se), (["-d", "-c", "-p", "-a", "350", "-b", "650"], pe)):
-        got = subprocess.run([salt] + args + [prefix] + files, capture_output=True)
+        got = subprocess.run([salt] + args + [prefix] + files, capture_output=True, env=MATRIX_ENV)
         want = subprocess.run([oracle_cli] + args + [prefix] + files, capture_output=True)
         assert got.returncode == want.returncode == 0, (args, got.stderr[-300:])
         g, w = strip(got.stdout).split(b"\n"), strip(want.stdout).split(b"\n")
