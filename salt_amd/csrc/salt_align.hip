@@ -1958,7 +1958,7 @@ __device__ __forceinline__ void rule_sparse_h(const uint32_t *pos, const uint8_t
 {
     const uint32_t lane = lane_id(), hl = lane & 31u, hb = lane & 32u;
     const uint32_t NONE = 0xFFFFFFFFu;
-    auto HB = [&](bool x) -> uint32_t { return (uint32_t)(__ballot(x) >> hb); };
+    auto HB = [&](bool x) -> uint32_t { const uint64_t m = __ballot(x); return hb ? (uint32_t)(m >> 32) : (uint32_t)m; };   // this half's 32 bits (a select, not a 64-bit shift)
     auto SHF = [&](uint32_t v, int src) -> uint32_t { return (uint32_t)__shfl((int)v, (int)hb + src); };
     any = false; n_hits = 0;
     if (n == 0) return;
@@ -2032,7 +2032,7 @@ k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
     const uint32_t lane = lane_id(), hl = lane & 31u, hb = lane & 32u, half = lane >> 5;
     LightLds2 &w = w2[half];
     const uint32_t lt = (1u << hl) - 1u;
-    auto HB = [&](bool x) -> uint32_t { return (uint32_t)(__ballot(x) >> hb); };
+    auto HB = [&](bool x) -> uint32_t { const uint64_t m = __ballot(x); return hb ? (uint32_t)(m >> 32) : (uint32_t)m; };   // this half's 32 bits (a select, not a 64-bit shift)
     auto SHF = [&](uint32_t v, int src) -> uint32_t { return (uint32_t)__shfl((int)v, (int)hb + src); };
     const uint32_t r = 2u * blockIdx.x + half;
     if (r >= ap.n_reads) return;
