@@ -305,9 +305,11 @@ extern "C" int salt_sam_se(const salt_index_t *ix, const salt_sam_opt_t *opt, co
         o.put('\t'); o.puts(qual ? qual : "*");
         return o.done();
     }
-    std::vector<uint8_t> rs((size_t)L);
-    for (int i = 0; i < L; ++i) { uint8_t c = seq[L - 1 - i]; rs[i] = c < 4 ? (uint8_t)(3 - c) : c; }
-    const uint8_t *sq = q->strand ? rs.data() : seq;             // bases as aligned
+    uint8_t rs_stack[1024]; std::vector<uint8_t> rs_heap;       // the reverse complement: no allocation per read for ordinary lengths
+    uint8_t *rs = rs_stack;
+    if (L > (int)sizeof rs_stack) { rs_heap.resize((size_t)L); rs = rs_heap.data(); }
+    if (q->strand) for (int i = 0; i < L; ++i) { uint8_t c = seq[L - 1 - i]; rs[i] = c < 4 ? (uint8_t)(3 - c) : c; }
+    const uint8_t *sq = q->strand ? rs : seq;                    // bases as aligned
     int rid = seq_id(ix, q->pos);
     o.puts(name); o.put('\t'); o.putu(q->strand ? 16 : 0); o.put('\t'); o.puts(ix->anns[rid].name.c_str()); o.put('\t');
     o.putu((uint64_t)((int64_t)q->pos - ix->anns[rid].offset + 1)); o.put('\t'); o.putu(q->mapq); o.put('\t');
@@ -344,7 +346,9 @@ extern "C" int salt_sam_pe(const salt_index_t *ix, const salt_sam_opt_t *opt, co
     }
     for (int i = 0; i < 2; ++i) {
         const int L = l_seq[i];
-        std::vector<uint8_t> rs((size_t)L);
+        uint8_t rs_stack[1024]; std::vector<uint8_t> rs_heap;
+        uint8_t *rs = rs_stack;
+        if (L > (int)sizeof rs_stack) { rs_heap.resize((size_t)L); rs = rs_heap.data(); }
         for (int k = 0; k < L; ++k) { uint8_t c = seq[i][L - 1 - k]; rs[k] = c < 4 ? (uint8_t)(3 - c) : c; }
         unsigned flag = 0x1;
         if (!is_map[i]) flag |= 0x4;
@@ -368,7 +372,7 @@ extern "C" int salt_sam_pe(const salt_index_t *ix, const salt_sam_opt_t *opt, co
         } else o.puts("*\t0\t");
         if (tlen != 0) { if (q[i].pos >= q[1 - i].pos) o.put('-'); o.putu((uint64_t)tlen); o.put('\t'); }
         else o.puts("0\t");
-        const uint8_t *sq = q[i].strand == 1 ? rs.data() : seq[i];
+        const uint8_t *sq = q[i].strand == 1 ? rs : seq[i];
         for (int k = 0; k < L; ++k) o.put(NT[sq[k] > 4 ? 4 : sq[k]]);
         o.put('\t');
         const bool has_q = qual[i] && qual[i][0];
@@ -376,7 +380,7 @@ extern "C" int salt_sam_pe(const salt_index_t *ix, const salt_sam_opt_t *opt, co
         else if (q[i].strand == 1) for (int k = L - 1; k >= 0; --k) o.put(qual[i][k]);
         else o.puts(qual[i]);
         put_xa(o, ix, opt, L, &q[i]);
-        if (opt->print_nm_md && is_map[i]) put_md_nm(o, ix, q[i].strand == 0 ? seq[i] : rs.data(), &q[i]);
+        if (opt->print_nm_md && is_map[i]) put_md_nm(o, ix, q[i].strand == 0 ? seq[i] : rs, &q[i]);
         if (opt->rg_id) { o.puts("\tRG:Z:"); o.puts(opt->rg_id); }
         o.puts("\n\n");
     }

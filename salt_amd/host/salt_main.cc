@@ -39,7 +39,7 @@ struct Batch {
     std::vector<uint8_t> seqs;
     std::vector<uint32_t> offs{ 0 };
     std::vector<salt_result_t> res;
-    std::string sam;
+    std::vector<std::string> sam;                    // the batch's SAM text in order, one piece per formatting thread
     std::unique_ptr<Batch> mate;              // -p: the second file's records of the same pairs
     int n() const { return (int)name.size(); }
 };
@@ -206,7 +206,8 @@ void parse_batch(std::vector<char> &raw, Batch &b, Pool &pool);
 void format_batch(const salt_index_t *ix, const salt_sam_opt_t *so, Batch &b, Pool &pool)
 {
     const int n = b.n(), n_threads = pool.n;
-    std::vector<std::string> part((size_t)n_threads);
+    std::vector<std::string> &part = b.sam;
+    part.assign((size_t)n_threads, std::string());
     pool.parallel([&](int t) {
             std::vector<char> buf(1 << 16);
             int lo = (int)((long)n * t / n_threads), hi = (int)((long)n * (t + 1) / n_threads);
@@ -221,8 +222,6 @@ void format_batch(const salt_index_t *ix, const salt_sam_opt_t *so, Batch &b, Po
                 out.push_back('\n');
             }
     });
-    b.sam.clear();
-    for (auto &p : part) b.sam += p;
 }
 
 // -p: both SAM records of every pair (alnpe_sam, sam.c:331-457); res holds the mates interleaved
@@ -230,7 +229,8 @@ void format_batch_pe(const salt_index_t *ix, const salt_sam_opt_t *so, const sal
 {
     const int n = b.n(), n_threads = pool.n;
     const Batch &m = *b.mate;
-    std::vector<std::string> part((size_t)n_threads);
+    std::vector<std::string> &part = b.sam;
+    part.assign((size_t)n_threads, std::string());
     pool.parallel([&](int t) {
             std::vector<char> buf(1 << 17);
             int lo = (int)((long)n * t / n_threads), hi = (int)((long)n * (t + 1) / n_threads);
@@ -247,8 +247,6 @@ void format_batch_pe(const salt_index_t *ix, const salt_sam_opt_t *so, const sal
                 out.append(buf.data(), (size_t)w);
             }
     });
-    b.sam.clear();
-    for (auto &p : part) b.sam += p;
 }
 
 void parse_batch(std::vector<char> &raw, Batch &b, Pool &pool)
@@ -502,7 +500,7 @@ int main(int argc, char **argv)
             if (!b) break;                                   // eof and nothing in flight
         }
         double tw0 = now();
-        fwrite(b->sam.data(), 1, b->sam.size(), stdout);
+        for (const std::string &piece : b->sam) fwrite(piece.data(), 1, piece.size(), stdout);
         t_write += now() - tw0;
         n_tot += b->n() * (pe ? 2 : 1); ++next;
         fprintf(stderr, "%ld reads have been aligned!\n", n_tot);
