@@ -7,6 +7,7 @@
 #include <string.h>
 #include <cstddef>
 #include <string>
+#include <thread>
 #include <vector>
 #include "salt_kernels.h"
 #include <rccl/rccl.h>
@@ -402,14 +403,28 @@ static int fetch_results(salt_gpu_ws_t *ws, uint32_t n_reads, salt_result_t *res
     launch_heads(ws->d_results, n_reads, ws->d_heads, st);
     HIPCHK(hipMemcpyAsync(ws->h_heads, ws->d_heads, (uint64_t)n_reads * HEAD_BYTES, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    // heads -> rows: 128 bytes into every 880-byte row (two cache lines of a strided 88 MB per 100 000 reads); big batches are
+    // split over a few threads, the caller's thread among them
     std::vector<uint32_t> full;
-    for (uint32_t i = 0; i < n_reads; ++i) {
-        memcpy(&results[i], ws->h_heads + (uint64_t)i * HEAD_BYTES, HEAD_BYTES);
-        const salt_result_t &r = results[i];
-        bool more = r.n_cigar > 8;
-        for (int h = 0; h < SALT_MAX_HITS; ++h) more |= r.hit_n_cigar[h] != 0;
-        if (more) full.push_back(i);
+    const uint32_t n_thr = n_reads >= 262144 ? 4u : 1u;        // a driver with 100 000-read batches (salt) runs several workers already
+    std::vector<std::vector<uint32_t>> full_t(n_thr);
+    auto scatter = [&](uint32_t t) {
+        const uint32_t lo = (uint32_t)((uint64_t)n_reads * t / n_thr), hi = (uint32_t)((uint64_t)n_reads * (t + 1) / n_thr);
+        for (uint32_t i = lo; i < hi; ++i) {
+            memcpy(&results[i], ws->h_heads + (uint64_t)i * HEAD_BYTES, HEAD_BYTES);
+            const salt_result_t &r = results[i];
+            bool more = r.n_cigar > 8;
+            for (int h = 0; h < SALT_MAX_HITS; ++h) more |= r.hit_n_cigar[h] != 0;
+            if (more) full_t[t].push_back(i);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint32_t t = 1; t < n_thr; ++t) th.emplace_back(scatter, t);
+        scatter(0);
+        for (auto &x : th) x.join();
     }
+    for (auto &v : full_t) full.insert(full.end(), v.begin(), v.end());
     if (full.size() > 4096) {                                  // unusual batch: one plain copy is cheaper than thousands of small ones
         HIPCHK(hipMemcpyAsync(results, ws->d_results, (uint64_t)n_reads * sizeof(salt_result_t), hipMemcpyDeviceToHost, st));
     } else {
