@@ -2023,18 +2023,22 @@ __device__ __forceinline__ void rule_sparse_h(const uint32_t *pos, const uint8_t
     bound = best_v < bound ? best_v : bound;
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+// L2_WAVES waves per workgroup; each wave still works alone on its two reads (no block-level synchronisation).  Two waves per
+// workgroup halve the number of workgroups the dispatcher has to place (5 x 10^5 -> 2.5 x 10^5 per batch): the kernel alone takes
+// the same 0.48 ms, but with other batches' kernels on the GPU the step rate rises ~6 %; four are slower again.
+template <int L2_WAVES>
+__global__ void __launch_bounds__(64 * L2_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
          const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
          uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl)
 {
-    __shared__ LightLds2 w2[2];
+    __shared__ LightLds2 w2[2 * L2_WAVES];
     const uint32_t lane = lane_id(), hl = lane & 31u, hb = lane & 32u, half = lane >> 5;
-    LightLds2 &w = w2[half];
+    LightLds2 &w = w2[2u * (threadIdx.x >> 6) + half];
     const uint32_t lt = (1u << hl) - 1u;
     auto HB = [&](bool x) -> uint32_t { const uint64_t m = __ballot(x); return hb ? (uint32_t)(m >> 32) : (uint32_t)m; };   // this half's 32 bits (a select, not a 64-bit shift)
     auto SHF = [&](uint32_t v, int src) -> uint32_t { return (uint32_t)__shfl((int)v, (int)hb + src); };
-    const uint32_t r = 2u * blockIdx.x + half;
+    const uint32_t r = 2u * (blockIdx.x * (uint32_t)L2_WAVES + (threadIdx.x >> 6)) + half;
     if (r >= ap.n_reads) return;
     const uint32_t *rec = pm + (uint64_t)r * ap.pg.pm_stride;
     const uint32_t L = rec[2 * ap.pg.nw8];
@@ -2273,7 +2277,9 @@ void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm
     if (!ap.n_reads) return;
     static const bool no_half = getenv("SALT_GPU_NO_LIGHT2") && atoi(getenv("SALT_GPU_NO_LIGHT2"));
     if (!no_half && !ctr && !ap.dbg_stop && ap.spr <= (uint32_t)L2_SLOTS && ap.pg.nw8 <= 15) {          // reads of at most 120 bases: two per wave
-        hipLaunchKernelGGL(k_light2, dim3((ap.n_reads + 1) / 2), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl);
+        static const int wv = getenv("SALT_GPU_L2_WAVES") ? atoi(getenv("SALT_GPU_L2_WAVES")) : 2;
+        if (wv == 1) hipLaunchKernelGGL(k_light2<1>, dim3((ap.n_reads + 1) / 2), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl);
+        else hipLaunchKernelGGL(k_light2<2>, dim3((ap.n_reads + 3) / 4), dim3(128), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl);
         return;
     }
     hipLaunchKernelGGL(k_light, dim3((ap.n_reads + LT_WAVES - 1) / LT_WAVES), dim3(64 * LT_WAVES), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr);
