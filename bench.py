@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W [--workload chr21|mini|tiny]
 
 A "step" is one pass of the hot path (k_pack ... k_cigar behind salt_gpu_align_se_resident) over one
-batch of synthetic reads that is already resident in HBM.  Steps are dealt round-robin to --streams (3)
+batch of synthetic reads that is already resident in HBM.  Steps are dealt round-robin to --streams (4)
 workspaces, each on its own HIP stream, as `salt` drives a GPU with several align workers: the tails of one
 batch's persistent kernels overlap the wide kernels of the next.  Per-GPU work is fixed (weak scaling): every
 rank aligns its own read shard against its own replica of the device index; rank 0 packs the index and
@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=200000, help="reads given to the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (experiments; default: the workload's own batch)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("SALT_BENCH_STREAMS", "3")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SALT_BENCH_STREAMS", "4")),
                     help="workspaces / HIP streams per GPU the steps are dealt to round-robin (salt runs 2-4 align workers per GPU)")
     args = ap.parse_args()
 

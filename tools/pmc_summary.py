@@ -14,10 +14,10 @@ KERNELS = ("k_pack", "k_seed", "k_light", "k_heavy_pe", "k_heavy", "k_gapfin", "
 
 
 def short(name):
-    if "salt::k_light2(" in name:          # the two-reads-per-wave variant of k_light; bench.py reports both as k_light
+    if "salt::k_light2<" in name or "salt::k_light2(" in name:     # the two-reads-per-wave variant of k_light; bench.py reports both as k_light
         return "k_light"
     for k in KERNELS:
-        if "salt::%s(" % k in name:
+        if "salt::%s(" % k in name or "salt::%s<" % k in name:       # plain and templated kernels
             return k
     return None
 

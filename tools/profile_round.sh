@@ -12,11 +12,11 @@ python3 bench.py "$@" > "$OUT/bench_chr21_1gpu.json" 2> "$OUT/bench.log"
 tail -1 "$OUT/bench_chr21_1gpu.json" | cut -c1-400
 cd /tmp && export TMPDIR=/tmp
 # kernel-trace stats twice: --streams 1 (every kernel alone on the GPU: what the roofline block of the bench line is built from)
-# and the default command (batches overlapping on 3 streams: what "kernel_ms" / roofline.timed_region of the bench line show)
+# and the default command (batches overlapping on 4 streams: what "kernel_ms" / roofline.timed_region of the bench line show)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --no-cpu --streams 1 "$@" > "$OUT/bench_under_rocprofv3.json" 2>> "$OUT/bench.log"
 cp "$OUT"/kt/*kernel_stats.csv "$OUT/rocprofv3_kernel_stats.csv" 2>/dev/null || find "$OUT/kt" -name '*kernel_stats.csv' -exec cp {} "$OUT/rocprofv3_kernel_stats.csv" \;
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt3" -o kt -- python3 "$ROOT/bench.py" --no-cpu "$@" > "$OUT/bench_under_rocprofv3_streams3.json" 2>> "$OUT/bench.log"
-find "$OUT/kt3" -name '*kernel_stats.csv' -exec cp {} "$OUT/rocprofv3_kernel_stats_streams3.csv" \;
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt3" -o kt -- python3 "$ROOT/bench.py" --no-cpu "$@" > "$OUT/bench_under_rocprofv3_streams.json" 2>> "$OUT/bench.log"
+find "$OUT/kt3" -name '*kernel_stats.csv' -exec cp {} "$OUT/rocprofv3_kernel_stats_streams.csv" \;
 rm -rf "$OUT/kt3"
 echo "[profile] kernel stats done"
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum" "sq:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "sq2:SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"; do
