@@ -1729,7 +1729,7 @@ struct LightLds {
     uint8_t  val[2][LT_LOCI];
 };
 
-static constexpr int LT_WAVES = 1;       // independent reads (waves) per block: 4x fewer workgroups to dispatch
+static constexpr int LT_WAVES = 2;       // independent reads (waves) per workgroup: half the workgroups to dispatch (as k_light2)
 __global__ void __launch_bounds__(64 * LT_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
         const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,

@@ -42,8 +42,8 @@ for _ in range(K):
     aln.align_pe_resident(opt, idx, n_pairs, L, d_seqs.data_ptr(), d_offs.data_ptr(), d_res.data_ptr(), st)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-# the same batches dealt to 3 workspaces on 3 streams (as bench.py does for SE); SALT_PE_STREAMS=1 skips it (kernel profiles)
-NS = int(os.environ.get("SALT_PE_STREAMS", "3"))
+# the same batches dealt to 4 workspaces on 4 streams (as bench.py does for SE); SALT_PE_STREAMS=1 skips it (kernel profiles)
+NS = int(os.environ.get("SALT_PE_STREAMS", "4"))
 forks = [aln] + [aln.fork() for _ in range(NS - 1)]
 streams = [torch.cuda.Stream() for _ in range(NS)]
 d_ress = [d_res] + [torch.zeros_like(d_res) for _ in range(NS - 1)]
