@@ -74,10 +74,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    # rehearsal of the N > 1 path on a one-GPU box: SALT_BENCH_SAME_GPU=1 puts every rank on GPU 0 and SALT_BENCH_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device); the driver's multi-GPU runs use neither
+    if os.environ.get("SALT_BENCH_SAME_GPU"):
+        local_rank = 0
+    backend = os.environ.get("SALT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cfg = workload.CONFIGS[args.workload]
     L, n_reads = cfg["read_len"], (args.reads or cfg["n_reads"])

@@ -561,3 +561,20 @@ def test_cli_on_snp_dense_indexes_equals_the_oracle(rate, edge, oracle_cli, tmp_
         g, w = strip(got.stdout).split(b"\n"), strip(want.stdout).split(b"\n")
         bad = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]
         assert not bad and len(g) == len(w), (args, len(bad), [(g[i][:200], w[i][:200]) for i in bad[:2]])
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
+    """The N > 1 path of bench.py -- rank 0 builds and packs the index, the compact image is broadcast, rank 1 attaches it and
+    tabulates its own W-mer table, both time their shard, MAX over ranks -- with two ranks sharing this box's one GPU (gloo instead
+    of RCCL, which refuses two ranks on one device).  The multi-GPU runs themselves are the driver's."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SALT_BENCH_SAME_GPU="1", SALT_BENCH_BACKEND="gloo", SALT_BENCH_WORKLOAD="mini", SALT_GPU_LKT_LEN="14",
+               SALT_BENCH_CACHE=str(tmp_path))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu"],
+                         capture_output=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-600:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["steps"] == 4
