@@ -139,6 +139,8 @@ def gpu_lib():
         lib.salt_gpu_ws_queue_counts.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         lib.salt_gpu_ws_heavy_reads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
         lib.salt_gpu_ws_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32)]
+        lib.salt_gpu_diag_verify.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         assert lib.salt_gpu_result_size() == RESULT_DTYPE.itemsize
         _gpu = lib
     return _gpu

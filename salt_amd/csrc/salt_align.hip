@@ -732,40 +732,6 @@ __device__ __forceinline__ uint32_t mismatch_capped(const IndexView &ix, const u
     return mism > 3 ? INF : mism;
 }
 
-// U candidates per lane with every reference word loaded before the first compare, so that the
-// U x (NW+1) independent loads overlap instead of paying one memory latency per candidate.
-// Requires (L+7)/8 <= NW.  pm[u] selects the strand's read masks; inactive slots return INF.
-template <int NW, int U>
-__device__ __forceinline__ void mismatch_batch(const IndexView &ix, const uint32_t *const (&pm)[U], uint32_t L,
-                                               const uint32_t (&pos)[U], const bool (&act)[U], uint32_t (&out)[U])
-{
-    const uint32_t nw = (L + 7) >> 3;
-    uint32_t rw[U][NW + 1];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint32_t *ref = ix.ref + (pos[u] >> 3);
-#pragma unroll
-        for (int j = 0; j <= NW; ++j) rw[u][j] = (act[u] && (uint32_t)j <= nw) ? ref[j] : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint32_t sh = (pos[u] & 7u) * 4u;
-        uint32_t mism = 0;
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            if ((uint32_t)j < nw) {
-                const uint32_t w = sh ? ((rw[u][j] >> sh) | (rw[u][j + 1] << (32 - sh))) : rw[u][j];
-                const uint32_t x = w & pm[u][j];
-                const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
-                const uint32_t rem = L - (uint32_t)j * 8;
-                const uint32_t vm = rem >= 8 ? 0x11111111u : (0x11111111u >> (4 * (8 - rem)));
-                mism += (uint32_t)__popc(vm) - (uint32_t)__popc(nz & vm);
-            }
-        }
-        out[u] = act[u] ? (mism > 3 ? INF : mism) : INF;
-    }
-}
-
 // ---- masked Hamming distance, four lanes per candidate -------------------------------------------
 // Each lane of a quad loads 16 contiguous bytes of the candidate's window (one dwordx4), so a wave-wide
 // load touches 16 candidates x 64 B instead of 64 lanes x 14 scattered dwords: ~8x fewer cache-line
@@ -2383,6 +2349,49 @@ void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const 
                     const uint32_t *offs, int32_t *out, uint16_t *cig, void *lvtab, hipStream_t st)
 {
     if (n) hipLaunchKernelGGL(k_diag_lv, dim3(n), dim3(64), 0, st, ix, n, pos, kdiff, seqs, offs, out, cig, static_cast<LvTables *>(lvtab));
+}
+
+// k_diag_verify: unit access to the candidate verifiers (tests only).  One wave per case: the read seqs[offs[c]..offs[c+1]) against
+// candidates cand[coffs[c]..coffs[c+1]) (at most 256) on the caller's mixRef.  mode 0: mismatch_capped per lane, 1: verify_quads<8>
+// (4 lanes per candidate, L <= 120), 2: verify_quads<8, 8> (L <= 248), 3 / 4: verify_quads_2<4> / <8> with the list split between the
+// "strands" (both use the same read).  out[i] = 0..3 or 255.  Candidates >= ref_len (a locate that wrapped below 0, alnse.c:672-673) must
+// come back 255 WITHOUT being used as an address: the test's mixRef is a few KB, so a regression reads far outside of it only by value.
+__global__ void __launch_bounds__(64)
+k_diag_verify(const uint32_t *__restrict__ ref, uint32_t ref_len, uint32_t n_cases, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+              const uint32_t *__restrict__ cand, const uint32_t *__restrict__ coffs, int mode, uint8_t *__restrict__ out)
+{
+    __shared__ uint32_t pm[64];
+    __shared__ uint32_t loci[256];
+    __shared__ uint8_t val[256];
+    const uint32_t c = blockIdx.x, lane = lane_id();
+    if (c >= n_cases) return;
+    const uint32_t off = offs[c], L = offs[c + 1] - off, c0 = coffs[c];
+    uint32_t n = coffs[c + 1] - c0;
+    if (n > 256) n = 256;
+    const uint32_t nw = (L + 7) >> 3;
+    for (uint32_t j = lane; j < 64; j += 64) {
+        uint32_t word = 0;
+        for (uint32_t q = 0; q < 8 && j < nw; ++q) {
+            const uint32_t i = j * 8 + q, cc = i < L ? seqs[off + i] : 5u;
+            word |= (cc < 4 ? (1u << cc) : (cc == 4 ? 15u : 0u)) << (4 * q);
+        }
+        pm[j] = word;
+    }
+    for (uint32_t i = lane; i < n; i += 64) { loci[i] = cand[c0 + i]; val[i] = 77; }
+    WSYNC();
+    IndexView ix; ix.ref = ref; ix.ref_len = ref_len;
+    if (mode == 0) { for (uint32_t i = lane; i < n; i += 64) val[i] = (uint8_t)mismatch_capped(ix, pm, L, loci[i]); }
+    else if (mode == 1) verify_quads<8>(ref, ref_len, pm, L, loci, n, val);
+    else if (mode == 2) verify_quads<8, 8>(ref, ref_len, pm, L, loci, n, val);
+    else if (mode == 3) verify_quads_2(ref, ref_len, pm, pm, L, loci, n / 2, loci + n / 2, n - n / 2, val, val + n / 2);
+    else verify_quads_2<8>(ref, ref_len, pm, pm, L, loci, n / 2, loci + n / 2, n - n / 2, val, val + n / 2);
+    WSYNC();
+    for (uint32_t i = lane; i < n; i += 64) out[c0 + i] = val[i];
+}
+void launch_diag_verify(const uint32_t *ref, uint32_t ref_len, uint32_t n_cases, const uint8_t *seqs, const uint32_t *offs, const uint32_t *cand,
+                        const uint32_t *coffs, int mode, uint8_t *out, hipStream_t st)
+{
+    if (n_cases) hipLaunchKernelGGL(k_diag_verify, dim3(n_cases), dim3(64), 0, st, ref, ref_len, n_cases, seqs, offs, cand, coffs, mode, out);
 }
 
 // first 128 bytes of every result row, densely packed (what the host needs of nearly every row)

@@ -359,7 +359,8 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     const PackGeom pg = PackGeom::make(max_read_len);
     if ((uint64_t)n_reads * pg.pm_stride > ws->pm_cap || (uint64_t)n_reads * pg.tb_stride > ws->tb_cap) {
         HIPCHK(hipStreamSynchronize(st));
-        hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_heads); if (ws->h_heads) hipHostFree(ws->h_heads); ws->d_pm = ws->d_tb = nullptr; ws->pm_cap = ws->tb_cap = 0;
+        // d_heads / h_heads are sized by max_reads alone and stay (freeing them here left fetch_results with dangling pointers)
+        hipFree(ws->d_pm); hipFree(ws->d_tb); ws->d_pm = ws->d_tb = nullptr; ws->pm_cap = ws->tb_cap = 0;
         const uint64_t nr = n_reads > ws->max_reads ? n_reads : ws->max_reads;
         HIPCHK(hipMalloc((void **)&ws->d_pm, nr * pg.pm_stride * 4));
         HIPCHK(hipMalloc((void **)&ws->d_tb, nr * pg.tb_stride * 4));
@@ -466,32 +467,51 @@ extern "C" int salt_gpu_index_replicate(salt_gpu_index_t *src, const int *device
 {
     if (!src || !devices || !out || n < 1 || devices[0] != src->device) return fail(SALT_E_INVAL, "bad replicate arguments");
     out[0] = src;
+    for (int i = 1; i < n; ++i) out[i] = nullptr;
     if (n == 1) return SALT_OK;
     std::vector<void *> buf((size_t)n, nullptr);
-    std::vector<ncclComm_t> comm((size_t)n);
+    std::vector<ncclComm_t> comm((size_t)n, nullptr);
     std::vector<hipStream_t> st((size_t)n, nullptr);
+    bool comm_ok = false;
+    // every exit passes here: what a failed step leaves behind (buffers not yet owned by an index, communicators, streams) is released
+    auto cleanup = [&](bool failed) {
+        for (int i = 0; i < n; ++i) {
+            hipSetDevice(devices[i]);
+            if (st[i]) hipStreamDestroy(st[i]);
+            if (comm_ok && comm[i]) ncclCommDestroy(comm[i]);
+            if (failed && i > 0) {
+                if (out[i]) { salt_gpu_index_detach(out[i]); out[i] = nullptr; }       // owns buf[i]
+                else if (buf[i]) hipFree(buf[i]);
+            }
+        }
+        hipSetDevice(devices[0]);
+    };
+#define REPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(true); \
+    return fail(SALT_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
     buf[0] = src->image;
-    for (int i = 1; i < n; ++i) { HIPCHK(hipSetDevice(devices[i])); HIPCHK(hipMalloc(&buf[i], src->bytes)); }
+    for (int i = 1; i < n; ++i) { REPCHK(hipSetDevice(devices[i])); REPCHK(hipMalloc(&buf[i], src->bytes)); }
     ncclResult_t rc = ncclCommInitAll(comm.data(), n, devices);
-    if (rc != ncclSuccess) return fail(SALT_E_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(rc));
-    for (int i = 0; i < n; ++i) { HIPCHK(hipSetDevice(devices[i])); HIPCHK(hipStreamCreate(&st[i])); }
+    if (rc != ncclSuccess) { cleanup(true); return fail(SALT_E_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(rc)); }
+    comm_ok = true;
+    for (int i = 0; i < n; ++i) { REPCHK(hipSetDevice(devices[i])); REPCHK(hipStreamCreate(&st[i])); }
     ncclGroupStart();
     for (int i = 0; i < n; ++i) {
         rc = ncclBroadcast(buf[i], buf[i], src->hdr.off_wlkt, ncclUint8, 0, comm[i], st[i]);      // the compact part only
-        if (rc != ncclSuccess) { ncclGroupEnd(); return fail(SALT_E_HIP, std::string("ncclBroadcast: ") + ncclGetErrorString(rc)); }
+        if (rc != ncclSuccess) { ncclGroupEnd(); cleanup(true); return fail(SALT_E_HIP, std::string("ncclBroadcast: ") + ncclGetErrorString(rc)); }
     }
     rc = ncclGroupEnd();
-    if (rc != ncclSuccess) return fail(SALT_E_HIP, std::string("ncclGroupEnd: ") + ncclGetErrorString(rc));
-    for (int i = 0; i < n; ++i) { HIPCHK(hipSetDevice(devices[i])); HIPCHK(hipStreamSynchronize(st[i])); HIPCHK(hipStreamDestroy(st[i])); ncclCommDestroy(comm[i]); }
+    if (rc != ncclSuccess) { cleanup(true); return fail(SALT_E_HIP, std::string("ncclGroupEnd: ") + ncclGetErrorString(rc)); }
+    for (int i = 0; i < n; ++i) { REPCHK(hipSetDevice(devices[i])); REPCHK(hipStreamSynchronize(st[i])); }
     for (int i = 1; i < n; ++i) {
         int r2 = salt_gpu_index_attach_image(buf[i], src->bytes, devices[i], &out[i]);
-        if (r2) return r2;
-        out[i]->owns = true;
-        HIPCHK(hipSetDevice(devices[i]));
+        if (r2) { out[i] = nullptr; const std::string m = g_err; cleanup(true); return fail(r2, m); }
+        out[i]->owns = true;                                        // from here on detach releases buf[i]
+        REPCHK(hipSetDevice(devices[i]));
         r2 = rebuild_wlkt(out[i]);                                  // each device tabulates its own W-mer table
-        if (r2) return r2;
+        if (r2) { const std::string m = g_err; cleanup(true); return fail(r2, m); }
     }
-    HIPCHK(hipSetDevice(devices[0]));
+#undef REPCHK
+    cleanup(false);
     return SALT_OK;
 }
 
@@ -687,6 +707,39 @@ extern "C" int salt_gpu_diag_rule(uint32_t n_cases, const uint32_t *pos, const u
     return SALT_OK;
 }
 
+// Unit entry of the candidate verifiers on a caller-supplied mixRef (see k_diag_verify): fault-free check of the guards that keep a
+// wrapped locate from being used as an address.
+extern "C" int salt_gpu_diag_verify(const uint32_t *ref_words, uint32_t ref_len, uint32_t n_cases, const uint8_t *seqs, const uint32_t *offs,
+                                    const uint32_t *cand, const uint32_t *cand_offs, int mode, uint8_t *out)
+{
+    if (!ref_words || !seqs || !offs || !cand || !cand_offs || !out) return fail(SALT_E_INVAL, "null argument");
+    if (mode < 0 || mode > 4) return fail(SALT_E_INVAL, "mode must be 0..4");
+    if (n_cases == 0) return SALT_OK;
+    int n_dev = 0;
+    HIPCHK(hipGetDeviceCount(&n_dev));
+    if (n_dev <= 0) return fail(SALT_E_HIP, "no HIP device visible");
+    for (uint32_t i = 0; i < n_cases; ++i) {
+        const uint32_t L = offs[i + 1] - offs[i];
+        if (L == 0 || L > SALT_MAX_READ_LEN || ((mode == 1 || mode == 3) && L > 120) || ((mode == 2 || mode == 4) && L > 248)) return fail(SALT_E_INVAL, "read length outside the verifier's range");
+        if (cand_offs[i + 1] - cand_offs[i] > 256) return fail(SALT_E_INVAL, "at most 256 candidates per case");
+    }
+    const uint64_t nw = ((uint64_t)ref_len + 7) / 8 + 36, bases = offs[n_cases], nc = cand_offs[n_cases];
+    uint32_t *d_ref = nullptr, *d_offs = nullptr, *d_cand = nullptr, *d_coffs = nullptr; uint8_t *d_seqs = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_ref, nw * 4)); HIPCHK(hipMemset(d_ref, 0, nw * 4));
+    HIPCHK(hipMemcpy(d_ref, ref_words, (nw - 36) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_offs, ((uint64_t)n_cases + 1) * 4)); HIPCHK(hipMemcpy(d_offs, offs, ((uint64_t)n_cases + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_coffs, ((uint64_t)n_cases + 1) * 4)); HIPCHK(hipMemcpy(d_coffs, cand_offs, ((uint64_t)n_cases + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_cand, (nc + 1) * 4)); HIPCHK(hipMemcpy(d_cand, cand, nc * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_seqs, bases + 64)); HIPCHK(hipMemcpy(d_seqs, seqs, bases, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&d_out, nc + 1));
+    launch_diag_verify(d_ref, ref_len, n_cases, d_seqs, d_offs, d_cand, d_coffs, mode, d_out, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, d_out, nc, hipMemcpyDeviceToHost));
+    hipFree(d_ref); hipFree(d_offs); hipFree(d_coffs); hipFree(d_cand); hipFree(d_seqs); hipFree(d_out);
+    return SALT_OK;
+}
+
 extern "C" int salt_gpu_ws_queue_counts(salt_gpu_ws_t *ws, uint32_t out[8])
 {
     if (!ws || !out) return fail(SALT_E_INVAL, "null argument");
@@ -748,6 +801,7 @@ static int pe_prepare(salt_gpu_ws_t *ws, uint32_t n_pairs, hipStream_t st)
     if (n_pairs > ws->pe_pairs_cap) {
         HIPCHK(hipStreamSynchronize(st));
         hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres); hipFree(ws->d_pcq);
+        ws->d_pairs = nullptr; ws->d_req = nullptr; ws->d_swres = nullptr; ws->d_pcq = nullptr; ws->pe_pairs_cap = 0;   // a failed malloc below leaves a consistent (empty) state
         HIPCHK(hipMalloc((void **)&ws->d_pcq, (uint64_t)n_pairs * 2 * 4));
         HIPCHK(hipMalloc((void **)&ws->d_pairs, (uint64_t)n_pairs * sizeof(PePair)));
         HIPCHK(hipMalloc((void **)&ws->d_req, (uint64_t)n_pairs * 2 * sizeof(PeSwReq)));

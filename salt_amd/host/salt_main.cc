@@ -408,6 +408,8 @@ int main(int argc, char **argv)
     bool eof = false; long n_tot = 0; std::atomic<bool> failed{ false };
     const size_t max_inflight = (size_t)n_gpus * WPG * 2 + 1;
     size_t inflight = 0;
+    // the flag is stored with `mu` held: a waiter that has evaluated its predicate but not yet blocked cannot miss the notify
+    auto set_failed = [&]() { { std::lock_guard<std::mutex> lk(mu); failed = true; } cv.notify_all(); };
 
     std::atomic<double> t_parse{ 0 }, t_gpu{ 0 }, t_fmt{ 0 };
     double t_write = 0, t_read = 0;
@@ -426,7 +428,7 @@ int main(int argc, char **argv)
             if (pe && got) {
                 b->mate = std::make_unique<Batch>();
                 b->mate->raw.reserve((size_t)per_batch * 260);
-                if (rr2->take(b->mate->raw, got, b->mate->rec) != got) { fprintf(stderr, "[salt] the two read files hold different numbers of reads\n"); failed = true; }
+                if (rr2->take(b->mate->raw, got, b->mate->rec) != got) { fprintf(stderr, "[salt] the two read files hold different numbers of reads\n"); set_failed(); }
             }
             if (got == 0 || failed) b.reset();
             t_read += now() - tr0;
@@ -456,7 +458,7 @@ int main(int argc, char **argv)
                 if (pe && b->n()) {                              // interleave the mates: pair i = reads 2i, 2i+1
                     Batch &m = *b->mate;
                     parse_batch(m.raw, m, pool);
-                    if (m.n() != b->n()) { fprintf(stderr, "[salt] the two read files hold different numbers of reads\n"); failed = true; cv.notify_all(); break; }
+                    if (m.n() != b->n()) { fprintf(stderr, "[salt] the two read files hold different numbers of reads\n"); set_failed(); break; }
                     const size_t n = (size_t)b->n();
                     ioff.resize(2 * n + 1); ioff[0] = 0;
                     iseq.resize(b->seqs.size() + m.seqs.size());
@@ -475,7 +477,7 @@ int main(int argc, char **argv)
                 t_gpu = t_gpu + (now() - tg0);
                 if (grc) {
                     fprintf(stderr, "[salt] %s\n", salt_gpu_last_error());
-                    failed = true; cv.notify_all(); break;
+                    set_failed(); break;
                 }
                 double tf0 = now();
                 if (pe) format_batch_pe(ix, &so, &po, *b, pool); else format_batch(ix, &so, *b, pool);

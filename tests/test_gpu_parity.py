@@ -243,6 +243,85 @@ def test_gpu_ragged_lengths_n_runs_and_extremes():
     assert len(bad2) == 0
 
 
+def test_gpu_one_workspace_takes_batches_of_growing_read_length():
+    """A 100-base batch followed by a 200-base batch (then 100 again) through ONE workspace: the second batch regrows the packed-read
+    records; the result-head staging buffers must survive that (they were freed there once and used afterwards)."""
+    import sys
+    import salt_amd
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    prefix = os.path.join(LAMBDA, "idx")
+    names, seqs, offs, quals = salt_amd.read_fastq(os.path.join(LAMBDA, "reads_ragged.fq"))
+    lens = np.diff(offs.astype(np.int64))
+    def batch(sel):
+        rs = [seqs[offs[i]:offs[i + 1]] for i in sel]
+        o = np.zeros(len(rs) + 1, dtype=np.uint32); o[1:] = np.cumsum([len(r) for r in rs])
+        return np.concatenate(rs), o
+    short = [i for i in range(len(lens)) if lens[i] <= 100][:150]
+    long_ = [i for i in range(len(lens)) if 150 <= lens[i] <= 300][:150]
+    assert len(short) > 50 and len(long_) > 20
+    idx = salt_amd.Index.reload(prefix)
+    opt, _ = salt_amd.AlnOpt.from_argv([], idx.l_seed)
+    aln = salt_amd.GpuAligner(idx, device=0, max_reads=256, max_bases=256 * 512)
+    ora = oracle_py.Oracle(prefix)
+    oo = ora.opt(l_overlap=opt.l_overlap, max_seed=opt.max_seed, max_locate=opt.max_locate, seed_only_ref=opt.seed_only_ref)
+    for sel in (short, long_, short, long_):
+        s, o = batch(sel)
+        got = aln.alnse_core1(opt, s, o).copy()
+        want = ora.align(oo, s, o, n_threads=4)
+        assert len(oracle_py.compare(got, want)) == 0
+    ora.close(); aln.close(); idx.destroy()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_gpu_verifiers_never_dereference_a_wrapped_locate(mode):
+    """Candidates at or beyond mixRef.l -- `pos - offset` that wrapped below 0 passes the reference's range check (alnse.c:672-673)
+    and is only dropped by the candidate rule (alnse.c:762) -- must come back as "no hit" from every verifier without being used as an
+    address.  Fault-free: the mixRef here is 4 KB and the wild values are 0xFFFFFFF0-style, so a regression shows as a wrong byte (or
+    a fault), a correct build as 255; in-range candidates must still give the masked Hamming distance."""
+    import ctypes
+    from salt_amd import api
+    lib = api.gpu_lib()
+    rng = np.random.default_rng(11 + mode)
+    ref_len = 8000
+    masks = (1 << rng.integers(0, 4, size=ref_len)).astype(np.uint32)
+    snp = rng.random(ref_len) < 0.05
+    masks[snp] |= (1 << rng.integers(0, 4, size=int(snp.sum()))).astype(np.uint32)
+    words = np.zeros((ref_len + 7) // 8, dtype=np.uint32)
+    for q in range(8):
+        m = masks[q::8]
+        words[:len(m)] |= m << np.uint32(4 * q)
+    Ls = [100, 120, 37] if mode in (0, 1, 3) else [150, 248, 121]
+    if mode == 0:
+        Ls += [300]
+    reads, cands, coffs, want = [], [], [0], []
+    for L in Ls * 8:
+        p = int(rng.integers(0, ref_len - L))
+        r = np.array([int(np.log2(int(m) & -int(m))) for m in masks[p:p + L]], dtype=np.uint8)
+        e = rng.random(L) < 0.02
+        r[e] = (r[e] + 1) & 3
+        wild = [0xFFFFFFF0, 0xFFFFFFFF, 0xFFFFFF9C, 0x80000000, ref_len, ref_len + 5, 0xFFFF0000]
+        good = [p, max(0, p - 1), int(rng.integers(0, ref_len - L))]
+        c = [int(x) for x in rng.permutation(np.array(wild + good + wild[:3], dtype=np.uint64))]
+        for x in c:
+            if x >= ref_len:
+                want.append(255)
+            else:
+                mm = int(sum(1 for i in range(L) if x + i < ref_len and not (int(masks[x + i]) >> int(r[i])) & 1)) + max(0, x + L - ref_len)
+                want.append(mm if mm <= 3 else 255)
+        reads.append(r); cands += c; coffs.append(len(cands))
+    offs = np.zeros(len(reads) + 1, dtype=np.uint32); offs[1:] = np.cumsum([len(r) for r in reads])
+    seqs = np.concatenate(reads)
+    cand = np.array(cands, dtype=np.uint32); co = np.array(coffs, dtype=np.uint32)
+    out = np.zeros(len(cand), dtype=np.uint8)
+    rc = lib.salt_gpu_diag_verify(words.ctypes.data, ref_len, len(reads), seqs.ctypes.data, offs.ctypes.data, cand.ctypes.data, co.ctypes.data,
+                                  mode, out.ctypes.data)
+    assert rc == 0, lib.salt_gpu_last_error()
+    # candidates whose window runs past the end are never produced by locate (pos + L <= l is checked there): compare only windows inside
+    inside = np.array([(c >= ref_len) or (c + int(offs[i + 1] - offs[i]) <= ref_len) for i in range(len(reads)) for c in cands[coffs[i]:coffs[i + 1]]])
+    assert np.array_equal(out[inside], np.array(want, dtype=np.uint8)[inside]), (mode, np.nonzero(out[inside] != np.array(want, dtype=np.uint8)[inside])[0][:10])
+
+
 def test_gpu_rejects_what_it_cannot_do():
     """Loud errors instead of silent fallbacks: -m above 1024, reads above 512 bp, too many seed slots."""
     import salt_amd

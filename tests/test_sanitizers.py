@@ -1,0 +1,41 @@
+"""CPU-only AddressSanitizer + UBSan builds of the host-side code (index builder; the oracle CLI): the runs must finish without a
+sanitizer report and give the golden bytes.  (GPU sanitizers are not available on the pool; device code is covered by the parity
+tests.)"""
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, LAMBDA, ROOT
+
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=97", UBSAN_OPTIONS="halt_on_error=1:exitcode=98:print_stacktrace=1")
+
+
+@pytest.fixture(scope="module")
+def asan_bins():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "salt_amd", "host"), "asan"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], check=True, stdout=subprocess.DEVNULL)
+    return os.path.join(ROOT, "salt_amd", "bin", "salt-idx.asan"), os.path.join(ROOT, "oracle", "salt_oracle.asan")
+
+
+@pytest.mark.parametrize("case", ["lambda"] + sorted(os.listdir(os.path.join(GOLDEN, "index_cases"))))
+def test_index_builder_under_asan_ubsan(case, asan_bins, tmp_path):
+    d = LAMBDA if case == "lambda" else os.path.join(GOLDEN, "index_cases", case)
+    prefix = str(tmp_path / "idx")
+    p = subprocess.run([asan_bins[0], "-k", "19", os.path.join(d, "genome.fa"), os.path.join(d, "snps.txt"), prefix], capture_output=True, env=ENV)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert b"runtime error" not in p.stderr and b"AddressSanitizer" not in p.stderr, p.stderr.decode()[-2000:]
+    for sfx in (".C.bwt", ".C.sa", ".R.backward.bwt", ".R.backward.occ"):
+        assert open(prefix + sfx, "rb").read() == open(os.path.join(d, "idx" + sfx), "rb").read(), sfx
+
+
+@pytest.mark.parametrize("case", ["se_default", "pe_default"])
+def test_oracle_cli_under_asan_ubsan(case, asan_bins):
+    from conftest import read_cases
+    args = read_cases()[case]
+    files = ["reads_pe_1.fq", "reads_pe_2.fq"] if case.startswith("pe") else ["reads_se.fq"]
+    p = subprocess.run([asan_bins[1]] + args + [os.path.join(LAMBDA, "idx")] + [os.path.join(LAMBDA, f) for f in files], capture_output=True, env=ENV)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert b"runtime error" not in p.stderr and b"AddressSanitizer" not in p.stderr, p.stderr.decode()[-2000:]
+    got = b"".join(l for l in p.stdout.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    assert got == open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
