@@ -227,6 +227,28 @@ int  salt_gpu_diag_lv(const uint32_t *ref_words, uint32_t ref_len, uint32_t n_ca
 int  salt_gpu_diag_ssw(uint32_t n_cases, const uint8_t *aware, const uint8_t *ref_syms, const uint32_t *ref_offs,
                        const uint8_t *codes, const uint32_t *read_offs, int32_t *out6, uint16_t *cigars, uint16_t *n_cigar);
 
+/* ---- index construction on the device (salt-idx's heavy steps; row N1) ----------------------------------------------
+ * Replaces, for texts of any length the 32-bit formats admit (n < 2^32 - 16): bwt_bwtgen / Rbwt_bwt_bwtgen (Index_src/bwt_gen.c,
+ * 4bit_bwt_gen.c:1044-1130), bwt_bwtupdate_core (bwtmisc.c:121-143), bwt_cal_sa (bwt.c:48-68), LKT_build_lookuptable
+ * (LookUpTable.c:70-150), Rbwt_gen_sa (rbwt.c:424-475).  Host buffers in and out; the suffix sorter (prefix doubling over a
+ * radix sort) and every derived array run on `device`.  salt_amd/host/salt_idx.cc is the caller.
+ *
+ * salt_gpu_suffix_array: sa_out[0..n] = suffix array of text[0..n) with the empty suffix first (sa_out[0] = n); text holds one symbol
+ *     per byte, values < 2^bits, bits = 2 or 3.
+ * salt_gpu_idx_build_c: text = n base codes 0..3.  Writes the words of <P>.C.bwt behind its 5-word header (salt_gpu_idx_c_bwt_words(n)
+ *     of them: 2-bit BWT with the interleaved Occ counts, bwt.h:57-64), primary and L2[0..4], the (n + sa_intv) / sa_intv suffix-array
+ *     samples (sa[0] = 0xFFFFFFFF) and the 4^lkt_len + 1 items of the k-mer table.
+ * salt_gpu_idx_build_r: rtext = n symbols 0..4 ('#' = 4) of the local-pattern text; sharp_off[j] = offset of the j-th '#', sharp_hdr[j]
+ *     = header value of its record (localPattern.c:269-271, 304-307), cum4 = number of symbols < 4.  Writes inverseSa0, the
+ *     code_words words of the 4-bit BWT (zero padded) and the n_sharp + 1 entries of saValueSharp (the last one is the caller's). */
+int  salt_gpu_suffix_array(int device, const uint8_t *text, uint64_t n, int bits, uint32_t *sa_out);
+uint64_t salt_gpu_idx_c_bwt_words(uint64_t n);
+int  salt_gpu_idx_build_c(int device, const uint8_t *text, uint64_t n, uint32_t sa_intv, uint32_t *primary, uint32_t L2[5],
+                          uint32_t *bwt, uint32_t *sa, uint32_t *lkt, uint32_t lkt_len);
+int  salt_gpu_idx_build_r(int device, const uint8_t *rtext, uint64_t n, const uint32_t *sharp_off, const uint32_t *sharp_hdr, uint64_t n_sharp,
+                          uint32_t cum4, uint32_t *inv_sa0, uint32_t *code, uint64_t code_words, uint32_t *rsa);
+const char *salt_gpu_idx_last_error(void);
+
 const char *salt_gpu_last_error(void);
 uint32_t    salt_gpu_result_size(void);         /* sizeof(salt_result_t), for bindings */
 

@@ -57,8 +57,32 @@ int salt_sam_pe(const salt_index_t *ix, const salt_sam_opt_t *opt, const salt_pe
 /* Index builder (row N1): writes <prefix>.{R.seedLen,C.pac,C.ann,C.amb,C.lkt,C.bwt,C.sa,lp,
  * R.backward.bwt,R.backward.occ,R.backward.sa,ref} in salt-idx's formats from a FASTA (plain or .gz)
  * and salt's 4-column SNP file (chr, 1-based pos, alleles "A/G", ref; no header; grouped by
- * chromosome in FASTA order).  Mirrors index_main (Index_src/index1.c:46-185).  0 on success. */
+ * chromosome in FASTA order).  Mirrors index_main (Index_src/index1.c:46-185).  0 on success.
+ *
+ * The two suffix-array-bound steps go through a backend: NULL = SA-IS on the host (any machine; 64-bit indices beyond
+ * 2^31 symbols), or the device builder of libsalt_gpu.so -- { device, salt_gpu_idx_build_c, salt_gpu_idx_build_r,
+ * salt_gpu_idx_last_error } (include/salt_gpu.h) -- which is what indexes a GRCh38-sized genome in seconds.  Both give
+ * the same bytes.  Nothing is chosen silently: the caller names the backend. */
+typedef struct {
+    int device;
+    int (*build_c)(int device, const uint8_t *text, uint64_t n, uint32_t sa_intv, uint32_t *primary, uint32_t L2[5],
+                   uint32_t *bwt, uint32_t *sa, uint32_t *lkt, uint32_t lkt_len);
+    int (*build_r)(int device, const uint8_t *rtext, uint64_t n, const uint32_t *sharp_off, const uint32_t *sharp_hdr, uint64_t n_sharp,
+                   uint32_t cum4, uint32_t *inv_sa0, uint32_t *code, uint64_t code_words, uint32_t *rsa);
+    const char *(*last_error)(void);
+} salt_idx_backend_t;
+#define SALT_IDX_NO_LP 1            /* flags: do not write <prefix>.lp (the local patterns as text; `salt` never reads it) */
 int salt_idx_build(const char *fn_fa, const char *fn_snp, const char *prefix, int l_seed);
+int salt_idx_build_ex(const char *fn_fa, const char *fn_snp, const char *prefix, int l_seed, const salt_idx_backend_t *backend, int flags);
+/* The same from memory (what bench.py and the tests use for generated genomes): contigs as base letters (as a FASTA would hold
+ * them), SNP groups in file order -- group i belongs to contig i, like the reference matches them (mixRef.c:149-152) --
+ * with 0-based positions, allele masks (bit b = base b listed) and reference base codes. */
+typedef struct { const char *name, *comment; const char *seq; uint64_t len; } salt_idx_contig_t;
+typedef struct { const char *chr; const uint32_t *pos; const uint8_t *alleles; const uint8_t *ref; uint32_t n; } salt_idx_snps_t;
+int salt_idx_build_mem(const salt_idx_contig_t *contigs, int n_contigs, const salt_idx_snps_t *snps, int n_groups, const char *prefix,
+                       int l_seed, const salt_idx_backend_t *backend, int flags);
+/* the host suffix sorter alone: sa_out[0..n] for text[0..n) of `bits`-bit symbols (2 or 3), empty suffix first */
+int salt_idx_suffix_array_cpu(const uint8_t *text, uint64_t n, int bits, uint32_t *sa_out);
 const char *salt_idx_last_error(void);
 
 /* "<len><op>..." text of a binary CIGAR (ops as in salt_result_t); returns bytes written or -1 */

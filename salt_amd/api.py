@@ -276,6 +276,89 @@ class Index:
         return buf.raw[:n]
 
 
+# ---- index builder (salt-idx; include/salt_host.h, include/salt_gpu.h "index construction on the device") ----
+_BUILD_C = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32)
+_BUILD_R = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                            ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p)
+_LAST_ERR = ctypes.CFUNCTYPE(ctypes.c_char_p)
+
+
+class _IdxBackend(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int), ("build_c", _BUILD_C), ("build_r", _BUILD_R), ("last_error", _LAST_ERR)]
+
+
+class _IdxContig(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("comment", ctypes.c_char_p), ("seq", ctypes.c_void_p), ("len", ctypes.c_uint64)]
+
+
+class _IdxSnps(ctypes.Structure):
+    _fields_ = [("chr", ctypes.c_char_p), ("pos", ctypes.c_void_p), ("alleles", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("n", ctypes.c_uint32)]
+
+
+IDX_NO_LP = 1
+
+
+def _idx_backend(gpu_device):
+    """None -> the host suffix sorter; a device number -> the device builder of libsalt_gpu.so."""
+    if gpu_device is None:
+        return None
+    g = gpu_lib()
+    return _IdxBackend(int(gpu_device), ctypes.cast(g.salt_gpu_idx_build_c, _BUILD_C), ctypes.cast(g.salt_gpu_idx_build_r, _BUILD_R),
+                       ctypes.cast(g.salt_gpu_idx_last_error, _LAST_ERR))
+
+
+def idx_build(fasta, snps, prefix, l_seed, gpu_device=None, flags=0):
+    """salt-idx: FASTA + SNP file -> index files (index_main, Index_src/index1.c:46-185)."""
+    lib = host_lib()
+    be = _idx_backend(gpu_device)
+    lib.salt_idx_build_ex.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    lib.salt_idx_last_error.restype = ctypes.c_char_p
+    if lib.salt_idx_build_ex(os.fsencode(fasta), os.fsencode(snps), os.fsencode(prefix), int(l_seed), ctypes.byref(be) if be else None, int(flags)) != 0:
+        raise SaltError("index build failed: %s" % lib.salt_idx_last_error().decode())
+
+
+def idx_build_mem(contigs, snp_groups, prefix, l_seed, gpu_device=None, flags=0):
+    """The same from memory.  contigs: [(name, uint8 array of base LETTERS)]; snp_groups: [(chr name, uint32 0-based positions,
+    uint8 allele masks, uint8 reference codes)] in contig order (group i belongs to contig i)."""
+    lib = host_lib()
+    be = _idx_backend(gpu_device)
+    keep = []
+    cs = (_IdxContig * len(contigs))()
+    for i, (name, seq) in enumerate(contigs):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        keep.append(seq)
+        cs[i] = _IdxContig(name.encode(), None, seq.ctypes.data, len(seq))
+    gs = (_IdxSnps * max(len(snp_groups), 1))()
+    for i, (name, pos, al, ref) in enumerate(snp_groups):
+        pos, al, ref = np.ascontiguousarray(pos, dtype=np.uint32), np.ascontiguousarray(al, dtype=np.uint8), np.ascontiguousarray(ref, dtype=np.uint8)
+        keep += [pos, al, ref]
+        gs[i] = _IdxSnps(name.encode(), pos.ctypes.data, al.ctypes.data, ref.ctypes.data, len(pos))
+    lib.salt_idx_build_mem.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    lib.salt_idx_last_error.restype = ctypes.c_char_p
+    rc = lib.salt_idx_build_mem(cs, len(contigs), gs, len(snp_groups), os.fsencode(prefix), int(l_seed), ctypes.byref(be) if be else None, int(flags))
+    if rc != 0:
+        raise SaltError("index build failed: %s" % lib.salt_idx_last_error().decode())
+
+
+def suffix_array(text, bits, gpu_device=None):
+    """Full suffix array (empty suffix first) of a uint8 symbol array: host SA-IS, or the device sorter."""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    sa = np.zeros(len(text) + 1, dtype=np.uint32)
+    if gpu_device is None:
+        lib = host_lib()
+        lib.salt_idx_suffix_array_cpu.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
+        if lib.salt_idx_suffix_array_cpu(text.ctypes.data, len(text), bits, sa.ctypes.data) != 0:
+            raise SaltError("host suffix sorter failed")
+    else:
+        g = gpu_lib()
+        g.salt_gpu_suffix_array.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
+        g.salt_gpu_idx_last_error.restype = ctypes.c_char_p
+        if g.salt_gpu_suffix_array(int(gpu_device), text.ctypes.data, len(text), bits, sa.ctypes.data) != 0:
+            raise SaltError("device suffix sorter: %s" % g.salt_gpu_idx_last_error().decode())
+    return sa
+
+
 KERNELS = ("k_pack", "k_seed", "k_light", "k_heavy", "k_gap", "k_gapfin", "k_cigar")
 
 

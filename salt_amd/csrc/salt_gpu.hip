@@ -129,53 +129,42 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     hd.bytes = off;
     ix->bytes = off;
 
-    // ---- re-pack on the host ----
-    std::vector<COcc> cocc(hd.n_c_blocks);
-    {
-        uint32_t cnt[4] = { 0, 0, 0, 0 };
-        for (uint64_t b = 0; b < hd.n_c_blocks; ++b) {
-            COcc rec; memcpy(rec.cnt, cnt, sizeof cnt); rec.lo = rec.hi = 0;
-            for (uint32_t i = 0; i < 64; ++i) {
-                uint64_t k = b * 64 + i;
-                if (k >= h->c_seq_len) break;
-                uint64_t widx = k / 128 * 12 + 4 + (k % 128) / 16;
-                if (widx >= h->c_bwt_size) { delete ix; return fail(SALT_E_INDEX, "C BWT array shorter than seq_len"); }
-                uint32_t s = (h->c_bwt[widx] >> ((~k & 15u) << 1)) & 3u;
-                rec.lo |= (uint64_t)(s & 1u) << i; rec.hi |= (uint64_t)(s >> 1) << i;
-                ++cnt[s];
-            }
-            cocc[b] = rec;
-        }
-    }
-    std::vector<ROcc> rocc(hd.n_r_blocks);
-    {
-        uint32_t cnt[5] = { 0, 0, 0, 0, 0 };
-        for (uint64_t b = 0; b < hd.n_r_blocks; ++b) {
-            ROcc rec; memset(&rec, 0, sizeof rec); memcpy(rec.cnt, cnt, 16);
-            for (uint32_t i = 0; i < 128; ++i) {
-                uint64_t k = b * 128 + i;
-                if (k >= h->r_text_len) break;
-                uint32_t s = (h->r_bwt[k >> 3] >> ((7u - (k & 7u)) * 4u)) & 15u;
-                if (s > 4) { delete ix; return fail(SALT_E_INDEX, "R BWT holds a symbol outside {A,C,G,T,#}"); }
-                uint32_t hh = i >> 6, bb = i & 63u;
-                rec.b0[hh] |= (uint64_t)(s & 1u) << bb; rec.b1[hh] |= (uint64_t)((s >> 1) & 1u) << bb; rec.b2[hh] |= (uint64_t)(s >> 2) << bb;
-                ++cnt[s];
-            }
-            rocc[b] = rec;
-        }
-    }
-
-    // ---- upload ----
+    // ---- upload the file-format arrays and re-pack them on the device ----
     hipError_t e = hipMalloc((void **)&ix->image, ix->bytes);
     if (e != hipSuccess) { delete ix; return fail(SALT_E_NOMEM, std::string("hipMalloc(index image): ") + hipGetErrorString(e)); }
-    uint32_t *d_sa_s = nullptr, *d_r_sa = nullptr;
-#define CHK2(x) do { hipError_t e2 = (x); if (e2 != hipSuccess) { hipFree(ix->image); hipFree(d_sa_s); hipFree(d_r_sa); delete ix; \
+    uint32_t *d_sa_s = nullptr, *d_r_sa = nullptr, *d_raw = nullptr, *d_minor = nullptr, *d_major = nullptr, *d_err = nullptr;
+#define CHK2(x) do { hipError_t e2 = (x); if (e2 != hipSuccess) { hipFree(ix->image); hipFree(d_sa_s); hipFree(d_r_sa); hipFree(d_raw); hipFree(d_minor); hipFree(d_major); hipFree(d_err); delete ix; \
     return fail(SALT_E_HIP, std::string(#x) + ": " + hipGetErrorString(e2)); } } while (0)
     CHK2(hipMemset(ix->image, 0, hd.off_wlkt));      // the W-mer table (last) is fully written by its kernel
     CHK2(hipMemcpy(ix->image, &hd, sizeof hd, hipMemcpyHostToDevice));
-    CHK2(hipMemcpy(ix->image + hd.off_c_occ, cocc.data(), cocc.size() * sizeof(COcc), hipMemcpyHostToDevice));
+    CHK2(hipMalloc((void **)&d_err, 4)); CHK2(hipMemset(d_err, 0, 4));
+    {   // C: 2-bit BWT with interleaved counts (bwt.h:57-64) -> 32-byte COcc blocks
+        CHK2(hipMalloc((void **)&d_raw, (uint64_t)h->c_bwt_size * 4 + 4));
+        CHK2(hipMemcpy(d_raw, h->c_bwt, (uint64_t)h->c_bwt_size * 4, hipMemcpyHostToDevice));
+        launch_pack_c_occ(d_raw, h->c_bwt_size, h->c_seq_len, hd.n_c_blocks, reinterpret_cast<COcc *>(ix->image + hd.off_c_occ), d_err, nullptr);
+        CHK2(hipGetLastError()); CHK2(hipDeviceSynchronize());
+        hipFree(d_raw); d_raw = nullptr;
+    }
+    {   // R: 4-bit BWT + explicit Occ values (rbwt.c:40-80) -> 64-byte ROcc blocks
+        CHK2(hipMalloc((void **)&d_raw, (uint64_t)h->r_bwt_words * 4 + 4));
+        CHK2(hipMemcpy(d_raw, h->r_bwt, (uint64_t)h->r_bwt_words * 4, hipMemcpyHostToDevice));
+        CHK2(hipMalloc((void **)&d_minor, (uint64_t)h->r_occ_words * 4 + 4)); CHK2(hipMemcpy(d_minor, h->r_occ, (uint64_t)h->r_occ_words * 4, hipMemcpyHostToDevice));
+        CHK2(hipMalloc((void **)&d_major, (uint64_t)h->r_major_words * 4 + 4)); CHK2(hipMemcpy(d_major, h->r_major, (uint64_t)h->r_major_words * 4, hipMemcpyHostToDevice));
+        launch_pack_r_occ(d_raw, h->r_bwt_words, d_minor, h->r_occ_words, d_major, h->r_major_words, h->r_text_len, hd.n_r_blocks,
+                          reinterpret_cast<ROcc *>(ix->image + hd.off_r_occ), d_err, nullptr);
+        CHK2(hipGetLastError()); CHK2(hipDeviceSynchronize());
+        hipFree(d_raw); hipFree(d_minor); hipFree(d_major); d_raw = d_minor = d_major = nullptr;
+    }
+    {
+        uint32_t perr = 0;
+        CHK2(hipMemcpy(&perr, d_err, 4, hipMemcpyDeviceToHost));
+        hipFree(d_err); d_err = nullptr;
+        if (perr) {
+            hipFree(ix->image); delete ix;
+            return fail(SALT_E_INDEX, perr & 1 ? "C BWT array shorter than seq_len" : perr & 4 ? "R BWT holds a symbol outside {A,C,G,T,#}" : "R BWT / Occ arrays shorter than the text length");
+        }
+    }
     CHK2(hipMemcpy(ix->image + hd.off_lkt, h->lkt, (uint64_t)h->lkt_n * 4, hipMemcpyHostToDevice));
-    CHK2(hipMemcpy(ix->image + hd.off_r_occ, rocc.data(), rocc.size() * sizeof(ROcc), hipMemcpyHostToDevice));
     CHK2(hipMemcpy(ix->image + hd.off_ref, h->ref, ref_words * 4, hipMemcpyHostToDevice));
     make_view(ix);
     // ---- expand the sampled suffix arrays / tabulate the R 12-mers on the device ----

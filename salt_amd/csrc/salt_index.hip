@@ -12,56 +12,146 @@
 
 namespace salt {
 
+// grid of a grid-stride kernel over n items: never more than 2^20 blocks (a HIP launch is limited to 2^32 threads, and a
+// GRCh38-sized index has more rows than that allows with one thread per row and a margin)
+static inline uint32_t stride_grid(uint64_t n) { uint64_t b = (n + 255) / 256; if (b > (1u << 20)) b = 1u << 20; return b ? (uint32_t)b : 1u; }
+
+// ---- re-packing of the file-format arrays into the device layout (salt_device.h) ----
+// COcc block b = BWT symbols [64 b, 64 b + 64) of the $-removed C BWT: running counts in front of it + two bit planes.  The file
+// (bwt.h:57-64) has 4 counts every 128 symbols followed by 8 words of 16 symbols, first symbol in the top bits.
+__global__ void __launch_bounds__(256)
+k_pack_c_occ(const uint32_t *__restrict__ bwt, uint64_t bwt_words, uint32_t seq_len, uint64_t n_blocks, COcc *__restrict__ out, uint32_t *__restrict__ err)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += stride) {
+        const uint64_t k0 = b * 64, base = k0 / 128 * 12;
+        COcc rec; rec.cnt[0] = rec.cnt[1] = rec.cnt[2] = rec.cnt[3] = 0; rec.lo = rec.hi = 0;
+        if (base + 4 <= bwt_words) for (int c = 0; c < 4; ++c) rec.cnt[c] = bwt[base + c];
+        else if (k0 < seq_len) atomicOr(err, 1u);
+        const uint32_t half = (uint32_t)(k0 % 128) / 64;                   // second half of a file block: add the first half's symbols
+        for (uint32_t h = 0; h <= half; ++h) {
+            for (uint32_t w = 0; w < 4; ++w) {
+                const uint64_t kw = k0 / 128 * 128 + h * 64 + w * 16;
+                if (kw >= seq_len) break;
+                const uint64_t widx = base + 4 + h * 4 + w;
+                if (widx >= bwt_words) { atomicOr(err, 1u); break; }
+                const uint32_t word = bwt[widx];
+                for (uint32_t q = 0; q < 16; ++q) {
+                    if (kw + q >= seq_len) break;
+                    const uint32_t sy = (word >> ((15u - q) << 1)) & 3u;
+                    if (h < half) ++rec.cnt[sy];
+                    else { const uint32_t i = w * 16 + q; rec.lo |= (uint64_t)(sy & 1u) << i; rec.hi |= (uint64_t)(sy >> 1) << i; }
+                }
+            }
+        }
+        out[b] = rec;
+    }
+}
+// ROcc block b = symbols [128 b, 128 b + 128) of the stored R BWT (8 nibbles per word, first in the top nibble, rbwt.h:115-119):
+// counts of A, C, G, T in front of it + three bit planes.  The counts come from the file's own explicit Occ values -- a 32-bit
+// major value every 65536 symbols plus a 16-bit minor value every 256 (two per word, the even one in the high half,
+// rbwt.c:40-80) -- and, for odd blocks, the 128 symbols of the block before.
+__global__ void __launch_bounds__(256)
+k_pack_r_occ(const uint32_t *__restrict__ code, uint64_t code_words, const uint32_t *__restrict__ minor, uint64_t minor_words, const uint32_t *__restrict__ major,
+             uint64_t major_words, uint32_t text_len, uint64_t n_blocks, ROcc *__restrict__ out, uint32_t *__restrict__ err)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += stride) {
+        ROcc rec; rec.cnt[0] = rec.cnt[1] = rec.cnt[2] = rec.cnt[3] = 0;
+        rec.b0[0] = rec.b0[1] = rec.b1[0] = rec.b1[1] = rec.b2[0] = rec.b2[1] = 0;
+        const uint64_t e = b / 2;                                           // explicit value at symbol 256 e
+        const uint64_t mi = e / 2 * 5, ma = e / 256 * 5;
+        if (mi + 4 < minor_words && ma + 4 < major_words) {
+            for (int c = 0; c < 4; ++c) { const uint32_t mv = minor[mi + c]; rec.cnt[c] = major[ma + c] + ((e & 1) ? (mv & 0xFFFFu) : (mv >> 16)); }
+        } else if (b * 128 <= text_len) atomicOr(err, 2u);
+        for (uint32_t h = (uint32_t)(b & 1) ^ 1u; h < 2; ++h) {                  // odd block: count the even block before it, then pack its own
+            const bool own = h == 1 || (b & 1) == 0;
+            const uint64_t k0 = own ? b * 128 : (b - 1) * 128;
+            for (uint32_t w = 0; w < 16; ++w) {
+                const uint64_t kw = k0 + w * 8;
+                if (kw >= text_len) break;
+                if (kw / 8 >= code_words) { atomicOr(err, 2u); break; }
+                const uint32_t word = code[kw / 8];
+                for (uint32_t q = 0; q < 8; ++q) {
+                    if (kw + q >= text_len) break;
+                    const uint32_t sy = (word >> ((7u - q) * 4u)) & 15u;
+                    if (sy > 4) { atomicOr(err, 4u); continue; }
+                    if (!own) { if (sy < 4) ++rec.cnt[sy]; }
+                    else {
+                        const uint32_t i = w * 8 + q, hh = i >> 6, bb = i & 63u;
+                        rec.b0[hh] |= (uint64_t)(sy & 1u) << bb; rec.b1[hh] |= (uint64_t)((sy >> 1) & 1u) << bb; rec.b2[hh] |= (uint64_t)(sy >> 2) << bb;
+                    }
+                }
+            }
+            if (own) break;
+        }
+        out[b] = rec;
+    }
+}
+void launch_pack_c_occ(const uint32_t *bwt, uint64_t bwt_words, uint32_t seq_len, uint64_t n_blocks, COcc *out, uint32_t *err, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pack_c_occ, dim3(stride_grid(n_blocks)), dim3(256), 0, st, bwt, bwt_words, seq_len, n_blocks, out, err);
+}
+void launch_pack_r_occ(const uint32_t *code, uint64_t code_words, const uint32_t *minor, uint64_t minor_words, const uint32_t *major, uint64_t major_words,
+                       uint32_t text_len, uint64_t n_blocks, ROcc *out, uint32_t *err, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pack_r_occ, dim3(stride_grid(n_blocks)), dim3(256), 0, st, code, code_words, minor, minor_words, major, major_words, text_len, n_blocks, out, err);
+}
+
 __global__ void __launch_bounds__(256)
 k_build_c_sa(IndexView ix, const uint32_t *__restrict__ sa_sampled, uint32_t intv, uint32_t *__restrict__ out)
 {
-    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > ix.c_seq_len) return;
-    uint32_t k = (uint32_t)j, steps = 0;
-    while (k % intv != 0) {
-        ++steps;
-        if (k == ix.c_primary) k = 0;
-        else {
-            uint32_t c = c_sym(ix, k < ix.c_primary ? k : k - 1);
-            k = ix.c_L2[c] + c_occ(ix, k, c);
+    const uint64_t n = (uint64_t)ix.c_seq_len + 1, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        uint32_t k = (uint32_t)j, steps = 0;
+        while (k % intv != 0) {
+            ++steps;
+            if (k == ix.c_primary) k = 0;
+            else {
+                uint32_t c = c_sym(ix, k < ix.c_primary ? k : k - 1);
+                k = ix.c_L2[c] + c_occ(ix, k, c);
+            }
         }
+        out[j] = steps + sa_sampled[k / intv];      // sa_sampled[0] = 0xFFFFFFFF: wraps exactly as in C
     }
-    out[j] = steps + sa_sampled[k / intv];          // sa_sampled[0] = 0xFFFFFFFF: wraps exactly as in C
 }
 
 // text[SA[row] - 1] = BWT[row]: the genome the C index was built over, 16 bases per word, first base in the high bits
 __global__ void __launch_bounds__(256)
 k_build_text(IndexView ix, uint32_t *__restrict__ out)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > ix.c_seq_len || j == ix.c_primary) return;             // the primary row holds '$'
-    uint32_t p = ix.c_sa[j];
-    if (p == 0xFFFFFFFFu) p = ix.c_seq_len;                        // row 0: the empty suffix (bwt_sa's sa[0] = -1)
-    if (p == 0 || p > ix.c_seq_len) return;
-    const uint32_t c = c_sym(ix, (uint32_t)(j < ix.c_primary ? j : j - 1)), i = p - 1;
-    atomicOr(out + (i >> 4), c << (30 - 2 * (i & 15u)));
+    const uint64_t n = (uint64_t)ix.c_seq_len + 1, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        if (j == ix.c_primary) continue;                           // the primary row holds '$'
+        uint32_t p = ix.c_sa[j];
+        if (p == 0xFFFFFFFFu) p = ix.c_seq_len;                    // row 0: the empty suffix (bwt_sa's sa[0] = -1)
+        if (p == 0 || p > ix.c_seq_len) continue;
+        const uint32_t c = c_sym(ix, (uint32_t)(j < ix.c_primary ? j : j - 1)), i = p - 1;
+        atomicOr(out + (i >> 4), c << (30 - 2 * (i & 15u)));
+    }
 }
 
 void launch_build_text(const IndexView &ix, uint32_t *out, hipStream_t st)
 {
     const uint64_t n = (uint64_t)ix.c_seq_len + 1;
-    hipLaunchKernelGGL(k_build_text, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, ix, out);
+    hipLaunchKernelGGL(k_build_text, dim3(stride_grid(n)), dim3(256), 0, st, ix, out);
 }
 
 __global__ void __launch_bounds__(256)
 k_build_r_pos(IndexView ix, const uint32_t *__restrict__ r_sa, uint32_t *__restrict__ out)
 {
-    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > ix.r_text_len) return;
-    uint32_t sa_index = (uint32_t)j, step = 0;
+    const uint64_t n = (uint64_t)ix.r_text_len + 1, stride = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t n_acgt = ix.r_cum[4];
-    // every walk ends at a '#' (the text starts with one); the bound only guards a corrupt index
-    while (sa_index <= n_acgt && step < (1u << 20)) {
-        uint32_t c = r_bwt2nt(ix, sa_index);
-        sa_index = ix.r_cum[c] + r_occ(ix, sa_index, c) + 1;
-        ++step;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        uint32_t sa_index = (uint32_t)j, step = 0;
+        // every walk ends at a '#' (the text starts with one); the bound only guards a corrupt index
+        while (sa_index <= n_acgt && step < (1u << 20)) {
+            uint32_t c = r_bwt2nt(ix, sa_index);
+            sa_index = ix.r_cum[c] + r_occ(ix, sa_index, c) + 1;
+            ++step;
+        }
+        out[j] = sa_index > n_acgt ? r_sa[sa_index - n_acgt - 1] + step - 1 : 0xFFFFFFFFu;
     }
-    out[j] = sa_index > n_acgt ? r_sa[sa_index - n_acgt - 1] + step - 1 : 0xFFFFFFFFu;
 }
 
 // One entry per W-mer x (first base in the high bits): the C interval after LKT_lookup_sa on the last lkt_len bases
@@ -104,13 +194,13 @@ void launch_build_wlkt(const IndexView &ix, uint32_t len, uint4 *out, hipStream_
 void launch_build_c_sa(const IndexView &ix, const uint32_t *sa_sampled, uint32_t sa_intv, uint32_t *out, hipStream_t st)
 {
     uint64_t n = (uint64_t)ix.c_seq_len + 1;
-    hipLaunchKernelGGL(k_build_c_sa, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, ix, sa_sampled, sa_intv, out);
+    hipLaunchKernelGGL(k_build_c_sa, dim3(stride_grid(n)), dim3(256), 0, st, ix, sa_sampled, sa_intv, out);
 }
 
 void launch_build_r_pos(const IndexView &ix, const uint32_t *r_sa, uint32_t *out, hipStream_t st)
 {
     uint64_t n = (uint64_t)ix.r_text_len + 1;
-    hipLaunchKernelGGL(k_build_r_pos, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, ix, r_sa, out);
+    hipLaunchKernelGGL(k_build_r_pos, dim3(stride_grid(n)), dim3(256), 0, st, ix, r_sa, out);
 }
 
 } // namespace salt

@@ -104,7 +104,10 @@ void launch_diag_verify(const uint32_t *ref, uint32_t ref_len, uint32_t n_cases,
 void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const uint32_t *kdiff, const uint8_t *seqs,
                     const uint32_t *offs, int32_t *out, uint16_t *cig, void *lvtab, hipStream_t st);
 
-// attach-time expansion kernels (salt_index.hip)
+// attach-time re-packing + expansion kernels (salt_index.hip)
+void launch_pack_c_occ(const uint32_t *bwt, uint64_t bwt_words, uint32_t seq_len, uint64_t n_blocks, COcc *out, uint32_t *err, hipStream_t st);
+void launch_pack_r_occ(const uint32_t *code, uint64_t code_words, const uint32_t *minor, uint64_t minor_words, const uint32_t *major, uint64_t major_words,
+                       uint32_t text_len, uint64_t n_blocks, ROcc *out, uint32_t *err, hipStream_t st);
 void launch_build_c_sa(const IndexView &ix, const uint32_t *sa_sampled, uint32_t sa_intv, uint32_t *out, hipStream_t st);
 void launch_build_r_pos(const IndexView &ix, const uint32_t *r_sa, uint32_t *out, hipStream_t st);
 void launch_build_text(const IndexView &ix, uint32_t *out, hipStream_t st);

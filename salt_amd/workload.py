@@ -20,6 +20,10 @@ CONFIGS = {
     "chr21": dict(genome_len=40_000_000, n_snps=190_000, k=21, n_reads=1_000_000, read_len=100),
     # a tenth of GRCh38 (configs[2] scaled to what one gpurun call can index): 8 contigs, SNP density of snp144Common
     "grch38_tenth": dict(genome_len=320_000_000, n_snps=1_520_000, k=21, n_reads=1_000_000, read_len=100, contigs=8),
+    # BASELINE.json configs[2] restated: GRCh38-sized genome, SNP density of snp144Common
+    "grch38": dict(genome_len=3_100_000_000, n_snps=14_800_000, k=21, n_reads=1_000_000, read_len=100, contigs=24, fast=True),
+    # the same generator at a size the CPU tests and quick GPU checks can afford
+    "grch38_mini": dict(genome_len=24_000_000, n_snps=115_000, k=21, n_reads=200_000, read_len=100, contigs=24, fast=True),
     "mini": dict(genome_len=2_000_000, n_snps=9_500, k=21, n_reads=50_000, read_len=100),
     "tiny": dict(genome_len=200_000, n_snps=1_000, k=19, n_reads=4_000, read_len=100),
 }
@@ -39,6 +43,191 @@ def make_genome(n, seed=21):
         c[m] = (c[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
         g[s:s + 300] = c
     return g
+
+
+# ---- GRCh38-scale generator: counter-based, the same bits on any device --------------------------------------------------------
+# Every random quantity is splitmix64(key(seed, stream) + index) evaluated with torch int64 tensor arithmetic (wrapping multiply,
+# logical shifts emulated), so the data are a pure function of (seed, stream, index) whether the tensors live on an MI355X or on
+# the host: 3.1e9 bases take a second on the GPU where numpy generators take minutes.  torch is plumbing here (test / bench data),
+# never part of the aligner.
+_M64 = (1 << 64) - 1
+
+
+def _s64(v):
+    v &= _M64
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _lsr(x, k):
+    return (x >> k) & ((1 << (64 - k)) - 1)
+
+
+def _mix(x):
+    x = x + _s64(0x9E3779B97F4A7C15)
+    x = (x ^ _lsr(x, 30)) * _s64(0xBF58476D1CE4E5B9)
+    x = (x ^ _lsr(x, 27)) * _s64(0x94D049BB133111EB)
+    return x ^ _lsr(x, 31)
+
+
+def _key(seed, stream):
+    z = (seed * 0x100000001B3 + stream * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & _M64
+    for _ in range(2):                                   # splitmix64 on python ints
+        z = (z + 0x9E3779B97F4A7C15) & _M64
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+        z ^= z >> 31
+    return _s64(z)
+
+
+def hbits(seed, stream, idx):
+    """63 random bits (non-negative int64) per element of the int64 index tensor `idx`."""
+    return _lsr(_mix(idx + _key(seed, stream)), 1)
+
+
+def hrange(seed, stream, start, count, device):
+    import torch
+    return hbits(seed, stream, torch.arange(start, start + count, dtype=torch.int64, device=device))
+
+
+REPEAT_SLOT = 3000          # one 300-base repeat copy per 3000-base slot: 10 % of the genome, copies never overlap
+
+
+def make_genome_hash(n, seed=38, device="cpu"):
+    """uint8 tensor of n base codes: i.i.d. bases with GC 0.41 (a byte through a 256-entry table: A, T 75/256 each; C, G 53/256 each,
+    stream 0), then one copy of a 300-base family (stream 1) per 3000-base slot at a random offset (stream 2), each copy with its own
+    divergence in [5 %, 15 %) (stream 3) applied per base (streams 4, 5)."""
+    import torch
+    lut = torch.zeros(256, dtype=torch.uint8, device=device)
+    lut[75:128] = 1; lut[128:181] = 2; lut[181:] = 3
+    g = torch.empty(n, dtype=torch.uint8, device=device)
+    chunk = 1 << 27
+    for lo in range(0, n, chunk):
+        c = min(chunk, n - lo)
+        g[lo:lo + c] = lut[hrange(seed, 0, lo, c, device) & 255]
+    fam = lut[hrange(seed, 1, 0, 300, device) & 255]
+    n_slots = n // REPEAT_SLOT
+    ar = torch.arange(300, dtype=torch.int64, device=device)
+    blk = 1 << 18
+    for lo in range(0, n_slots, blk):
+        c = min(blk, n_slots - lo)
+        slot = torch.arange(lo, lo + c, dtype=torch.int64, device=device)
+        start = slot * REPEAT_SLOT + hbits(seed, 2, slot) % (REPEAT_SLOT - 300)
+        thr = 50 + hbits(seed, 3, slot) % 100                             # divergence in 1/1000
+        cell = slot[:, None] * 300 + ar[None, :]
+        mut = (hbits(seed, 4, cell) % 1000) < thr[:, None]
+        cp = fam[None, :].expand(c, 300).clone()
+        sub = ((cp.to(torch.int64) + 1 + hbits(seed, 5, cell) % 3) & 3).to(torch.uint8)
+        cp[mut] = sub[mut]
+        g[(start[:, None] + ar[None, :]).reshape(-1)] = cp.reshape(-1)
+    return g
+
+
+def make_snps_hash(genome, n_snps, seed=144):
+    """(sorted int64 positions, uint8 allele masks) as tensors on genome.device: distinct uniform positions (an oversampled draw,
+    stream 0; the n_snps with the smallest stream-1 hash are kept), 98 % bi-allelic / 2 % tri-allelic, reference allele listed."""
+    import torch
+    dev, n = genome.device, genome.numel()
+    pos = torch.unique(hrange(seed, 0, 0, int(n_snps * 1.03) + 64, dev) % n)
+    if pos.numel() < n_snps:
+        raise ValueError("SNP density too high for the oversampled draw")
+    keep = torch.argsort(hbits(seed, 1, pos))[:n_snps]
+    pos = torch.sort(pos[keep]).values
+    ref = genome[pos].to(torch.int64)
+    alt1 = (ref + 1 + hbits(seed, 2, pos) % 3) & 3
+    alt2 = (ref + 1 + hbits(seed, 3, pos) % 3) & 3
+    tri = ((hbits(seed, 4, pos) % 100) < 2) & (alt2 != alt1)
+    mask = (1 << ref) | (1 << alt1)
+    mask = torch.where(tri, mask | (1 << alt2), mask).to(torch.uint8)
+    return pos, mask
+
+
+_PICK = None
+
+
+def _pick_table(device):
+    """[mask][r] -> the (r mod popcount)-th listed allele, r in 0..11 (12 = lcm(1..4): every listed allele equally likely)."""
+    global _PICK
+    import torch
+    if _PICK is None or _PICK.device != torch.device(device):
+        t = np.zeros((16, 12), dtype=np.uint8)
+        for m in range(1, 16):
+            bits = [b for b in range(4) if (m >> b) & 1]
+            for r in range(12):
+                t[m, r] = bits[r % len(bits)]
+        _PICK = torch.from_numpy(t).to(device)
+    return _PICK
+
+
+def make_site_map(n, pos, mask):
+    """uint8[n]: the allele mask at SNP positions, 0 elsewhere (what the read generators look alleles up in)."""
+    import torch
+    site = torch.zeros(n, dtype=torch.uint8, device=pos.device)
+    site[pos] = mask
+    return site
+
+
+def make_reads_hash(genome, site, n_reads, L, seed=1, batch=0):
+    """One batch of single-end reads as tensors on genome.device: (codes uint8 [n_reads * L], offs int32 [n_reads + 1], start int64,
+    reverse bool).  Model of make_reads: uniform start over the concatenated genome, every SNP site under the read takes a random
+    listed allele, 0.5 %/base substitutions, 0.02 % of the reads with one 1-2 base indel, 0.1 % with 1-3 N, half reverse-complemented.
+    Streams are keyed by (seed, 16 * batch + k), indices by read and base."""
+    import torch
+    dev, n = genome.device, genome.numel()
+    st = lambda k: 16 * batch + k
+    rid = torch.arange(n_reads, dtype=torch.int64, device=dev)
+    W = L + 4
+    start = hbits(seed, st(0), rid) % (n - W)
+    ar = torch.arange(W, dtype=torch.int64, device=dev)
+    idx = start[:, None] + ar[None, :]
+    cell = rid[:, None] * W + ar[None, :]
+    frag = genome[idx]
+    m = site[idx]
+    has = m != 0
+    pick = _pick_table(dev)[m.to(torch.int64), hbits(seed, st(1), cell) % 12]
+    frag = torch.where(has, pick, frag)
+    err = (hbits(seed, st(2), cell) % 1000) < 5
+    frag = torch.where(err, ((frag.to(torch.int64) + 1 + hbits(seed, st(3), cell) % 3) & 3).to(torch.uint8), frag)
+    # indels: shift the tail of the window left (deletion of k bases at p) or right (insertion of k random bases at p)
+    ind = (hbits(seed, st(4), rid) % 10000) < 2
+    p = 10 + hbits(seed, st(5), rid) % (L - 20)
+    k = 1 + hbits(seed, st(6), rid) % 2
+    dele = (hbits(seed, st(7), rid) % 2) == 0
+    col = ar[None, :].expand(n_reads, W)
+    src_del = torch.where(col >= p[:, None], col + k[:, None], col).clamp(max=W - 1)
+    src_ins = torch.where(col >= p[:, None] + k[:, None], col - k[:, None], col)
+    src = torch.where((ind & dele)[:, None], src_del, torch.where((ind & ~dele)[:, None], src_ins, col))
+    out = torch.gather(frag, 1, src)
+    insz = (ind & ~dele)[:, None] & (col >= p[:, None]) & (col < p[:, None] + k[:, None])
+    out = torch.where(insz, (hbits(seed, st(8), cell) % 4).to(torch.uint8), out)
+    reads = out[:, :L].contiguous()
+    # N: 0.1 % of the reads get 1-3 of them
+    hasn = (hbits(seed, st(9), rid) % 1000) < 1
+    nn = 1 + hbits(seed, st(10), rid) % 3
+    colL = col[:, :L]
+    for j in range(3):
+        q = hbits(seed, st(11 + j), rid) % L
+        reads = torch.where((hasn & (nn > j))[:, None] & (colL == q[:, None]), torch.full_like(reads, 4), reads)
+    rev = (hbits(seed, st(14), rid) % 2) == 1
+    rc = torch.flip(reads, dims=[1])
+    rc = torch.where(rc < 4, 3 - rc, rc)
+    reads = torch.where(rev[:, None], rc, reads)
+    offs = (torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * L).to(torch.int32)
+    return reads.reshape(-1), offs, start, rev
+
+
+def as_builder_input(genome, pos, mask, contigs=1, name="synth1"):
+    """(contigs, SNP groups) as salt_amd.idx_build_mem takes them: base letters per contig, and per contig its SNPs with 0-based
+    positions inside the contig, allele masks and reference codes (what write_fasta + write_snps would put into files)."""
+    b = contig_bounds(len(genome), contigs)
+    cs, gs = [], []
+    edges = np.searchsorted(pos, b)
+    for ci in range(contigs):
+        nm = name if contigs == 1 else "synth%d" % (ci + 1)
+        cs.append((nm, ACGT[genome[b[ci]:b[ci + 1]]]))
+        p = pos[edges[ci]:edges[ci + 1]]
+        if len(p):
+            gs.append((nm, (p - b[ci]).astype(np.uint32), mask[edges[ci]:edges[ci + 1]], genome[p]))
+    return cs, gs
 
 
 def make_tandem(unit_len=30, copies=40000, divergence=0.01, flank=30000, seed=77):
@@ -207,25 +396,49 @@ def write_fastq(path, seqs, offs, n=None):
             f.write(b"@r%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
 
 
-def prepare(config, cache_dir):
-    """Generates (or finds cached) genome FASTA + SNP file + index for `config`; returns paths."""
+def generate(config):
+    """(genome codes, SNP positions, SNP allele masks) of a config -- a pure function of its seeds."""
+    c = CONFIGS[config]
+    if c.get("fast"):
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        tg = make_genome_hash(c["genome_len"], 38, dev)
+        tp, tm = make_snps_hash(tg, c["n_snps"], 144)
+        genome, pos, mask = tg.cpu().numpy(), tp.cpu().numpy(), tm.cpu().numpy()
+        del tg, tp, tm
+    else:
+        genome = make_genome(c["genome_len"])
+        pos, mask = make_snps(genome, c["n_snps"])
+    return genome, pos, mask
+
+
+def prepare(config, cache_dir, gpu_device=None, log=None):
+    """Generates the genome + SNP set of `config` and indexes it with the product's own salt-idx (from memory, without FASTA / SNP
+    text files; `.lp` is not written) unless the cache holds the index already.  gpu_device: the device the suffix sorter runs on
+    (None = host SA-IS, minutes for hundreds of Mbp and hopeless for GRCh38).  Returns paths, the generated arrays and stage times."""
+    import time
     from . import api
-    import ctypes
     c = dict(CONFIGS[config])
     nc = c.setdefault("contigs", 1)
     d = os.path.join(cache_dir, "salt_%s_g%d_s%d_k%d" % (config, c["genome_len"], c["n_snps"], c["k"]))
     os.makedirs(d, exist_ok=True)
-    fa, snp, prefix = os.path.join(d, "genome.fa"), os.path.join(d, "snps.txt"), os.path.join(d, "idx")
+    prefix = os.path.join(d, "idx")
     done = os.path.join(d, "DONE")
-    genome = make_genome(c["genome_len"])
-    pos, mask = make_snps(genome, c["n_snps"])
+    times = {}
+    t0 = time.time()
+    genome, pos, mask = generate(config)
+    times["generate_s"] = round(time.time() - t0, 2)
+    if log:
+        log("genome + SNPs generated in %.1f s" % times["generate_s"])
     if not os.path.exists(done):
-        write_fasta(fa, "synth1", genome, nc)
-        write_snps(snp, "synth1", genome, pos, mask, nc)
-        lib = api.host_lib()
-        lib.salt_idx_build.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
-        lib.salt_idx_last_error.restype = ctypes.c_char_p
-        if lib.salt_idx_build(fa.encode(), snp.encode(), prefix.encode(), c["k"]) != 0:
-            raise api.SaltError("index build failed: %s" % lib.salt_idx_last_error().decode())
+        t0 = time.time()
+        contigs, groups = as_builder_input(genome, pos, mask, nc)
+        times["letters_s"] = round(time.time() - t0, 2)
+        t0 = time.time()
+        api.idx_build_mem(contigs, groups, prefix, c["k"], gpu_device=gpu_device, flags=api.IDX_NO_LP)
+        del contigs, groups
+        times["index_s"] = round(time.time() - t0, 2)
+        if log:
+            log("index built in %.1f s (%s suffix sorter)" % (times["index_s"], "device" if gpu_device is not None else "host"))
         open(done, "w").write("ok\n")
-    return dict(dir=d, fasta=fa, snps=snp, prefix=prefix, genome=genome, snp_pos=pos, snp_mask=mask, **c)
+    return dict(dir=d, prefix=prefix, genome=genome, snp_pos=pos, snp_mask=mask, times=times, **c)
