@@ -1,25 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of salt's single-end alignment hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload chr21|mini|tiny]
+    python bench.py --gpus N --steps K --warmup W [--workload grch38|grch38_tenth|chr21|grch38_mini|mini|tiny]
 
-A "step" is one pass of the hot path (k_pack ... k_cigar behind salt_gpu_align_se_resident) over one
-batch of synthetic reads that is already resident in HBM.  Steps are dealt round-robin to --streams (4)
-workspaces, each on its own HIP stream, as `salt` drives a GPU with several align workers: the tails of one
-batch's persistent kernels overlap the wide kernels of the next.  Per-GPU work is fixed (weak scaling): every
-rank aligns its own read shard against its own replica of the device index; rank 0 packs the index and
-the other ranks receive its compact part by one RCCL broadcast (no collective on the data path).
+Workload (default `grch38` = BASELINE.json configs[2] restated as seeded synthetic data): a 3.1e9-base genome in 24
+contigs with 14.8 M SNPs, generated on the GPU, indexed on the GPU by the product's own salt-idx (device suffix sorter), k = 21;
+100-base single-end reads.  A "step" is one pass of the hot path (k_pack ... k_cigar behind salt_gpu_align_se_resident) over one
+batch of 1 000 000 reads that is already resident in HBM.  --batches (8) DISTINCT batches are resident and the steps rotate
+through them, dealt round-robin to --streams (4) workspaces, each on its own HIP stream, as `salt` drives a GPU with several align
+workers.  Per-GPU work is fixed (weak scaling): every rank aligns its own read shards against its own replica of the device
+index; rank 0 builds + packs the index and the other ranks receive its compact part by one RCCL broadcast (no collective on the
+data path).
 
 Prints ONE JSON line (rank 0) with the metric of BASELINE.json plus
-  "roofline":     dominant kernel, algorithmic bytes per launch / its HIP-event time vs 8 TB/s, from three
-                  serialized steps of the same run (the kernel alone on the GPU); the timed region's own
-                  start-to-end times are in "kernel_ms" / roofline.timed_region
-  "cpu_baseline": the CPU oracle (bit-exact restatement of the reference) on a bounded sample of the
-                  same reads on this box's host cores, also used to check the GPU results.
+  "stages_s":     what the run spent before the timed region (generate / index / load / attach / broadcast / reads)
+  "roofline":     the dominant single kernel: device-layout algorithmic bytes per launch (kernel counters) / its HIP-event time
+                  vs 8 TB/s, PMC traffic and the issue-rate bound from profiles/ when they hold this workload
+  "cpu_baseline": the CPU oracle (bit-exact restatement of the reference) on a bounded sample of the same reads on this box's
+                  host cores, also used to check the GPU results ("parity")
+  "e2e":          the `salt` binary, FASTQ text in -> SAM text out on reads of the same workload: SURVEY 8d's wall-clock metric.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,34 +31,41 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+SECTOR = 64                    # bytes a random access moves at least (one L2 / fabric sector)
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def algorithmic_bytes(ctr, L):
-    """bytes per read of the reference algorithm's logical accesses, split by kernel.
-    ctr: oracle counters over a sample.  R-Occ scan bytes are taken as syms/2 (no word rounding)."""
-    n = float(ctr["n_reads"])
-    seed = (2 * L * n + 8 * ctr["n_lkt"] + 48 * ctr["n_occC_seed"] + 8 * ctr["n_occR_seed"]
-            + ctr["n_occR_syms_seed"] / 2.0)
-    occC_loc = ctr["n_occC"] - ctr["n_occC_seed"]
-    occR_loc = ctr["n_occR"] - ctr["n_occR_seed"]
-    syms_loc = ctr["n_occR_syms"] - ctr["n_occR_syms_seed"]
-    align = (48 * occC_loc + 8 * occR_loc + syms_loc / 2.0 + 4 * (ctr["n_saC"] + ctr["n_saR"] + ctr["n_bwt2nt"])
-             + 4 * ctr["n_verify_words"] + (L + 4) / 2.0 * ctr["n_lv"] + 24 * n + 8 * ctr["n_hits_out"])
-    return seed / n, align / n
+def device_bytes(ctr, n_reads, L, spr):
+    """Device-layout algorithmic bytes of ONE launch per kernel, from the kernels' own access counters (salt_gpu_ws_counters,
+    DESIGN 5): what the device structures must move -- one 64-byte sector per W-mer gather, the 32-byte C / 64-byte R Occ blocks
+    actually fetched, 4 bytes per suffix-array / R-position load, 8 per text word pair, 16 per verify lane-load (64 per
+    candidate window), the packed read records, seed intervals and result rows each kernel reads and writes."""
+    items = n_reads * 2 * spr
+    nw8, nw16, nw32 = (L + 7) // 8, (L + 15) // 16, (L + 31) // 32
+    pm = ((2 * nw8 + 1 + 3) & ~3) * 4
+    tb = ((2 * nw16 + 2 * nw32 + 1 + 3) & ~3) * 4
+    b = {}
+    b["k_pack"] = n_reads * (L + 4 + pm + tb)
+    b["k_seed"] = (n_reads * tb + ctr["d_wlkt"] * SECTOR + ctr["d_cocc_seed"] * 32 + ctr["d_rocc_seed"] * 64 + ctr["d_sa_seed"] * 4
+                   + ctr["d_text_seed"] * 8 + items * 32)
+    b["k_light"] = (n_reads * pm + items * 32 + ctr["d_sa_light"] * 4 + ctr["d_verify_light"] * 16 + ctr["d_out_light"])
+    b["k_heavy"] = (ctr["heavy_reads"] * (pm + 2 * spr * 32) + ctr["d_sa_heavy"] * 4 + ctr["d_verify_heavy"] * 16 + ctr["d_out_heavy"])
+    return b
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=os.environ.get("SALT_BENCH_WORKLOAD", "chr21"))
-    ap.add_argument("--cpu-sample", type=int, default=200000, help="reads given to the CPU baseline")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default=os.environ.get("SALT_BENCH_WORKLOAD", "grch38"))
+    ap.add_argument("--batches", type=int, default=int(os.environ.get("SALT_BENCH_BATCHES", "8")), help="distinct resident read batches the steps rotate through")
+    ap.add_argument("--cpu-sample", type=int, default=1000000, help="reads given to the CPU baseline / parity check")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--e2e-reads", type=int, default=4000000, help="reads of the end-to-end leg (`salt` binary, FASTQ -> SAM); 0 = skip")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (experiments; default: the workload's own batch)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("SALT_BENCH_STREAMS", "4")),
                     help="workspaces / HIP streams per GPU the steps are dealt to round-robin (salt runs 2-4 align workers per GPU)")
@@ -90,35 +101,40 @@ def main():
     cfg = workload.CONFIGS[args.workload]
     L, n_reads = cfg["read_len"], (args.reads or cfg["n_reads"])
     cache = os.environ.get("SALT_BENCH_CACHE", "/tmp/salt_bench_cache")
+    stages = {}
 
-    # ---- index files (rank 0 builds them with the product's own salt-idx equivalent) ----
+    # ---- genome + SNPs: every rank generates them on its own GPU (it draws its read shards from them) ----
     t0 = time.time()
+    genome, pos, mask = workload.generate_device(args.workload, dev)
+    site = workload.make_site_map(genome.numel(), pos, mask)
+    torch.cuda.synchronize()
+    stages["generate"] = round(time.time() - t0, 2)
+
+    # ---- index files: rank 0 builds them with the product's own salt-idx (suffixes sorted on its GPU) ----
     w = None
     if rank == 0:
-        w = workload.prepare(args.workload, cache)
-        log("workload %s ready in %.1f s (%s)" % (args.workload, time.time() - t0, w["dir"]))
+        w = workload.prepare(args.workload, cache, gpu_device=local_rank, log=log, arrays=(genome, pos, mask))
+        stages.update(w["times"])
     if world > 1:
         dist.barrier()
-    # every rank regenerates the genome/SNPs from the seeds to draw its own read shard
-    genome = w["genome"] if w else workload.make_genome(cfg["genome_len"])
-    if w:
-        pos, mask = w["snp_pos"], w["snp_mask"]
-    else:
-        pos, mask = workload.make_snps(genome, cfg["n_snps"])
-    seqs, offs, _, _ = workload.make_reads(genome, pos, mask, n_reads, L, seed=1 + rank)
 
-    # ---- device index: rank 0 packs, the others get the image by one broadcast over RCCL ----
-    t0 = time.time()
+    # ---- device index: rank 0 packs, the others get the compact image by one broadcast over RCCL ----
     idx = None
     nbytes = cbytes = 0
     if rank == 0:
+        t0 = time.time()
         idx = salt_amd.Index.reload(w["prefix"], rebuild_lkt=False)
+        stages["load_files"] = round(time.time() - t0, 2)
+        t0 = time.time()
         aln = salt_amd.GpuAligner(idx, device=local_rank, max_reads=n_reads, max_bases=n_reads * L)
+        torch.cuda.synchronize()
+        stages["attach"] = round(time.time() - t0, 2)
         nbytes = aln.image()[1]
         cbytes = aln.image_compact()[1]
     if world > 1:
         # only the compact part travels (FM-indexes, suffix arrays, mixRef, 2-bit text); the 16-byte W-mer table that
         # ends the image is a function of it and each rank tabulates its own copy
+        t0 = time.time()
         sz = torch.tensor([cbytes], dtype=torch.int64, device=dev)
         dist.broadcast(sz, 0)
         cbytes = int(sz.item())
@@ -133,13 +149,23 @@ def main():
                                       compact=(img.data_ptr(), cbytes))
         torch.cuda.synchronize()
         del img
+        stages["broadcast_and_attach_replicas"] = round(time.time() - t0, 2)
     torch.cuda.synchronize()
     if rank == 0:
-        log("device index: %.2f GiB (compact part, the only thing broadcast: %.2f GiB), attach+broadcast %.1f s" % (nbytes / 2**30, cbytes / 2**30, time.time() - t0))
+        log("device index: %.2f GiB (compact part, the only thing broadcast: %.2f GiB); stages so far: %s" % (nbytes / 2**30, cbytes / 2**30, stages))
+
+    # ---- distinct read batches, resident ----
+    t0 = time.time()
+    n_batches = max(1, args.batches)
+    batches = []
+    for b in range(n_batches):
+        seqs, offs, _, _ = workload.make_reads_hash(genome, site, n_reads, L, seed=1 + rank, batch=b)
+        batches.append((seqs, offs))
+    torch.cuda.synchronize()
+    stages["reads"] = round(time.time() - t0, 2)
 
     opt = salt_amd.AlnOpt(l_seed=cfg["k"])
-    d_seqs = torch.from_numpy(seqs).to(dev)
-    d_offs = torch.from_numpy(offs.view(np.int32)).to(dev)
+    spr = (L - cfg["k"]) // cfg["k"] + 1
     # Steps are dealt round-robin to n_streams workspaces, each on its own HIP stream, all on the one device index: a step is
     # still one pass of the whole path over one batch, but the persistent kernels' tails of one batch overlap the wide kernels
     # of the next -- the way `salt` drives a GPU with 2-4 align workers (salt_main.cc).
@@ -147,22 +173,23 @@ def main():
     alns = [aln] + [aln.fork() for _ in range(n_streams - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
     d_ress = [torch.zeros(n_reads * salt_amd.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(n_streams)]
-    d_res = d_ress[0]
 
-    def step(i):
-        k = i % n_streams
-        alns[k].align_resident(opt, n_reads, L, d_seqs.data_ptr(), d_offs.data_ptr(), d_ress[k].data_ptr(), streams[k].cuda_stream)
+    def step(i, k=None):
+        k = i % n_streams if k is None else k
+        s, o = batches[i % n_batches]
+        alns[k].align_resident(opt, n_reads, L, s.data_ptr(), o.data_ptr(), d_ress[k].data_ptr(), streams[k].cuda_stream)
 
     torch.cuda.synchronize()
     for i in range(max(args.warmup, 0)):
         step(i)
     torch.cuda.synchronize()
-    # three serialized steps first (one workspace, one stream): per-kernel durations of a kernel that has the GPU to itself --
-    # what a roofline fraction is about; in the timed region a kernel shares the GPU with the other batches' kernels
+    # serialized steps first (one workspace, one stream, every batch once): per-kernel durations of a kernel that has the GPU to
+    # itself -- what a roofline fraction is about; in the timed region a kernel shares the GPU with the other batches' kernels
     for a in alns:
         a.timing(True)
-    for _ in range(3):
-        step(0)
+    n_serial = max(3, n_batches)
+    for i in range(n_serial):
+        step(i, 0)
     torch.cuda.synchronize()
     serial_kms, serial_calls = aln.kernel_ms()
     serial_kms = {k: v / max(serial_calls, 1) for k, v in serial_kms.items()}
@@ -188,102 +215,102 @@ def main():
         for k, v in km.items():
             kms[k] = kms.get(k, 0.0) + v
     kms = {k: v / max(n_calls, 1) for k, v in kms.items()}
-    heavy_ids = aln.heavy_reads()
-    qc = aln.queue_counts()
+    for a in alns:
+        a.timing(False)
 
     out = None
     if rank == 0:
         total_reads = n_reads * world * args.steps
         value = total_reads / dt / 1e6
+        names = {"grch38": "GRCh38-scale synthetic (SURVEY 8d config 3 = BASELINE configs[2])", "chr21": "chr21-scale synthetic (SURVEY 8d config 2)"}
         out = {
             "metric": "Mreads/s aligned (100 bp SE, GRCh38+snp144) at 1/2/4/8 MI355X vs CPU ref",
             "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "%s-scale synthetic (SURVEY 8d config 2): %d bp genome, %d SNPs, k=%d, %d x %d bp SE reads per GPU, "
-                                   "inputs and results resident in HBM" % (args.workload, cfg["genome_len"], cfg["n_snps"], cfg["k"], n_reads, L),
-                       "reads_per_gpu_per_step": n_reads, "read_len": L, "options": "default (-s 50 -m 1000, overlap = k)",
+            "config": {"workload": "%s: %d bp genome in %d contigs, %d SNPs, k=%d, %d x %d bp SE reads per GPU per step, %d distinct resident batches "
+                                   "rotated, inputs and results resident in HBM" % (names.get(args.workload, args.workload + " synthetic"), cfg["genome_len"],
+                                                                                    cfg.get("contigs", 1), cfg["n_snps"], cfg["k"], n_reads, L, n_batches),
+                       "reads_per_gpu_per_step": n_reads, "read_len": L, "distinct_batches": n_batches, "options": "default (-s 50 -m 1000, overlap = k)",
                        "parallelism": "reads sharded over %d GPU(s), index replicated (one RCCL broadcast of its compact part); "
                                       "steps dealt round-robin to %d workspace(s)/HIP stream(s) per GPU" % (world, n_streams),
                        "streams_per_gpu": n_streams},
+            "stages_s": stages,
             "kernel_ms": {k: round(v, 3) for k, v in kms.items()},
             "kernel_ms_serialized": {k: round(v, 3) for k, v in serial_kms.items()},
-            "reads_to_k_heavy": int(len(heavy_ids)),
-            "queue_counts": dict(zip(("heavy_reads", "gapped_reads", "k_gap_items", "k_cigar_items"), [qc[0], qc[2], qc[5], qc[6]])),
         }
+        # ---- one more serialized step of batch 0 with the access counters on (k_light instead of k_light2: same accesses) ----
+        copt = salt_amd.AlnOpt(l_seed=cfg["k"], collect_counters=1)
+        aln.counters()
+        s0, o0 = batches[0]
+        aln.align_resident(copt, n_reads, L, s0.data_ptr(), o0.data_ptr(), d_ress[0].data_ptr(), streams[0].cuda_stream)
+        torch.cuda.synchronize()
+        ctr = aln.counters()
+        qc = aln.queue_counts()
+        out["queue_counts"] = dict(zip(("heavy_reads", "gapped_reads", "k_gap_items", "k_cigar_items"), [qc[0], qc[2], qc[5], qc[6]]))
+        ctr["heavy_reads"] = qc[0]
+        try:
+            db = device_bytes(ctr, n_reads, L, spr)
+        except KeyError:
+            db = None
+        dom = max(serial_kms, key=lambda k: serial_kms[k])
+        prof = {}
+        pf = os.path.join(ROOT, "profiles", "r02", "pmc_summary_%s.json" % args.workload)
+        if os.path.exists(pf):
+            try:
+                prof = json.load(open(pf))
+            except Exception:
+                prof = {}
+        roof = {"bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "timing": "HIP events on the launch stream over %d serialized steps of this run, every resident batch once (kernel_ms_serialized)" % n_serial}
+        if db and dom in db:
+            ach = db[dom] / (serial_kms[dom] / 1e3) / 1e9
+            roof.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": int(db[dom]),
+                         "avg_launch_ms": round(serial_kms[dom], 3),
+                         "all_kernels": {k: {"bytes_per_launch": int(v), "ms": round(serial_kms.get(k, 0.0), 3),
+                                             "GBps": round(v / (serial_kms[k] / 1e3) / 1e9, 1) if serial_kms.get(k) else None} for k, v in db.items()},
+                         "whole_step_GBps_wall": round(sum(db.values()) / (dt / args.steps) / 1e9, 1),
+                         "bytes_model": "device layout: 64 B per W-mer gather, 32/64 B per C/R Occ block fetched, 4 B per SA / R-position load, 8 B per text "
+                                        "word pair, 16 B per verify lane-load, packed read records, 32 B per seed interval pair, result rows; counted by the kernels"})
+        tr = prof.get("hbm_bytes_per_launch", {}).get(dom)
+        roof["traffic"] = tr
+        if tr:
+            roof["traffic_GBps"] = round(tr / (serial_kms[dom] / 1e3) / 1e9, 1)
+        ir = prof.get("issue", {}).get(dom)
+        if ir:
+            roof["issue_bound"] = ir
+        roof["counters"] = {k: int(v) for k, v in ctr.items() if k.startswith("d_")}
+        out["roofline"] = roof
+
         # ---- CPU baseline + parity check on a bounded sample (oracle = checker, never the product) ----
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle_py
             ns = min(args.cpu_sample, n_reads)
-            ora = oracle_py.Oracle(os.path.join(w["dir"], "idx"))
+            t1 = time.time()
+            ora = oracle_py.Oracle(w["prefix"])
+            stages["oracle_load_files"] = round(time.time() - t1, 2)
             oo = ora.opt()
             cores = min(os.cpu_count() or 1, 64)
+            hs, ho = s0[:ns * L].cpu().numpy(), o0[:ns + 1].cpu().numpy().view(np.uint32)
             t1 = time.perf_counter()
-            ores = ora.align(oo, seqs[:ns * L], offs[:ns + 1], n_threads=cores)
+            ores = ora.align(oo, hs, ho, n_threads=cores)
             cpu_dt = time.perf_counter() - t1
-            # logical accesses of the reference algorithm, separately for the reads each align kernel took
-            nc = min(ns, 40000)
-            is_heavy = np.zeros(n_reads, dtype=bool)
-            is_heavy[heavy_ids] = True
-            rd = seqs[:nc * L].reshape(nc, L)
-            sub_off = lambda m: (np.arange(m + 1, dtype=np.uint64) * L).astype(np.uint32)
-            hv, lt_ = rd[is_heavy[:nc]], rd[~is_heavy[:nc]]
-            _, ctr = ora.align(oo, rd.reshape(-1), sub_off(nc), n_threads=cores, counters=True)
-            ctr_h = ora.align(oo, hv.reshape(-1), sub_off(len(hv)), n_threads=cores, counters=True)[1] if len(hv) else None
-            ctr_l = ora.align(oo, lt_.reshape(-1), sub_off(len(lt_)), n_threads=cores, counters=True)[1] if len(lt_) else None
-            gres = d_res.cpu().numpy().view(salt_amd.RESULT_DTYPE)[:ns]
+            gres = d_ress[0].cpu().numpy().view(salt_amd.RESULT_DTYPE)[:ns]     # batch 0 was the last batch aligned into d_ress[0]
             bad = oracle_py.compare(gres, ores)
             out["cpu_baseline"] = {"value": round(ns / cpu_dt / 1e6, 5), "unit": "Mreads/s", "cores": cores, "kind": "port",
-                                   "sample": "first %d reads of the same batch, oracle/libsalt_oracle.so (bit-exact CPU restatement "
-                                             "of the reference), %d threads, align time only" % (ns, cores),
-                                   "speedup_1gpu": round(value / (ns / cpu_dt / 1e6), 1)}
-            out["parity"] = {"checked_reads": int(ns), "mismatching_reads": int(len(bad))}
-            b_seed, b_align = algorithmic_bytes(ctr, L)
-            n_heavy = len(heavy_ids)
-            # k_heavy, k_gap and k_gapfin share one byte figure: the oracle counts per read, and a read that k_light queues
-            # is finished by those three kernels together ("heavy stage")
-            HEAVY = ("k_heavy", "k_gap", "k_gapfin", "k_cigar")
-            SEED = ("k_pack", "k_seed")
-            per_launch = {"seed_stage": b_seed * n_reads,
-                          "k_light": (algorithmic_bytes(ctr_l, L)[1] if ctr_l else 0.0) * (n_reads - n_heavy),
-                          "heavy_stage": (algorithmic_bytes(ctr_h, L)[1] if ctr_h else 0.0) * n_heavy}
-            live_kms = kms
-            kms = serial_kms                                          # roofline basis: the kernel alone on the GPU (HIP events, this run)
-            stage_ms = {"seed_stage": sum(kms[k] for k in SEED), "k_light": kms["k_light"], "heavy_stage": sum(kms[k] for k in HEAVY)}
-            live_stage_ms = {"seed_stage": sum(live_kms[k] for k in SEED), "k_light": live_kms["k_light"], "heavy_stage": sum(live_kms[k] for k in HEAVY)}
-            dom = max(kms, key=lambda k: kms[k])                      # the single kernel with the longest launch
-            grp = "heavy_stage" if dom in HEAVY else "seed_stage" if dom in SEED else dom
-            ach = per_launch[grp] / (stage_ms[grp] / 1e3) / 1e9
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(tf):
-                try:
-                    tj = json.load(open(tf)).get(args.workload, {})
-                    traffic = sum(tj[k] for k in HEAVY) if grp == "heavy_stage" else sum(tj[k] for k in SEED) if grp == "seed_stage" else tj.get(dom)
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": dom if grp == dom else "+".join(HEAVY if grp == "heavy_stage" else SEED), "achieved": round(ach, 2),
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                               "algorithmic_bytes_per_read": {"seed_stage": round(b_seed, 1), "align_stage": round(b_align, 1)},
-                               "bytes_per_launch": {k: round(v, 0) for k, v in per_launch.items()},
-                               "avg_launch_ms": round(stage_ms[grp], 3),
-                               "all_stages_GBps": {k: round(per_launch[k] / (stage_ms[k] / 1e3) / 1e9, 1) for k in stage_ms if stage_ms[k] > 0},
-                               "whole_step_GBps": round(sum(per_launch.values()) / (sum(stage_ms.values()) / 1e3) / 1e9, 1),
-                               "whole_step_GBps_wall": round(sum(per_launch.values()) / (dt / args.steps) / 1e9, 1),
-                               "timing": "HIP events on the launch stream over 3 serialized steps of this run (kernel_ms_serialized)",
-                               "timed_region": {"streams": n_streams, "avg_launch_ms": round(live_stage_ms[grp], 3),
-                                                "achieved": round(per_launch[grp] / (live_stage_ms[grp] / 1e3) / 1e9, 2),
-                                                "frac": round(per_launch[grp] / (live_stage_ms[grp] / 1e3) / 1e9 / HBM_PEAK_GBS, 5)},
-                               "physical_GBps": (round(traffic / (stage_ms[grp] / 1e3) / 1e9, 1) if traffic else None),
-                               "note": "achieved = the REFERENCE algorithm's logical bytes (SURVEY 8d formula, counted by the oracle) / kernel time; "
-                                       "the device layout (full SA, 16-byte W-mer table, 32/64-byte Occ blocks) moves fewer bytes than that, so the "
-                                       "seed stage can exceed 1.0 of HBM peak; physical_GBps = measured FETCH+WRITE traffic / the same time. "
-                                       "In the timed region %d batches are in flight on as many streams: a kernel then shares the GPU with other "
-                                       "batches' kernels, its own start-to-end time (kernel_ms, roofline.timed_region) is longer while the batch rate "
-                                       "is higher; achieved / frac are taken from the serialized steps, where the duration is the kernel's own; "
-                                       "whole_step_GBps_wall = all stages' bytes / ms_per_step" % n_streams}
+                                   "sample": "first %d reads of batch 0 of the same workload, oracle/libsalt_oracle.so (bit-exact CPU restatement "
+                                             "of the reference), %d threads, align time only (%.1f s)" % (ns, cores, cpu_dt),
+                                   "speedup_1gpu": round(value / world / (ns / cpu_dt / 1e6), 1)}
+            out["parity"] = {"checked_reads": int(ns), "mismatching_reads": int(len(bad)),
+                             "mapped_fraction": round(float((gres["pos"] != 0xFFFFFFFF).mean()), 5)}
             ora.close()
+        # ---- end to end: the drop-in binary, FASTQ text -> SAM text, wall clock (SURVEY 8d's metric; never `value`) ----
+        if args.e2e_reads > 0:
+            try:
+                out["e2e"] = e2e_leg(args, cfg, w, genome, site, workload, torch, np, log)
+            except Exception as ex:                                    # the leg is a report, not a gate
+                out["e2e"] = {"error": str(ex)[:300]}
         print(json.dumps(out), flush=True)
     for a in alns[1:]:
         a.close()
@@ -293,6 +320,44 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log):
+    """`salt -d -c` on a FASTQ file of the same workload: wall clock from the first batch submitted to the last SAM byte written
+    (the binary's own clock, which starts after the index is loaded and attached), plus the whole process."""
+    L = cfg["read_len"]
+    d = w["dir"]
+    fq = os.path.join(d, "e2e.fq")
+    n = args.e2e_reads
+    t0 = time.time()
+    with open(fq, "wb") as f:
+        done = 0
+        while done < n:
+            m = min(1000000, n - done)
+            seqs, _, _, _ = workload.make_reads_hash(genome, site, m, L, seed=77, batch=done // 1000000)
+            f.write(workload.fastq_bytes(seqs.cpu().numpy(), m, L, first_id=done))
+            done += m
+    t_write = time.time() - t0
+    threads = min(os.cpu_count() or 1, 64)
+    salt = os.path.join(ROOT, "salt_amd", "bin", "salt")
+    sam = os.path.join(d, "e2e.sam")
+    t0 = time.time()
+    with open(sam, "wb") as fo:
+        p = subprocess.run([salt, "-d", "-c", "-t", str(threads), w["prefix"], fq], stdout=fo, stderr=subprocess.PIPE, timeout=900)
+    wall = time.time() - t0
+    err = p.stderr.decode(errors="replace")
+    if p.returncode != 0:
+        raise RuntimeError("salt exited %d: %s" % (p.returncode, err[-200:]))
+    align_s = None
+    for line in err.splitlines():
+        if line.startswith("[alnse_core]: total"):
+            align_s = float(line.split()[2])
+    sam_bytes = os.path.getsize(sam)
+    os.unlink(sam); os.unlink(fq)
+    return {"value": round(n / align_s / 1e6, 3) if align_s else None, "unit": "Mreads/s", "reads": n, "threads": threads,
+            "what": "salt -d -c -t %d <idx> reads.fq > out.sam: FASTQ text in, SAM text out (%.2f GB), PCIe and host I/O included; clock = the binary's "
+                    "[alnse_core] total (first batch submitted to last SAM byte written; index load + attach excluded, as SURVEY 8d defines it)" % (threads, sam_bytes / 1e9),
+            "align_wall_s": align_s, "process_wall_s": round(wall, 2), "fastq_write_s": round(t_write, 2)}
 
 
 if __name__ == "__main__":

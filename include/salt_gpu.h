@@ -98,7 +98,8 @@ typedef struct {
     uint16_t hit_cigar[SALT_MAX_HITS][SALT_MAX_CIGAR_OPS];
 } salt_result_t;                                /* 880 bytes */
 
-/* logical accesses of the reference algorithm, summed over a batch */
+/* access counters summed over a batch (only with collect_counters): SA / verify / LV / loci entries count what the align kernels do
+ * per located row and candidate; LKT / OCC_C / OCC_R count k_seed's DEVICE accesses (W-mer gathers, Occ blocks fetched) */
 enum { SALT_CTR_LKT, SALT_CTR_OCC_C, SALT_CTR_OCC_R, SALT_CTR_SA_C, SALT_CTR_SA_R, SALT_CTR_VERIFY,
        SALT_CTR_VERIFY_WORDS, SALT_CTR_LV, SALT_CTR_READS, SALT_CTR_BASES, SALT_CTR_LOCI,
        /* diagnostics: shader-clock cycles k_heavy waves spent per phase (only with collect_counters) */
@@ -106,6 +107,11 @@ enum { SALT_CTR_LKT, SALT_CTR_OCC_C, SALT_CTR_OCC_R, SALT_CTR_SA_C, SALT_CTR_SA_
        SALT_CTR_T_SCAN, SALT_CTR_T_GAP, SALT_CTR_T_TAIL, SALT_CTR_HEAVY_READS, SALT_CTR_X0, SALT_CTR_X1, SALT_CTR_X2, SALT_CTR_X3,
        SALT_CTR_LT_SEEDS, SALT_CTR_LT_LOCATE, SALT_CTR_LT_SORT, SALT_CTR_LT_VERIFY, SALT_CTR_LT_OUT, SALT_CTR_LT_SAMPLES,   /* k_light: s_memtime ticks of every 128th read */
        SALT_CTR_MAX_HEAVY, SALT_CTR_MAX_GAPFIN,   /* slowest read of k_heavy / k_gapfin: (s_memrealtime ticks << 32) | read index */
+       /* DEVICE-layout accesses (what the kernels' own structures move; bench.py's roofline): k_seed -- 16-byte W-mer table gathers,
+        * 32-byte C / 64-byte R Occ blocks fetched, suffix-array loads and 8-byte text loads of the one-row resolve; k_light / k_heavy --
+        * 4-byte suffix-array / R-position loads, 16-byte verify lane-loads, result bytes stored */
+       SALT_CTR_D_WLKT, SALT_CTR_D_COCC_SEED, SALT_CTR_D_ROCC_SEED, SALT_CTR_D_SA_SEED, SALT_CTR_D_TEXT_SEED,
+       SALT_CTR_D_SA_LIGHT, SALT_CTR_D_VERIFY_LIGHT, SALT_CTR_D_OUT_LIGHT, SALT_CTR_D_SA_HEAVY, SALT_CTR_D_VERIFY_HEAVY, SALT_CTR_D_OUT_HEAVY,
        SALT_CTR_N };
 
 typedef struct salt_gpu_index salt_gpu_index_t;

@@ -22,7 +22,9 @@ MAX_HITS = 5
 MAX_CIGAR_OPS = 64
 CTR_NAMES = ["lkt", "occ_c", "occ_r", "sa_c", "sa_r", "verify", "verify_words", "lv", "reads", "bases", "loci",
              "t_load", "t_gather", "t_locate", "t_sort", "t_dedup", "t_verify", "t_scan", "t_gap", "t_tail", "heavy_reads", "x0", "x1", "x2", "x3",
-             "lt_seeds", "lt_locate", "lt_sort", "lt_verify", "lt_out", "lt_samples", "max_heavy", "max_gapfin"]
+             "lt_seeds", "lt_locate", "lt_sort", "lt_verify", "lt_out", "lt_samples", "max_heavy", "max_gapfin",
+             "d_wlkt", "d_cocc_seed", "d_rocc_seed", "d_sa_seed", "d_text_seed", "d_sa_light", "d_verify_light", "d_out_light",
+             "d_sa_heavy", "d_verify_heavy", "d_out_heavy"]
 
 
 class SaltError(RuntimeError):

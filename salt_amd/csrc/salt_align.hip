@@ -265,7 +265,7 @@ __device__ __forceinline__ bool seed_is_n(const SeedCtx c, uint32_t i)
 // read and the text in front of that suffix differ.  Everything by value: what a lambda captures by reference ends up in scratch.
 __device__ __forceinline__ uint32_t seed_resolve_unique(const uint32_t *__restrict__ c_sa, const uint32_t *__restrict__ text, uint32_t c_seq_len,
                                                         uint32_t s, uint32_t wb, uint32_t nb, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t n0, uint32_t n1,
-                                                        int it, uint32_t row, uint32_t &n_occ_c)
+                                                        int it, uint32_t row, uint32_t &n_aux)
 {
         const uint32_t m = (uint32_t)it + 1u;
         const uint32_t reln = s - (nb << 5);
@@ -282,12 +282,14 @@ __device__ __forceinline__ uint32_t seed_resolve_unique(const uint32_t *__restri
             const uint32_t xr = (uint32_t)((vr >> (64 - 2 * rr - 2 * cnt)) & ((1ull << (2 * cnt)) - 1ull));
             const uint32_t tj = t0 >> 4, tr = t0 & 15u;
             const uint64_t vt = ((uint64_t)text[tj] << 32) | text[tj + 1];
+            n_aux += 1u << 21;                               // one 8-byte text load
             const uint32_t xt = (uint32_t)((vt >> (64 - 2 * tr - 2 * cnt)) & ((1ull << (2 * cnt)) - 1ull));
             const uint32_t diff = xr ^ xt;
             if (diff) { ok = false; steps = done + ((uint32_t)__ffs((int)diff) - 1u) / 2u + 1u; }
             done += cnt;
         }
-        n_occ_c += 2 * steps;
+        (void)steps;
+        n_aux += 1u << 10;                                   // one suffix-array load
         return ok ? p0 - m : 0xFFFFFFFFu;
     }
 
@@ -296,18 +298,18 @@ __device__ __forceinline__ uint32_t seed_resolve_unique(const uint32_t *__restri
 // succeeds iff the read's remaining bases equal the text in front of that suffix, so one suffix-array load and one text load
 // replace the remaining Occ steps and the seed leaves already located (.w = 2: .x = .y = the genome position).
 __device__ __forceinline__ uint4 seed_c_rest(const IndexView &ix, const SeedParams &sp, const SeedCtx c, uint32_t kc, uint32_t lc, int i_top,
-                                             uint32_t &n_occ_c)
+                                             uint32_t &n_occ_c, uint32_t &n_aux)
 {
     const uint32_t s = c.s;
     const bool uniq = c.inreg && sp.resolve_unique;
     bool alive = true, located = false;
-    if (uniq && kc == lc && i_top >= 0) { const uint32_t p = seed_resolve_unique(ix.c_sa, ix.text, ix.c_seq_len, s, c.wb, c.nb, c.w0, c.w1, c.w2, c.n0, c.n1, i_top, kc, n_occ_c); alive = p != 0xFFFFFFFFu; located = alive; if (alive) kc = lc = p; }
+    if (uniq && kc == lc && i_top >= 0) { const uint32_t p = seed_resolve_unique(ix.c_sa, ix.text, ix.c_seq_len, s, c.wb, c.nb, c.w0, c.w1, c.w2, c.n0, c.n1, i_top, kc, n_aux); alive = p != 0xFFFFFFFFu; located = alive; if (alive) kc = lc = p; }
     for (int i = i_top; i >= 0 && alive && !located; --i) {
         if (seed_is_n(c, s + (uint32_t)i)) { alive = false; break; }
         const uint32_t b = seed_base2(c, s + (uint32_t)i);
-        uint32_t ok, ol; c_occ2(ix, kc - 1, lc, b, ok, ol);
-        { const uint32_t l2 = pick4(ix.c_L2, b); kc = l2 + ok + 1; lc = l2 + ol; } alive = kc <= lc; n_occ_c += 2;
-        if (uniq && alive && kc == lc && i > 0) { const uint32_t p = seed_resolve_unique(ix.c_sa, ix.text, ix.c_seq_len, s, c.wb, c.nb, c.w0, c.w1, c.w2, c.n0, c.n1, i - 1, kc, n_occ_c); alive = p != 0xFFFFFFFFu; located = alive; if (alive) kc = lc = p; }
+        uint32_t ok, ol; n_occ_c += c_occ2(ix, kc - 1, lc, b, ok, ol);
+        { const uint32_t l2 = pick4(ix.c_L2, b); kc = l2 + ok + 1; lc = l2 + ol; } alive = kc <= lc;
+        if (uniq && alive && kc == lc && i > 0) { const uint32_t p = seed_resolve_unique(ix.c_sa, ix.text, ix.c_seq_len, s, c.wb, c.nb, c.w0, c.w1, c.w2, c.n0, c.n1, i - 1, kc, n_aux); alive = p != 0xFFFFFFFFu; located = alive; if (alive) kc = lc = p; }
     }
     if (!alive) return make_uint4(1, 0, 0, 0);
     if (located) return make_uint4(kc, kc, s, 2);
@@ -315,8 +317,7 @@ __device__ __forceinline__ uint4 seed_c_rest(const IndexView &ix, const SeedPara
     while (lc - kc > sp.max_seed && ext < s) {
         if (seed_is_n(c, s - ext - 1)) break;
         const uint32_t b = seed_base2(c, s - ext - 1);
-        uint32_t ok, ol; c_occ2(ix, kc - 1, lc, b, ok, ol);
-        n_occ_c += 2;
+        uint32_t ok, ol; n_occ_c += c_occ2(ix, kc - 1, lc, b, ok, ol);
         if (ok + 1 > ol) break;
         { const uint32_t l2 = pick4(ix.c_L2, b); kc = l2 + ok + 1; lc = l2 + ol; } ++ext;
         if (lc - kc <= sp.max_seed) break;
@@ -333,15 +334,14 @@ __device__ __forceinline__ uint4 seed_r_rest(const IndexView &ix, const SeedPara
     for (int i = i_top; i >= 0 && alive; --i) {
         if (seed_is_n(c, s + (uint32_t)i)) { alive = false; break; }
         const uint32_t b = seed_base2(c, s + (uint32_t)i);
-        uint32_t ok, ol; r_occ2(ix, kr, lr + 1, b, ok, ol);
-        { const uint32_t cm = pick5(ix.r_cum, b); kr = cm + ok + 1; lr = cm + ol; } alive = kr <= lr; n_occ_r += 2;
+        uint32_t ok, ol; n_occ_r += r_occ2(ix, kr, lr + 1, b, ok, ol);
+        { const uint32_t cm = pick5(ix.r_cum, b); kr = cm + ok + 1; lr = cm + ol; } alive = kr <= lr;
     }
     if (!alive) return make_uint4(1, 0, 0, 0);
     uint32_t ext = 0;
     while (lr - kr > sp.max_seed && ext < s) {
         const uint32_t b = seed_is_n(c, s - ext - 1) ? 4u : seed_base2(c, s - ext - 1);               // an N walks the '#' column
-        uint32_t ok, ol; r_occ2(ix, kr, lr + 1, b, ok, ol);
-        n_occ_r += 2;
+        uint32_t ok, ol; n_occ_r += r_occ2(ix, kr, lr + 1, b, ok, ol);
         if (ok + 1 > ol) break;
         { const uint32_t cm = pick5(ix.r_cum, b); kr = cm + ok + 1; lr = cm + ol; } ++ext;
         if (lr - kr <= sp.max_seed) break;
@@ -385,14 +385,13 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
             }
             if (!has_n) {
                 const uint4 v = ix.wlkt[x];                  // one 16-byte gather: C interval in .x/.y, R interval in .z/.w
-                ++n_lkt; n_occ_c += 2 * (W - ix.lkt_len);
+                ++n_lkt;                                     // device counters: bits 0..9 W-mer gathers, 10..20 SA loads, 21..31 text loads
                 const int i_top = (int)(c.k - W) - 1;        // head bases s .. s+i_top are still to consume
                 if (v.x <= v.y) {
-                    if ((v.x == v.y && c.inreg && sp.resolve_unique) || i_top < 0) oc = seed_c_rest(ix, sp, c, v.x, v.y, i_top, n_occ_c);   // no walk left (or only the extension)
+                    if ((v.x == v.y && c.inreg && sp.resolve_unique) || i_top < 0) oc = seed_c_rest(ix, sp, c, v.x, v.y, i_top, n_occ_c, n_lkt);   // no walk left (or only the extension)
                     else { pend_c = true; pk_c = v.x; pl_c = v.y; }
                 }
                 if (!sp.seed_only_ref) {
-                    n_occ_r += 2 * W;
                     if (v.z <= v.w) { pend_r = true; pk_r = v.z; pl_r = v.w; }
                 }
             }
@@ -418,15 +417,16 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
         const SeedCtx c = seed_ctx(sp, tb, (uint32_t)it, ix.r_lkt_len);
         const int i_top = (int)(c.k - c.W) - 1;
         if (which == 0) sai_r[it] = seed_r_rest(ix, sp, c, q_k[0][at], q_l[0][at], i_top, n_occ_r);
-        else sai_c[it] = seed_c_rest(ix, sp, c, q_k[1][at], q_l[1][at], i_top, n_occ_c);
+        else sai_c[it] = seed_c_rest(ix, sp, c, q_k[1][at], q_l[1][at], i_top, n_occ_c, n_lkt);
     }
     if (ctr) {                                                // one atomic per wave and counter
         for (int o = 32; o > 0; o >>= 1) {
             n_lkt += __shfl_down(n_lkt, o); n_occ_c += __shfl_down(n_occ_c, o); n_occ_r += __shfl_down(n_occ_r, o);
         }
         if (lane_id() == 0) {
-            atomicAdd(ctr + SALT_CTR_LKT, n_lkt); atomicAdd(ctr + SALT_CTR_OCC_C, n_occ_c);
-            atomicAdd(ctr + SALT_CTR_OCC_R, n_occ_r);
+            atomicAdd(ctr + SALT_CTR_LKT, n_lkt & 1023u); atomicAdd(ctr + SALT_CTR_OCC_C, n_occ_c); atomicAdd(ctr + SALT_CTR_OCC_R, n_occ_r);
+            atomicAdd(ctr + SALT_CTR_D_WLKT, n_lkt & 1023u); atomicAdd(ctr + SALT_CTR_D_COCC_SEED, n_occ_c); atomicAdd(ctr + SALT_CTR_D_ROCC_SEED, n_occ_r);
+            atomicAdd(ctr + SALT_CTR_D_SA_SEED, (n_lkt >> 10) & 2047u); atomicAdd(ctr + SALT_CTR_D_TEXT_SEED, n_lkt >> 21);
         }
     }
 }
@@ -1337,6 +1337,9 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                             atomicAdd(ctr + SALT_CTR_VERIFY, c_verify); atomicAdd(ctr + SALT_CTR_VERIFY_WORDS, c_vwords);
                             atomicAdd(ctr + SALT_CTR_LV, ns[0] + ns[1]); atomicAdd(ctr + SALT_CTR_READS, 1ull);
                             atomicAdd(ctr + SALT_CTR_BASES, L); atomicAdd(ctr + SALT_CTR_LOCI, c_loci);
+                            atomicAdd(ctr + SALT_CTR_D_SA_HEAVY, c_sa_c + c_sa_r);
+                            atomicAdd(ctr + SALT_CTR_D_VERIFY_HEAVY, c_verify * (L <= 120 ? 4u : L <= 248 ? 8u : (((L + 7) >> 3) + 4u) / 4u));
+                            atomicAdd(ctr + SALT_CTR_D_OUT_HEAVY, 5u * (ns[0] + ns[1]) + 16u);      // the located rows + distances handed to k_gap
                         }
                     }
                     return;
@@ -1466,6 +1469,9 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             atomicAdd(ctr + SALT_CTR_VERIFY, c_verify); atomicAdd(ctr + SALT_CTR_VERIFY_WORDS, c_vwords);
             atomicAdd(ctr + SALT_CTR_LV, c_lv); atomicAdd(ctr + SALT_CTR_READS, 1ull);
             atomicAdd(ctr + SALT_CTR_BASES, L); atomicAdd(ctr + SALT_CTR_LOCI, c_loci);
+            atomicAdd(ctr + SALT_CTR_D_SA_HEAVY, c_sa_c + c_sa_r);
+            atomicAdd(ctr + SALT_CTR_D_VERIFY_HEAVY, c_verify * (L <= 120 ? 4u : L <= 248 ? 8u : (((L + 7) >> 3) + 4u) / 4u));
+            atomicAdd(ctr + SALT_CTR_D_OUT_HEAVY, 128u);
         }
     }
 }
@@ -1897,6 +1903,9 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
             atomicAdd(ctr + SALT_CTR_SA_C, c_sa_c); atomicAdd(ctr + SALT_CTR_SA_R, c_sa_r);
             atomicAdd(ctr + SALT_CTR_VERIFY, c_verify); atomicAdd(ctr + SALT_CTR_VERIFY_WORDS, c_vwords);
             atomicAdd(ctr + SALT_CTR_READS, 1ull); atomicAdd(ctr + SALT_CTR_BASES, L); atomicAdd(ctr + SALT_CTR_LOCI, c_loci);
+            atomicAdd(ctr + SALT_CTR_D_SA_LIGHT, c_sa_c + c_sa_r);
+            atomicAdd(ctr + SALT_CTR_D_VERIFY_LIGHT, c_verify * (L <= 120 ? 4u : L <= 248 ? 8u : (((L + 7) >> 3) + 4u) / 4u));
+            atomicAdd(ctr + SALT_CTR_D_OUT_LIGHT, 40u);                     // 24-byte header + CIGAR word + (typically one) 8-byte hit
         }
     }
 }

@@ -90,7 +90,8 @@ __device__ __forceinline__ uint32_t c_occ_eval(const uint4 cnt, const uint4 pl, 
     const uint64_t eq = ((c & 1) ? lo : ~lo) & ((c & 2) ? hi : ~hi) & mask;
     return sel4(cnt, c) + (uint32_t)__popcll(eq);
 }
-__device__ __forceinline__ void c_occ2(const IndexView &ix, const uint32_t k, const uint32_t l, const uint32_t c, uint32_t &ok, uint32_t &ol)
+// returns the number of 32-byte blocks fetched (0..2)
+__device__ __forceinline__ uint32_t c_occ2(const IndexView &ix, const uint32_t k, const uint32_t l, const uint32_t c, uint32_t &ok, uint32_t &ol)
 {
     const uint32_t full = pick4(ix.c_L2 + 1, c) - pick4(ix.c_L2, c);
     const bool ks = k == ix.c_seq_len || k == 0xFFFFFFFFu, ls = l == ix.c_seq_len || l == 0xFFFFFFFFu;
@@ -98,9 +99,11 @@ __device__ __forceinline__ void c_occ2(const IndexView &ix, const uint32_t k, co
     uint4 cnt = make_uint4(0, 0, 0, 0), pl = make_uint4(0, 0, 0, 0);
     if (!ks) { const uint4 *p = reinterpret_cast<const uint4 *>(ix.c_occ + (kk >> 6)); cnt = p[0]; pl = p[1]; }
     ok = ks ? (k == ix.c_seq_len ? full : 0u) : c_occ_eval(cnt, pl, kk, c);
-    if (ls) { ol = l == ix.c_seq_len ? full : 0u; return; }
-    if (ks || (ll >> 6) != (kk >> 6)) { const uint4 *p = reinterpret_cast<const uint4 *>(ix.c_occ + (ll >> 6)); cnt = p[0]; pl = p[1]; }
+    if (ls) { ol = l == ix.c_seq_len ? full : 0u; return ks ? 0u : 1u; }
+    const bool second = ks || (ll >> 6) != (kk >> 6);
+    if (second) { const uint4 *p = reinterpret_cast<const uint4 *>(ix.c_occ + (ll >> 6)); cnt = p[0]; pl = p[1]; }
     ol = c_occ_eval(cnt, pl, ll, c);
+    return (ks ? 0u : 1u) + (second ? 1u : 0u);
 }
 
 // symbol k of the $-removed C BWT (bwt_B0, bwt.h:64) -- used only by the attach-time SA expansion
@@ -150,13 +153,16 @@ __device__ __forceinline__ uint32_t r_occ_eval(const ROccBlk &r, const uint32_t 
     const uint32_t base = c < 4 ? sel4(r.cnt, c) : (blk << 7) - (r.cnt.x + r.cnt.y + r.cnt.z + r.cnt.w);
     return base + (uint32_t)__popcll(el) + (uint32_t)__popcll(eh);
 }
-__device__ __forceinline__ void r_occ2(const IndexView &ix, uint32_t a, uint32_t b, const uint32_t c, uint32_t &oa, uint32_t &ob)
+// returns the number of 64-byte blocks fetched (1 or 2)
+__device__ __forceinline__ uint32_t r_occ2(const IndexView &ix, uint32_t a, uint32_t b, const uint32_t c, uint32_t &oa, uint32_t &ob)
 {
     a -= (a > ix.r_inv_sa0); b -= (b > ix.r_inv_sa0);              // '$' is not stored (rbwt.c:165)
     ROccBlk r = r_occ_load(ix, a >> 7);
     oa = r_occ_eval(r, a, c);
-    if ((b >> 7) != (a >> 7)) r = r_occ_load(ix, b >> 7);
+    const bool second = (b >> 7) != (a >> 7);
+    if (second) r = r_occ_load(ix, b >> 7);
     ob = r_occ_eval(r, b, c);
+    return second ? 2u : 1u;
 }
 
 // Rbwt_bwt2nt (rbwt.h:103-122): BWT symbol of row pos; the '$' row reads as '#'

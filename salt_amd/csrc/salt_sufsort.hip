@@ -61,7 +61,6 @@ __global__ void __launch_bounds__(TPB) k_keys0(const uint8_t *__restrict__ text,
             uint64_t key = 0;
 #pragma unroll
             for (int j = 0; j < K; ++j) key = (key << BITS) | tile[threadIdx.x + j];
-            if (BITS * K < 64) key <<= (64 - BITS * K);
             const uint64_t i = n - 1 - p;                                  // element i holds position n-1-i
             keys[i] = key; vals[i] = (uint32_t)p;
         }
@@ -159,10 +158,10 @@ int suffix_sort(const uint8_t *d_text, uint64_t n, int bits, uint32_t *d_sa, uin
     if (bits == 2) hipLaunchKernelGGL(k_keys0<2>, dim3(grid_for(n)), dim3(TPB), 0, nullptr, d_text, n, keys_a.as<uint64_t>(), vals_a.as<uint32_t>());
     else hipLaunchKernelGGL(k_keys0<3>, dim3(grid_for(n)), dim3(TPB), 0, nullptr, d_text, n, keys_a.as<uint64_t>(), vals_a.as<uint32_t>());
     SCHK(hipGetLastError());
-    const unsigned begin_bit = bits == 2 ? 0u : 1u;                     // 21 x 3 bits sit in bits 1..63
-    SCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<uint32_t>(), d_sa, (size_t)n, begin_bit, 64u, nullptr));
+    const unsigned key_bits = bits == 2 ? 64u : 63u;                    // 32 x 2 or 21 x 3 bits, in the low bits of the key
+    SCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<uint32_t>(), d_sa, (size_t)n, 0u, key_bits, nullptr));
     SCHK(tmp.alloc(tmp_bytes));
-    SCHK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<uint32_t>(), d_sa, (size_t)n, begin_bit, 64u, nullptr));
+    SCHK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<uint32_t>(), d_sa, (size_t)n, 0u, key_bits, nullptr));
     hipLaunchKernelGGL(k_flags0, dim3(grid_for(n)), dim3(TPB), 0, nullptr, keys_b.as<uint64_t>(), d_sa, n, K, flag.as<uint8_t>(), start.as<uint32_t>());
     SCHK(hipGetLastError());
     keys_a.release(); keys_b.release(); vals_a.release();

@@ -396,28 +396,57 @@ def write_fastq(path, seqs, offs, n=None):
             f.write(b"@r%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
 
 
-def generate(config):
-    """(genome codes, SNP positions, SNP allele masks) of a config -- a pure function of its seeds."""
+def generate_device(config, device):
+    """(genome uint8 codes, sorted int64 SNP positions, uint8 allele masks) of a config as torch tensors on `device`.  The
+    `fast` configs are generated there (counter-based hash generator: the same data on any device); the numpy-generated ones
+    (chr21, mini, tiny, grch38_tenth) are generated on the host and copied."""
+    import torch
     c = CONFIGS[config]
     if c.get("fast"):
-        import torch
-        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-        tg = make_genome_hash(c["genome_len"], 38, dev)
-        tp, tm = make_snps_hash(tg, c["n_snps"], 144)
-        genome, pos, mask = tg.cpu().numpy(), tp.cpu().numpy(), tm.cpu().numpy()
-        del tg, tp, tm
-    else:
-        genome = make_genome(c["genome_len"])
-        pos, mask = make_snps(genome, c["n_snps"])
-    return genome, pos, mask
+        g = make_genome_hash(c["genome_len"], 38, device)
+        p, m = make_snps_hash(g, c["n_snps"], 144)
+        return g, p, m
+    genome = make_genome(c["genome_len"])
+    pos, mask = make_snps(genome, c["n_snps"])
+    return torch.from_numpy(genome).to(device), torch.from_numpy(pos).to(device), torch.from_numpy(mask).to(device)
 
 
-def prepare(config, cache_dir, gpu_device=None, log=None):
+def generate(config):
+    """The same as numpy arrays (genome codes, SNP positions, SNP allele masks) -- a pure function of the config's seeds."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    g, p, m = generate_device(config, dev)
+    return g.cpu().numpy(), p.cpu().numpy(), m.cpu().numpy()
+
+
+def fastq_bytes(seqs, n, L, first_id=0):
+    """FASTQ text of n fixed-length reads (uint8 codes, n * L of them): @r<10-digit id> / bases / + / 'I' qualities, built without a
+    per-read Python loop."""
+    chars = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    w = 1 + 1 + 10 + 1 + L + 1 + 2 + L + 1                     # "@r" + id + nl + seq + nl + "+\n" + qual + nl
+    rec = np.empty((n, w), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+    ids = np.arange(first_id, first_id + n, dtype=np.int64)
+    for d in range(10):
+        rec[:, 2 + 9 - d] = 48 + (ids // 10 ** d) % 10
+    rec[:, 12] = 10
+    rec[:, 13:13 + L] = chars[np.asarray(seqs[:n * L]).reshape(n, L)]
+    rec[:, 13 + L] = 10; rec[:, 14 + L] = ord("+"); rec[:, 15 + L] = 10
+    rec[:, 16 + L:16 + 2 * L] = ord("I")
+    rec[:, 16 + 2 * L] = 10
+    return rec.tobytes()
+
+
+def prepare(config, cache_dir, gpu_device="auto", log=None, arrays=None):
     """Generates the genome + SNP set of `config` and indexes it with the product's own salt-idx (from memory, without FASTA / SNP
     text files; `.lp` is not written) unless the cache holds the index already.  gpu_device: the device the suffix sorter runs on
-    (None = host SA-IS, minutes for hundreds of Mbp and hopeless for GRCh38).  Returns paths, the generated arrays and stage times."""
+    (None = host SA-IS, minutes for hundreds of Mbp and hopeless for GRCh38).  arrays: (genome, positions, masks) when the caller has
+    generated them already.  Returns paths, the generated arrays and stage times."""
     import time
     from . import api
+    if gpu_device == "auto":                                # test / bench tooling: the device sorter wherever a GPU is visible
+        import torch
+        gpu_device = torch.cuda.current_device() if torch.cuda.is_available() else None
     c = dict(CONFIGS[config])
     nc = c.setdefault("contigs", 1)
     d = os.path.join(cache_dir, "salt_%s_g%d_s%d_k%d" % (config, c["genome_len"], c["n_snps"], c["k"]))
@@ -426,19 +455,21 @@ def prepare(config, cache_dir, gpu_device=None, log=None):
     done = os.path.join(d, "DONE")
     times = {}
     t0 = time.time()
-    genome, pos, mask = generate(config)
-    times["generate_s"] = round(time.time() - t0, 2)
-    if log:
-        log("genome + SNPs generated in %.1f s" % times["generate_s"])
+    if arrays is not None:                                   # already generated (torch tensors on a device, or numpy arrays)
+        genome, pos, mask = [a.cpu().numpy() if hasattr(a, "cpu") else a for a in arrays]
+        times["to_host"] = round(time.time() - t0, 2)
+    else:
+        genome, pos, mask = generate(config)
+        times["generate_host"] = round(time.time() - t0, 2)
     if not os.path.exists(done):
         t0 = time.time()
         contigs, groups = as_builder_input(genome, pos, mask, nc)
-        times["letters_s"] = round(time.time() - t0, 2)
+        times["letters"] = round(time.time() - t0, 2)
         t0 = time.time()
         api.idx_build_mem(contigs, groups, prefix, c["k"], gpu_device=gpu_device, flags=api.IDX_NO_LP)
         del contigs, groups
-        times["index_s"] = round(time.time() - t0, 2)
+        times["index_build"] = round(time.time() - t0, 2)
         if log:
-            log("index built in %.1f s (%s suffix sorter)" % (times["index_s"], "device" if gpu_device is not None else "host"))
+            log("index built in %.1f s (%s suffix sorter)" % (times["index_build"], "device" if gpu_device is not None else "host"))
         open(done, "w").write("ok\n")
     return dict(dir=d, prefix=prefix, genome=genome, snp_pos=pos, snp_mask=mask, times=times, **c)
