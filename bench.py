@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+RANDOM_SECTOR_GBS = 2900.0     # measured: random 64-byte sectors from a 16 GiB table, tools/ubench/gather (profiles/r02/gather_rate.txt: 2.5-3.06 TB/s)
 SECTOR = 64                    # bytes a random access moves at least (one L2 / fabric sector)
 
 
@@ -276,6 +277,12 @@ def main():
         roof["traffic"] = tr
         if tr:
             roof["traffic_GBps"] = round(tr / (serial_kms[dom] / 1e3) / 1e9, 1)
+            roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE of profiles/r02 (separate --pmc passes), raw: tools/ubench/gather shows FETCH_SIZE = 64.0 B per random "
+                                    "4/16/32/64-byte record, i.e. exact for these gather shapes (no x2 streaming correction applies)")
+            roof["random_sector_ceiling_GBps"] = RANDOM_SECTOR_GBS
+            roof["traffic_frac_of_random_sector_ceiling"] = round(tr / (serial_kms[dom] / 1e3) / 1e9 / RANDOM_SECTOR_GBS, 3)
+            alltr = prof.get("hbm_bytes_per_launch", {})
+            roof["whole_step_traffic_GBps_wall"] = round(sum(alltr.values()) / (dt / args.steps) / 1e9, 1)
         ir = prof.get("issue", {}).get(dom)
         if ir:
             roof["issue_bound"] = ir

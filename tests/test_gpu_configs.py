@@ -1,0 +1,116 @@
+"""Parity on the BASELINE.json workloads themselves (SURVEY 8d configs 2, 3, 4 restated as seeded synthetic data), through the C ABI,
+against the CPU oracle:
+  config 2   chr21-scale: 40 Mbp, 190 000 SNPs, the WHOLE batch of 1 000 000 x 100-base SE reads, every result field
+  config 4'  the same genome, 2 x 150-base pairs (-p -a 250 -b 550): 60 000 pairs, every field after pairing / rescue
+  config 3   GRCh38-scale: 3.1e9 bases in 24 contigs, 14.8 M SNPs, indexed here by the device suffix sorter: 200 000 SE reads
+  config 4   2 x 150-base pairs on that index: 20 000 pairs
+Each index is built once per session with the product's own salt-idx (device backend).  Size-independent properties on the full
+batches: a simulated read maps to the position it was drawn from (mapped fraction and exact-position fraction)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def _workload(name, tmp):
+    import torch
+    import salt_amd
+    from salt_amd import workload
+    dev = torch.device("cuda", 0)
+    g, p, m = workload.generate_device(name, dev)
+    w = workload.prepare(name, str(tmp), gpu_device=0, arrays=(g, p, m))
+    return dict(w=w, genome=g, pos=p, mask=m, site=workload.make_site_map(g.numel(), p, m))
+
+
+@pytest.fixture(scope="module")
+def chr21(tmp_path_factory):
+    return _workload("chr21", tmp_path_factory.mktemp("chr21"))
+
+
+@pytest.fixture(scope="module")
+def grch38(tmp_path_factory):
+    d = _workload("grch38", tmp_path_factory.mktemp("grch38"))
+    yield d
+    for f in os.listdir(d["w"]["dir"]):                    # 6 GB of index files
+        os.unlink(os.path.join(d["w"]["dir"], f))
+
+
+def _se_parity(d, n_reads, seed, threads=64):
+    import salt_amd
+    import oracle_py
+    from salt_amd import workload
+    w = d["w"]
+    seqs, offs, start, rev = workload.make_reads_hash(d["genome"], d["site"], n_reads, 100, seed=seed, batch=0)
+    hs, ho = seqs.cpu().numpy(), offs.cpu().numpy().view(np.uint32)
+    idx = salt_amd.Index.reload(w["prefix"], rebuild_lkt=False)
+    aln = salt_amd.GpuAligner(idx, device=0, max_reads=n_reads, max_bases=n_reads * 100)
+    opt = salt_amd.AlnOpt(l_seed=w["k"])
+    res = aln.alnse_core1(opt, hs, ho).copy()
+    aln.close()
+    idx.destroy()
+    ora = oracle_py.Oracle(w["prefix"])
+    want = ora.align(ora.opt(), hs, ho, n_threads=min(os.cpu_count() or 1, threads))
+    ora.close()
+    bad = oracle_py.compare(res, want)
+    mapped = res["pos"] != 0xFFFFFFFF
+    exact = mapped & (res["pos"].astype(np.int64) == start.cpu().numpy())
+    return bad, float(mapped.mean()), float(exact.mean()), res, want
+
+
+def _pe_parity(d, n_pairs, seed):
+    import salt_amd
+    import oracle_py
+    from salt_amd import workload
+    w = d["w"]
+    g, p, m = d["genome"].cpu().numpy(), d["pos"].cpu().numpy(), d["mask"].cpu().numpy()
+    seqs, offs, _, _ = workload.make_pairs(g, p, m, n_pairs, 150, seed=seed, insert_mean=400, insert_sd=50, damaged=0.03, orphan=0.01)
+    idx = salt_amd.Index.reload(w["prefix"], rebuild_lkt=False)
+    opt, _ = salt_amd.AlnOpt.from_argv(["-p", "-a", "250", "-b", "550"], idx.l_seed)
+    aln = salt_amd.GpuAligner(idx, device=0, max_reads=2 * n_pairs, max_bases=2 * n_pairs * 150)
+    res = aln.alnpe_core1(opt, idx, seqs, offs).copy()
+    aln.close()
+    idx.destroy()
+    ora = oracle_py.Oracle(w["prefix"])
+    oo = ora.opt(l_overlap=opt.l_overlap, max_seed=opt.max_seed, max_locate=opt.max_locate, seed_only_ref=opt.seed_only_ref)
+    want = ora.align_pe(oo, seqs, offs, opt.min_tlen, opt.max_tlen, n_threads=min(os.cpu_count() or 1, 64))
+    ora.close()
+    bad = oracle_py.compare(res, want, pe=True)
+    rescued = int(((want["seq_start"] != 0) | (want["seq_end"] != 149)).sum())
+    return bad, float((res["pos"] != 0xFFFFFFFF).mean()), rescued, res, want
+
+
+def _detail(bad, res, want):
+    return [(int(i), [(f, res[f][i].tolist(), want[f][i].tolist()) for f in ("pos", "strand", "n_diff", "is_gap", "mapq", "b0", "b1")]) for i in bad[:4]]
+
+
+def test_config2_chr21_whole_se_batch_equals_the_oracle(chr21):
+    bad, mapped, exact, res, want = _se_parity(chr21, 1_000_000, seed=1)
+    assert len(bad) == 0, (len(bad), _detail(bad, res, want))
+    assert mapped > 0.995 and exact > 0.99, (mapped, exact)
+
+
+def test_config4_shape_on_chr21_pairs_equal_the_oracle(chr21):
+    bad, mapped, rescued, res, want = _pe_parity(chr21, 60_000, seed=3)
+    assert len(bad) == 0, (len(bad), _detail(bad, res, want))
+    assert mapped > 0.97 and rescued > 500, (mapped, rescued)
+
+
+def test_config3_grch38_scale_se_reads_equal_the_oracle(grch38):
+    """3.1e9 bases: suffix-array rows and positions beyond 2^31, a 12 GB suffix array and a 64 GiB k-mer table on the device, 24
+    contigs; the index was built a moment ago by the device suffix sorter."""
+    bad, mapped, exact, res, want = _se_parity(grch38, 200_000, seed=2)
+    assert len(bad) == 0, (len(bad), _detail(bad, res, want))
+    assert mapped > 0.995 and exact > 0.99, (mapped, exact)
+    assert int((res["pos"][res["pos"] != 0xFFFFFFFF] > 2**31).sum()) > 10_000        # positions in the upper half of the u32 range are exercised
+
+
+def test_config4_grch38_scale_pairs_equal_the_oracle(grch38):
+    bad, mapped, rescued, res, want = _pe_parity(grch38, 20_000, seed=4)
+    assert len(bad) == 0, (len(bad), _detail(bad, res, want))
+    assert mapped > 0.97 and rescued > 150, (mapped, rescued)
