@@ -384,11 +384,25 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
                 for (uint32_t t = 0; t < W; ++t) { has_n |= seed_is_n(c, a0 + t); x = (x << 2) | seed_base2(c, a0 + t); }
             }
             if (!has_n) {
-                const uint4 v = ix.wlkt[x];                  // one 16-byte gather: C interval in .x/.y, R interval in .z/.w
+                const uint4 v = ix.wlkt[2 * (uint64_t)x];    // one 32-byte gather (one sector): C interval in .x/.y, R interval in .z/.w,
+                const uint4 u = ix.wlkt[2 * (uint64_t)x + 1];//   and for a one-row C interval its genome position + the 16 bases in front of it
                 ++n_lkt;                                     // device counters: bits 0..9 W-mer gathers, 10..20 SA loads, 21..31 text loads
                 const int i_top = (int)(c.k - W) - 1;        // head bases s .. s+i_top are still to consume
                 if (v.x <= v.y) {
-                    if ((v.x == v.y && c.inreg && sp.resolve_unique) || i_top < 0) oc = seed_c_rest(ix, sp, c, v.x, v.y, i_top, n_occ_c, n_lkt);   // no walk left (or only the extension)
+                    const uint32_t m = c.k - W;
+                    if (v.x == v.y && c.inreg && sp.resolve_unique && m >= 1 && m <= 16) {
+                        // one row: the search succeeds iff the m bases in front of the W-mer equal the text in front of that suffix
+                        // (what the remaining steps of bwt_match_exact_alt, bwt.c:281-309, decide) -- both are in registers
+                        const uint32_t rel = c.s - (c.wb << 4), rr = rel & 15u;
+                        const uint64_t vr = rel < 16 ? (((uint64_t)c.w0 << 32) | c.w1) : (((uint64_t)c.w1 << 32) | c.w2);
+                        const uint32_t mk = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+                        const uint32_t xr = (uint32_t)(vr >> (64 - 2 * rr - 2 * m)) & mk;
+                        const uint32_t reln2 = c.s - (c.nb << 5);
+                        const uint64_t vn2 = ((uint64_t)c.n0 << 32) | c.n1;
+                        const bool head_n = ((vn2 >> (64 - reln2 - m)) & ((1ull << m) - 1ull)) != 0;
+                        if (!head_n && u.x >= m && xr == (u.y & mk)) oc = make_uint4(u.x - m, u.x - m, c.s, 2);
+                    }
+                    else if ((v.x == v.y && c.inreg && sp.resolve_unique) || i_top < 0) oc = seed_c_rest(ix, sp, c, v.x, v.y, i_top, n_occ_c, n_lkt);   // no walk left (or only the extension)
                     else { pend_c = true; pk_c = v.x; pl_c = v.y; }
                 }
                 if (!sp.seed_only_ref) {
@@ -791,6 +805,73 @@ __device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, u
             if (c0 + CPW * g >= n) break;
             const uint32_t mism = quad_mismatch<LN>(x[g], pos[g], pmw, nvalid);
             if (act[g] && sub == 0) out[c0 + CPW * g + q] = (uint8_t)((mism > 3 || pos[g] == 0xFFFFFFFFu) ? INF : mism);
+        }
+    }
+}
+
+// ---- masked Hamming distance from ALIGNED 64-byte sectors, second sector on demand (k_heavy) ------------------------------
+// A 100-base window of 4-bit masks is 50 bytes at an arbitrary offset: 1.8 sectors on average.  The candidates k_heavy verifies are
+// mostly wrong copies of a repeat (hundreds per read) that fail within a few dozen bases, and at GRCh38 scale every sector is an HBM
+// access (the kernel runs at ~80 % of the machine's random-sector rate, profiles/r02): so the four lanes of a candidate fetch the
+// sector that holds the window's start (aligned 16-byte loads), count the mismatches of the bases inside it, and only candidates still
+// within the cap fetch the next sector.  Exact: a candidate is dropped only when its partial count already exceeds the cap.
+// mismatches of the window bases that lie in the four reference words gw0 .. gw0+3 held by this lane (x), for the window at `pos`
+__device__ __forceinline__ uint32_t sector_part_mismatch(const u32x4_a4 x, const uint32_t gw0, const uint32_t pos, const uint32_t *pm, const uint32_t L, const uint32_t nw)
+{
+    const uint32_t w0 = pos >> 3, p7 = pos & 7u, sh = p7 * 4u;
+    const uint32_t xs[4] = { x.x, x.y, x.z, x.w };
+    uint32_t mism = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int rel = (int)(gw0 + (uint32_t)t) - (int)w0;                 // reference word `rel` of the window
+        const int b_lo = rel * 8 - (int)p7;                                 // read base under its nibble 0
+        int lo = b_lo < 0 ? 0 : b_lo, hi = b_lo + 8 > (int)L ? (int)L : b_lo + 8;
+        if (rel < 0 || hi <= lo) continue;
+        const uint32_t cur = (uint32_t)rel < nw ? pm[rel] : 0u, prv = (rel >= 1 && (uint32_t)(rel - 1) < nw) ? pm[rel - 1] : 0u;
+        const uint32_t rd = sh ? ((cur << sh) | (prv >> (32u - sh))) : cur;   // the read's one-hot nibbles under this reference word
+        const uint32_t y = xs[t] & rd;
+        const uint32_t match = (uint32_t)__popc((((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u);
+        mism += (uint32_t)(hi - lo) - match;
+    }
+    return mism;
+}
+template <int G>
+__device__ __forceinline__ void verify_sectors(const uint32_t *__restrict__ ref, uint32_t ref_len, const uint32_t *pm, uint32_t L,
+                                               const uint32_t *cand, uint32_t n, uint8_t *out)
+{
+    const uint32_t lane = lane_id(), sub = lane & 3u, q = lane >> 2;
+    const uint32_t nw = (L + 7) >> 3;
+    for (uint32_t c0 = 0; c0 < n; c0 += 16u * G) {
+        uint32_t pos[G], part[G]; u32x4_a4 x[G]; bool act[G], more[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (c0 + 16u * g >= n) break;
+            const uint32_t c = c0 + 16u * g + q;
+            act[g] = c < n;
+            pos[g] = act[g] ? cand[c] : 0xFFFFFFFFu;
+            if (pos[g] >= ref_len) pos[g] = 0xFFFFFFFFu;                 // wrapped below 0 (see mismatch_capped): no load, INF
+            const uint32_t sb = ((pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) & ~15u;
+            x[g] = *reinterpret_cast<const u32x4_a4 *>(ref + sb + 4 * sub);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (c0 + 16u * g >= n) break;
+            const uint32_t sb = ((pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) & ~15u;
+            uint32_t m1 = pos[g] == 0xFFFFFFFFu ? 0u : sector_part_mismatch(x[g], sb + 4 * sub, pos[g], pm, L, nw);
+            m1 += (uint32_t)__shfl_xor((int)m1, 1); m1 += (uint32_t)__shfl_xor((int)m1, 2);
+            part[g] = m1;
+            const uint32_t w_end = (pos[g] >> 3) + (((pos[g] & 7u) + L + 7u) >> 3);      // one past the window's last word
+            more[g] = pos[g] != 0xFFFFFFFFu && m1 <= 3u && w_end > sb + 16u;
+            if (more[g]) x[g] = *reinterpret_cast<const u32x4_a4 *>(ref + sb + 16u + 4 * sub);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (c0 + 16u * g >= n) break;
+            const uint32_t sb = ((pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) & ~15u;
+            uint32_t m2 = more[g] ? sector_part_mismatch(x[g], sb + 16u + 4 * sub, pos[g], pm, L, nw) : 0u;
+            m2 += (uint32_t)__shfl_xor((int)m2, 1); m2 += (uint32_t)__shfl_xor((int)m2, 2);
+            const uint32_t mism = part[g] + m2;
+            if (act[g] && sub == 0) out[c0 + 16u * g + q] = (uint8_t)((mism > 3 || pos[g] == 0xFFFFFFFFu) ? INF : mism);
         }
     }
 }
@@ -1263,7 +1344,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         const uint32_t n_loc = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
         uint32_t call_best_n = INF, call_best_pos = 0;
         auto verify_all = [&](uint32_t n) {                   // cand_e[i] = min(mismatches, INF) of loci[i], loads of 128 candidates in flight
-            if (L <= 120) verify_quads<8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
+            if (L <= 120) verify_sectors<8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
             else if (L <= 248) verify_quads<8, 8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
             else for (uint32_t i = lane; i < n; i += 64) cand_e[i] = (uint8_t)mismatch_capped(ix, w.pm[strand], L, loci[i]);
             WSYNC();
@@ -2392,6 +2473,7 @@ k_diag_verify(const uint32_t *__restrict__ ref, uint32_t ref_len, uint32_t n_cas
     if (mode == 0) { for (uint32_t i = lane; i < n; i += 64) val[i] = (uint8_t)mismatch_capped(ix, pm, L, loci[i]); }
     else if (mode == 1) verify_quads<8>(ref, ref_len, pm, L, loci, n, val);
     else if (mode == 2) verify_quads<8, 8>(ref, ref_len, pm, L, loci, n, val);
+    else if (mode == 5) verify_sectors<8>(ref, ref_len, pm, L, loci, n, val);
     else if (mode == 3) verify_quads_2(ref, ref_len, pm, pm, L, loci, n / 2, loci + n / 2, n - n / 2, val, val + n / 2);
     else verify_quads_2<8>(ref, ref_len, pm, pm, L, loci, n / 2, loci + n / 2, n - n / 2, val, val + n / 2);
     WSYNC();

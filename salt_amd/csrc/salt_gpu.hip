@@ -100,12 +100,12 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     hd.lkt_len = h->lkt_len; hd.lkt_n = h->lkt_n;
     hd.r_text_len = h->r_text_len; hd.r_inv_sa0 = h->r_inv_sa0; memcpy(hd.r_cum, h->r_cum, sizeof hd.r_cum);
     hd.ref_len = h->ref_len;
-    {   // width of the device k-mer table: 16 B x 4^W (14: 4 GiB, 15: 16 GiB, 16: 64 GiB).  Every extra base saves each seed
-        // one C and one R backward-search step (k_seed: -9 % per base), so the widest table that leaves most of the HBM free
-        // is taken: W = 16 on a 288 GB MI355X.
+    {   // width of the device k-mer table: 32 B x 4^W (14: 8 GiB, 15: 32 GiB, 16: 128 GiB).  Every extra base saves each seed
+        // one C and one R backward-search step (k_seed: -9 % per base) and makes more C intervals one row wide, which the entry then
+        // resolves by itself, so the widest table that leaves room for the rest is taken: W = 16 on a 288 GB MI355X.
         uint32_t w = 14;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) w = free_b >= (176ull << 30) ? 16 : free_b >= (48ull << 30) ? 15 : 14;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) w = free_b >= (200ull << 30) ? 16 : free_b >= (72ull << 30) ? 15 : 14;
         if (const char *e = getenv("SALT_GPU_LKT_LEN")) w = (uint32_t)atoi(e);
         if (h->l_seed > 0 && w > (uint32_t)h->l_seed) w = (uint32_t)h->l_seed;
         if (h->l_seed <= 0) w = h->lkt_len;
@@ -125,7 +125,7 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     hd.off_ref = off;   off = align_up(off + (ref_words + 4) * 4, 256);
     hd.off_text = off;  off = align_up(off + ((uint64_t)h->c_seq_len / 16 + 4) * 4, 256);
     // last: everything before it is the COMPACT image, from which the W-mer table can be rebuilt on any device
-    hd.off_wlkt = off; off = align_up(off + (1ull << (2 * hd.r_lkt_len)) * 16, 256);
+    hd.off_wlkt = off; off = align_up(off + (1ull << (2 * hd.r_lkt_len)) * 32, 256);
     hd.bytes = off;
     ix->bytes = off;
 
@@ -702,14 +702,14 @@ extern "C" int salt_gpu_diag_verify(const uint32_t *ref_words, uint32_t ref_len,
                                     const uint32_t *cand, const uint32_t *cand_offs, int mode, uint8_t *out)
 {
     if (!ref_words || !seqs || !offs || !cand || !cand_offs || !out) return fail(SALT_E_INVAL, "null argument");
-    if (mode < 0 || mode > 4) return fail(SALT_E_INVAL, "mode must be 0..4");
+    if (mode < 0 || mode > 5) return fail(SALT_E_INVAL, "mode must be 0..5");
     if (n_cases == 0) return SALT_OK;
     int n_dev = 0;
     HIPCHK(hipGetDeviceCount(&n_dev));
     if (n_dev <= 0) return fail(SALT_E_HIP, "no HIP device visible");
     for (uint32_t i = 0; i < n_cases; ++i) {
         const uint32_t L = offs[i + 1] - offs[i];
-        if (L == 0 || L > SALT_MAX_READ_LEN || ((mode == 1 || mode == 3) && L > 120) || ((mode == 2 || mode == 4) && L > 248)) return fail(SALT_E_INVAL, "read length outside the verifier's range");
+        if (L == 0 || L > SALT_MAX_READ_LEN || ((mode == 1 || mode == 3 || mode == 5) && L > 120) || ((mode == 2 || mode == 4) && L > 248)) return fail(SALT_E_INVAL, "read length outside the verifier's range");
         if (cand_offs[i + 1] - cand_offs[i] > 256) return fail(SALT_E_INVAL, "at most 256 candidates per case");
     }
     const uint64_t nw = ((uint64_t)ref_len + 7) / 8 + 36, bases = offs[n_cases], nc = cand_offs[n_cases];

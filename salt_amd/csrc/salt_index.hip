@@ -154,10 +154,13 @@ k_build_r_pos(IndexView ix, const uint32_t *__restrict__ r_sa, uint32_t *__restr
     }
 }
 
-// One entry per W-mer x (first base in the high bits): the C interval after LKT_lookup_sa on the last lkt_len bases
-// + bwt_match_exact_alt on the W - lkt_len bases before them (lookup.h:39-53, bwt.c:281-309) in .x/.y, and the R
-// interval after the first W steps of Rbwt_exact_match_backward from (0, textLength) (rbwt.c:619-648) in .z/.w;
-// (1, 0) = empty.  One 16-byte gather serves both searches of a seed.
+// One 32-byte entry (two uint4) per W-mer x (first base in the high bits).  First half: the C interval after LKT_lookup_sa on the last
+// lkt_len bases + bwt_match_exact_alt on the W - lkt_len bases before them (lookup.h:39-53, bwt.c:281-309) in .x/.y, and the R interval
+// after the first W steps of Rbwt_exact_match_backward from (0, textLength) (rbwt.c:619-648) in .z/.w; (1, 0) = empty.  Second half,
+// for a C interval of ONE row (the usual case at W = 16): .x = the genome position of that suffix and .y = the 16 bases in front of
+// it (2 bits each, the base right in front of the suffix in the lowest bits) -- so k_seed finishes such a seed (the remaining k - W
+// bases must equal the text in front of the suffix, the rest of bwt_match_exact_alt cannot branch any more) from this one gather,
+// without touching the suffix array or the text.
 __global__ void __launch_bounds__(256)
 k_build_wlkt(IndexView ix, uint32_t len, uint4 *__restrict__ out)
 {
@@ -177,10 +180,21 @@ k_build_wlkt(IndexView ix, uint32_t len, uint4 *__restrict__ out)
             k0 = ix.r_cum[c] + r_occ(ix, k0, c) + 1;
             l0 = ix.r_cum[c] + r_occ(ix, l0 + 1, c);
         }
-        uint4 e = make_uint4(1u, 0u, 1u, 0u);
+        uint4 e = make_uint4(1u, 0u, 1u, 0u), f = make_uint4(0u, 0u, 0u, 0u);
         if (k <= l) { e.x = k; e.y = l; }
         if (k0 <= l0) { e.z = k0; e.w = l0; }
-        out[x] = e;
+        if (k == l) {
+            uint32_t p0 = ix.c_sa[k];
+            if (p0 == 0xFFFFFFFFu) p0 = ix.c_seq_len;          // row 0: the empty suffix (bwt_sa's sa[0] = -1)
+            uint32_t prev = 0;
+            if (p0 >= 16) {
+                const uint32_t t0 = p0 - 16, tj = t0 >> 4, tr = t0 & 15u;
+                const uint64_t vt = ((uint64_t)ix.text[tj] << 32) | ix.text[tj + 1];
+                prev = (uint32_t)(vt >> (32 - 2 * tr));
+            } else if (p0 > 0) prev = ix.text[0] >> (32 - 2 * p0);
+            f.x = p0; f.y = prev;
+        }
+        out[2 * x] = e; out[2 * x + 1] = f;
     }
 }
 
