@@ -126,6 +126,7 @@ def main():
         t0 = time.time()
         idx = salt_amd.Index.reload(w["prefix"], rebuild_lkt=False)
         stages["load_files"] = round(time.time() - t0, 2)
+        torch.cuda.empty_cache()                             # the generators' temporaries: the device image sizes its k-mer table by what is free
         t0 = time.time()
         aln = salt_amd.GpuAligner(idx, device=local_rank, max_reads=n_reads, max_bases=n_reads * L)
         torch.cuda.synchronize()

@@ -14,6 +14,13 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+    # torch must initialise its HIP context before libsalt_gpu.so touches the device, whatever order the test files run in
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 def read_cases():
