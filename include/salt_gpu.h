@@ -204,8 +204,7 @@ int  salt_gpu_diag_rule(uint32_t n_cases, const uint32_t *pos, const uint8_t *va
 
 /* Unit entry of the candidate verifiers (tests): case i = read seqs[offs[i]..offs[i+1]) against candidates
  * cand[cand_offs[i]..cand_offs[i+1]) (<= 256) on the 4-bit mixRef `ref_words`; mode 0 = one candidate per lane, 1 / 2 = four / eight lanes
- * per candidate (reads <= 120 / 248 bases), 3 / 4 = the two-strand variants of 1 / 2; 5..9 = modes 0..4 reading from the sixteen
- * staggered mixRef copies the device image holds (every window starts on a 64-byte sector boundary).  out[j] = masked Hamming distance 0..3 of candidate
+ * per candidate (reads <= 120 / 248 bases), 3 / 4 = the two-strand variants of 1 / 2.  out[j] = masked Hamming distance 0..3 of candidate
  * j or 255 (more, or a candidate at or beyond ref_len -- a locate that wrapped below 0, alnse.c:672-673,762 -- which must never be
  * dereferenced).  Mirrors ed_mismatch (editdistance.c:88-163) under code_kmismatch's cap (alnse.c:348-369). */
 int  salt_gpu_diag_verify(const uint32_t *ref_words, uint32_t ref_len, uint32_t n_cases, const uint8_t *seqs, const uint32_t *offs,

@@ -753,17 +753,6 @@ __device__ __forceinline__ uint32_t mismatch_capped(const IndexView &ix, const u
 // Needs (L+7)/8 + 1 <= 16 words, i.e. L <= 120.  Writes min(count, INF) for candidates [0, n) to out[].
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
-// Where a candidate's window is read from.  A 100-base window of 4-bit masks is 50 bytes at an arbitrary offset: 1.8 sectors of 64
-// bytes on average, and at GRCh38 scale every sector is an HBM access (the align step runs at ~87 % of the machine's random-sector
-// rate, profiles/r02).  The device image therefore holds the mixRef SIXTEEN times, copy c shifted by c words (25 GB of the 288):
-// the window that starts at word w0 is read from copy (16 - w0 % 16) % 16, where it starts on a sector boundary -- every verify of a
-// read of up to 120 bases is one aligned 64-byte sector (two for up to 248).  stride = 0: no copies (unit entries on a caller's mixRef).
-__device__ __forceinline__ const uint32_t *stag_words(const uint32_t *__restrict__ refs, const uint32_t stride, const uint32_t w0)
-{
-    const uint32_t c = stride ? ((16u - (w0 & 15u)) & 15u) : 0u;
-    return refs + (uint64_t)c * stride + w0 + c;
-}
-
 // mismatches of one candidate, computed by its 4 lanes (sub = 0..3 holds words 4*sub..4*sub+3 of the window).
 // pmw: the read's one-hot words of this lane (zero past the read's end), nvalid: bases of the read inside them.
 // A base matches when (reference mask & one-hot) != 0 (ed_mismatch, editdistance.c:88-163); matches are counted
@@ -790,7 +779,7 @@ __device__ __forceinline__ uint32_t quad_mismatch(const u32x4_a4 x, const uint32
 }
 
 template <int G, int LN = 4>                                             // groups of 64 / LN candidates whose loads are in flight together
-__device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ refs, uint32_t stride, uint32_t ref_len, const uint32_t *pm, uint32_t L,
+__device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, uint32_t ref_len, const uint32_t *pm, uint32_t L,
                                              const uint32_t *cand, uint32_t n, uint8_t *out)
 {
     constexpr uint32_t CPW = 64u / LN;                                   // candidates per wave-wide load
@@ -809,7 +798,7 @@ __device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ refs, 
             act[g] = c < n;
             pos[g] = act[g] ? cand[c] : 0u;
             if (pos[g] >= ref_len) pos[g] = 0xFFFFFFFFu;                 // wrapped below 0 (see mismatch_capped): no load, INF
-            x[g] = *reinterpret_cast<const u32x4_a4 *>(stag_words(refs, stride, (pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) + 4 * sub);
+            x[g] = *reinterpret_cast<const u32x4_a4 *>(ref + ((pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) + 4 * sub);
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -822,7 +811,7 @@ __device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ refs, 
 
 // Both strands of one read in the same trips (k_light): candidates c0[0..n0) use pm0, c1[0..n1) use pm1.
 template <int LN = 4>
-__device__ __forceinline__ void verify_quads_2(const uint32_t *__restrict__ refs, uint32_t stride, uint32_t ref_len, const uint32_t *pm0, const uint32_t *pm1, uint32_t L,
+__device__ __forceinline__ void verify_quads_2(const uint32_t *__restrict__ ref, uint32_t ref_len, const uint32_t *pm0, const uint32_t *pm1, uint32_t L,
                                                const uint32_t *c0, uint32_t n0, const uint32_t *c1, uint32_t n1, uint8_t *o0, uint8_t *o1)
 {
     constexpr uint32_t CPW = 64u / LN;
@@ -841,7 +830,7 @@ __device__ __forceinline__ void verify_quads_2(const uint32_t *__restrict__ refs
             act[g] = c < n; rev[g] = c >= n0;
             pos[g] = act[g] ? (rev[g] ? c1[c - n0] : c0[c]) : 0u;
             if (pos[g] >= ref_len) pos[g] = 0xFFFFFFFFu;
-            x[g] = *reinterpret_cast<const u32x4_a4 *>(stag_words(refs, stride, (pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) + 4 * sub);
+            x[g] = *reinterpret_cast<const u32x4_a4 *>(ref + ((pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) + 4 * sub);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1288,8 +1277,8 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         const uint32_t n_loc = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
         uint32_t call_best_n = INF, call_best_pos = 0;
         auto verify_all = [&](uint32_t n) {                   // cand_e[i] = min(mismatches, INF) of loci[i], loads of 128 candidates in flight
-            if (L <= 120) verify_quads<8>(ix.refs, ix.ref_stride, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
-            else if (L <= 248) verify_quads<8, 8>(ix.refs, ix.ref_stride, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
+            if (L <= 120) verify_quads<8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
+            else if (L <= 248) verify_quads<8, 8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
             else for (uint32_t i = lane; i < n; i += 64) cand_e[i] = (uint8_t)mismatch_capped(ix, w.pm[strand], L, loci[i]);
             WSYNC();
         };
@@ -1853,8 +1842,8 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
             uint32_t n_hits_s[2] = { 0, 0 }, a0[2] = { 0, 0 };
             bool found[2] = { false, false };
             {
-                if (L <= 120) verify_quads_2(ix.refs, ix.ref_stride, ix.ref_len, w.pm[0], w.pm[1], L, w.loci[0], n_s[0], w.loci[1], n_s[1], w.val[0], w.val[1]);
-                else if (L <= 248) verify_quads_2<8>(ix.refs, ix.ref_stride, ix.ref_len, w.pm[0], w.pm[1], L, w.loci[0], n_s[0], w.loci[1], n_s[1], w.val[0], w.val[1]);
+                if (L <= 120) verify_quads_2(ix.ref, ix.ref_len, w.pm[0], w.pm[1], L, w.loci[0], n_s[0], w.loci[1], n_s[1], w.val[0], w.val[1]);
+                else if (L <= 248) verify_quads_2<8>(ix.ref, ix.ref_len, w.pm[0], w.pm[1], L, w.loci[0], n_s[0], w.loci[1], n_s[1], w.val[0], w.val[1]);
                 else
                     for (int s = 0; s < 2; ++s)
                         for (uint32_t i = lane; i < n_s[s]; i += 64) w.val[s][i] = (uint8_t)mismatch_capped(ix, w.pm[s], L, w.loci[s][i]);
@@ -2139,7 +2128,7 @@ k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
                         act[g] = c < n; rev[g] = c >= n_s[0];
                         pos[g] = act[g] ? (rev[g] ? w.loci[1][c - n_s[0]] : w.loci[0][c]) : 0u;
                         if (pos[g] >= ix.ref_len) pos[g] = 0xFFFFFFFFu;      // wrapped below 0 (see mismatch_capped): no load, INF
-                        x[g] = *reinterpret_cast<const u32x4_a4 *>(stag_words(ix.refs, ix.ref_stride, (pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) + 4 * sub);
+                        x[g] = *reinterpret_cast<const u32x4_a4 *>(ix.ref + ((pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) + 4 * sub);
                     }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -2388,10 +2377,10 @@ void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const 
 // k_diag_verify: unit access to the candidate verifiers (tests only).  One wave per case: the read seqs[offs[c]..offs[c+1]) against
 // candidates cand[coffs[c]..coffs[c+1]) (at most 256) on the caller's mixRef.  mode 0: mismatch_capped per lane, 1: verify_quads<8>
 // (4 lanes per candidate, L <= 120), 2: verify_quads<8, 8> (L <= 248), 3 / 4: verify_quads_2<4> / <8> with the list split between the
-// "strands" (both use the same read); stride != 0: `ref` holds the sixteen staggered copies (stag_words).  out[i] = 0..3 or 255.  Candidates >= ref_len (a locate that wrapped below 0, alnse.c:672-673) must
+// "strands" (both use the same read).  out[i] = 0..3 or 255.  Candidates >= ref_len (a locate that wrapped below 0, alnse.c:672-673) must
 // come back 255 WITHOUT being used as an address: the test's mixRef is a few KB, so a regression reads far outside of it only by value.
 __global__ void __launch_bounds__(64)
-k_diag_verify(const uint32_t *__restrict__ ref, uint32_t stride, uint32_t ref_len, uint32_t n_cases, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+k_diag_verify(const uint32_t *__restrict__ ref, uint32_t ref_len, uint32_t n_cases, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
               const uint32_t *__restrict__ cand, const uint32_t *__restrict__ coffs, int mode, uint8_t *__restrict__ out)
 {
     __shared__ uint32_t pm[64];
@@ -2415,17 +2404,17 @@ k_diag_verify(const uint32_t *__restrict__ ref, uint32_t stride, uint32_t ref_le
     WSYNC();
     IndexView ix; ix.ref = ref; ix.ref_len = ref_len;
     if (mode == 0) { for (uint32_t i = lane; i < n; i += 64) val[i] = (uint8_t)mismatch_capped(ix, pm, L, loci[i]); }
-    else if (mode == 1) verify_quads<8>(ref, stride, ref_len, pm, L, loci, n, val);
-    else if (mode == 2) verify_quads<8, 8>(ref, stride, ref_len, pm, L, loci, n, val);
-    else if (mode == 3) verify_quads_2(ref, stride, ref_len, pm, pm, L, loci, n / 2, loci + n / 2, n - n / 2, val, val + n / 2);
-    else verify_quads_2<8>(ref, stride, ref_len, pm, pm, L, loci, n / 2, loci + n / 2, n - n / 2, val, val + n / 2);
+    else if (mode == 1) verify_quads<8>(ref, ref_len, pm, L, loci, n, val);
+    else if (mode == 2) verify_quads<8, 8>(ref, ref_len, pm, L, loci, n, val);
+    else if (mode == 3) verify_quads_2(ref, ref_len, pm, pm, L, loci, n / 2, loci + n / 2, n - n / 2, val, val + n / 2);
+    else verify_quads_2<8>(ref, ref_len, pm, pm, L, loci, n / 2, loci + n / 2, n - n / 2, val, val + n / 2);
     WSYNC();
     for (uint32_t i = lane; i < n; i += 64) out[c0 + i] = val[i];
 }
-void launch_diag_verify(const uint32_t *ref, uint32_t stride, uint32_t ref_len, uint32_t n_cases, const uint8_t *seqs, const uint32_t *offs, const uint32_t *cand,
+void launch_diag_verify(const uint32_t *ref, uint32_t ref_len, uint32_t n_cases, const uint8_t *seqs, const uint32_t *offs, const uint32_t *cand,
                         const uint32_t *coffs, int mode, uint8_t *out, hipStream_t st)
 {
-    if (n_cases) hipLaunchKernelGGL(k_diag_verify, dim3(n_cases), dim3(64), 0, st, ref, stride, ref_len, n_cases, seqs, offs, cand, coffs, mode, out);
+    if (n_cases) hipLaunchKernelGGL(k_diag_verify, dim3(n_cases), dim3(64), 0, st, ref, ref_len, n_cases, seqs, offs, cand, coffs, mode, out);
 }
 
 // first 128 bytes of every result row, densely packed (what the host needs of nearly every row)

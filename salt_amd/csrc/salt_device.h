@@ -16,9 +16,7 @@
 //   text   the genome the C index was built over, 2 bits per base, 16 per word with the first base in the high bits
 //          (rebuilt at attach time from the expanded suffix array and the BWT: text[SA[row] - 1] = BWT[row]).  Once a seed's C
 //          interval is down to one row, the rest of its backward search is a comparison against this text.
-//   refs   sixteen copies of the mixRef, copy c shifted by c words: a candidate's window is read from the copy in which it starts on a
-//          64-byte sector boundary, so a verify of a read of up to 120 bases is ONE aligned sector instead of 1.8 (25 GB of the 288).
-//   wlkt   W-mer table, 32 B per W-mer (W = 12..16, default 14, never above the seed length): for every W-mer
+//   wlkt   W-mer table, 16 B per W-mer (W = 12..16, default 14, never above the seed length): for every W-mer
 //          the SA intervals both searches hold after consuming it (.x/.y = C, .z/.w = R; one gather serves both) -- C: LKT_lookup_sa on its last 12 bases
 //          (lookup.h:39-53, with that table's A-padded tail quirk) followed by W-12 steps of
 //          bwt_match_exact_alt (bwt.c:281-309); R: the first W iterations of Rbwt_exact_match_backward
@@ -44,8 +42,7 @@ struct ImageHeader {
     uint32_t ref_len, r_lkt_len;
     uint64_t off_c_occ, off_c_sa, off_lkt, off_r_occ, off_r_pos, off_wlkt, off_ref, off_text;
     uint64_t n_c_blocks, n_r_blocks;
-    uint64_t off_refs, ref_stride;      // sixteen staggered copies of the mixRef (behind the W-mer table; rebuilt on every device)
-    uint64_t reserved[5];
+    uint64_t reserved[7];
 };
 static const uint64_t IMAGE_MAGIC = 0x53414c5447465839ull;          // "SALTGFX9"
 
@@ -53,7 +50,6 @@ static const uint64_t IMAGE_MAGIC = 0x53414c5447465839ull;          // "SALTGFX9
 struct IndexView {
     const COcc *c_occ; const uint32_t *c_sa; const uint32_t *lkt;
     const ROcc *r_occ; const uint32_t *r_pos; const uint4 *wlkt; const uint32_t *ref; const uint32_t *text;
-    const uint32_t *refs; uint32_t ref_stride;      // staggered mixRef copies: copy c = the words shifted by c, at refs + c * ref_stride
     uint32_t c_primary, c_L2[5], c_seq_len;
     uint32_t r_text_len, r_inv_sa0, r_cum[6];
     uint32_t ref_len, lkt_len, r_lkt_len;

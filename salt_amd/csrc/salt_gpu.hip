@@ -70,7 +70,6 @@ static void make_view(salt_gpu_index *ix)
     v.wlkt = reinterpret_cast<const uint4 *>(b + h.off_wlkt);
     v.ref = reinterpret_cast<const uint32_t *>(b + h.off_ref);
     v.text = reinterpret_cast<const uint32_t *>(b + h.off_text);
-    v.refs = h.off_refs ? reinterpret_cast<const uint32_t *>(b + h.off_refs) : v.ref; v.ref_stride = (uint32_t)h.ref_stride;
     v.c_primary = h.c_primary; memcpy(v.c_L2, h.c_L2, sizeof v.c_L2); v.c_seq_len = h.c_seq_len;
     v.r_text_len = h.r_text_len; v.r_inv_sa0 = h.r_inv_sa0; memcpy(v.r_cum, h.r_cum, sizeof v.r_cum);
     v.ref_len = h.ref_len; v.lkt_len = h.lkt_len; v.r_lkt_len = h.r_lkt_len;
@@ -106,7 +105,7 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
         // resolves by itself, so the widest table that leaves room for the rest is taken: W = 16 on a 288 GB MI355X.
         uint32_t w = 14;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) w = free_b >= (215ull << 30) ? 16 : free_b >= (88ull << 30) ? 15 : 14;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) w = free_b >= (200ull << 30) ? 16 : free_b >= (72ull << 30) ? 15 : 14;
         if (const char *e = getenv("SALT_GPU_LKT_LEN")) w = (uint32_t)atoi(e);
         if (h->l_seed > 0 && w > (uint32_t)h->l_seed) w = (uint32_t)h->l_seed;
         if (h->l_seed <= 0) w = h->lkt_len;
@@ -127,8 +126,6 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     hd.off_text = off;  off = align_up(off + ((uint64_t)h->c_seq_len / 16 + 4) * 4, 256);
     // last: everything before it is the COMPACT image, from which the W-mer table can be rebuilt on any device
     hd.off_wlkt = off; off = align_up(off + (1ull << (2 * hd.r_lkt_len)) * 32, 256);
-    hd.ref_stride = align_up(ref_words + 64, 16);                     // words per staggered copy: sector aligned, room for the shift + the verify over-read
-    hd.off_refs = off; off = align_up(off + 16ull * hd.ref_stride * 4, 256);
     hd.bytes = off;
     ix->bytes = off;
 
@@ -179,7 +176,6 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     launch_build_r_pos(ix->view, d_r_sa, reinterpret_cast<uint32_t *>(ix->image + hd.off_r_pos), nullptr);
     launch_build_text(ix->view, reinterpret_cast<uint32_t *>(ix->image + hd.off_text), nullptr);       // after c_sa (same stream)
     launch_build_wlkt(ix->view, hd.r_lkt_len, reinterpret_cast<uint4 *>(ix->image + hd.off_wlkt), nullptr);
-    launch_build_refs(ix->view.ref, ref_words, (uint32_t)hd.ref_stride, reinterpret_cast<uint32_t *>(ix->image + hd.off_refs), nullptr);
     CHK2(hipGetLastError());
     CHK2(hipDeviceSynchronize());
     hipFree(d_sa_s); hipFree(d_r_sa);
@@ -228,7 +224,6 @@ extern "C" int salt_gpu_index_image_compact(const salt_gpu_index_t *ix, void **d
 static int rebuild_wlkt(salt_gpu_index *ix)
 {
     launch_build_wlkt(ix->view, ix->hdr.r_lkt_len, reinterpret_cast<uint4 *>(ix->image + ix->hdr.off_wlkt), nullptr);
-    launch_build_refs(ix->view.ref, ((uint64_t)ix->hdr.ref_len + 7) / 8, (uint32_t)ix->hdr.ref_stride, reinterpret_cast<uint32_t *>(ix->image + ix->hdr.off_refs), nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     return SALT_OK;
@@ -707,7 +702,7 @@ extern "C" int salt_gpu_diag_verify(const uint32_t *ref_words, uint32_t ref_len,
                                     const uint32_t *cand, const uint32_t *cand_offs, int mode, uint8_t *out)
 {
     if (!ref_words || !seqs || !offs || !cand || !cand_offs || !out) return fail(SALT_E_INVAL, "null argument");
-    if (mode < 0 || mode > 9) return fail(SALT_E_INVAL, "mode must be 0..9");
+    if (mode < 0 || mode > 4) return fail(SALT_E_INVAL, "mode must be 0..4");
     if (n_cases == 0) return SALT_OK;
     int n_dev = 0;
     HIPCHK(hipGetDeviceCount(&n_dev));
@@ -726,18 +721,11 @@ extern "C" int salt_gpu_diag_verify(const uint32_t *ref_words, uint32_t ref_len,
     HIPCHK(hipMalloc((void **)&d_cand, (nc + 1) * 4)); HIPCHK(hipMemcpy(d_cand, cand, nc * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void **)&d_seqs, bases + 64)); HIPCHK(hipMemcpy(d_seqs, seqs, bases, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void **)&d_out, nc + 1));
-    uint32_t *d_stag = nullptr; uint32_t stride = 0;
-    if (mode >= 5) {                                            // the same verifiers reading from the sixteen staggered copies
-        stride = (uint32_t)align_up(nw + 32, 16);
-        HIPCHK(hipMalloc((void **)&d_stag, 16ull * stride * 4));
-        launch_build_refs(d_ref, nw - 36, stride, d_stag, nullptr);
-        mode -= 5;
-    }
-    launch_diag_verify(d_stag ? d_stag : d_ref, stride, ref_len, n_cases, d_seqs, d_offs, d_cand, d_coffs, mode, d_out, nullptr);
+    launch_diag_verify(d_ref, ref_len, n_cases, d_seqs, d_offs, d_cand, d_coffs, mode, d_out, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, d_out, nc, hipMemcpyDeviceToHost));
-    hipFree(d_ref); hipFree(d_offs); hipFree(d_coffs); hipFree(d_cand); hipFree(d_seqs); hipFree(d_out); hipFree(d_stag);
+    hipFree(d_ref); hipFree(d_offs); hipFree(d_coffs); hipFree(d_cand); hipFree(d_seqs); hipFree(d_out);
     return SALT_OK;
 }
 

@@ -198,21 +198,6 @@ k_build_wlkt(IndexView ix, uint32_t len, uint4 *__restrict__ out)
     }
 }
 
-// copy c of the mixRef = its words shifted by c (zero filled): out[c * stride + w] = ref[w - c]
-__global__ void __launch_bounds__(256)
-k_build_refs(const uint32_t *__restrict__ ref, uint64_t ref_words, uint32_t stride, uint32_t *__restrict__ out)
-{
-    const uint64_t n = 16ull * stride, st = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
-        const uint64_t c = i / stride, w = i % stride;
-        out[i] = (w >= c && w - c < ref_words) ? ref[w - c] : 0u;
-    }
-}
-void launch_build_refs(const uint32_t *ref, uint64_t ref_words, uint32_t stride, uint32_t *out, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_build_refs, dim3(stride_grid(16ull * stride)), dim3(256), 0, st, ref, ref_words, stride, out);
-}
-
 void launch_build_wlkt(const IndexView &ix, uint32_t len, uint4 *out, hipStream_t st)
 {
     uint64_t n = 1ull << (2 * len), blocks = (n + 255) / 256;

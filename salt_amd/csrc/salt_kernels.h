@@ -99,7 +99,7 @@ void launch_heads(const salt_result_t *res, uint32_t n, uint8_t *heads, hipStrea
 void launch_diag_rule(uint32_t n_cases, const uint32_t *pos, const uint8_t *val, const uint32_t *offs, const uint32_t *bound_in,
                       uint32_t L, uint32_t ref_len, int mode, uint32_t *out, hipStream_t st);
 uint32_t diag_rule_words();
-void launch_diag_verify(const uint32_t *ref, uint32_t stride, uint32_t ref_len, uint32_t n_cases, const uint8_t *seqs, const uint32_t *offs, const uint32_t *cand,
+void launch_diag_verify(const uint32_t *ref, uint32_t ref_len, uint32_t n_cases, const uint8_t *seqs, const uint32_t *offs, const uint32_t *cand,
                         const uint32_t *coffs, int mode, uint8_t *out, hipStream_t st);
 void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const uint32_t *kdiff, const uint8_t *seqs,
                     const uint32_t *offs, int32_t *out, uint16_t *cig, void *lvtab, hipStream_t st);
@@ -112,6 +112,5 @@ void launch_build_c_sa(const IndexView &ix, const uint32_t *sa_sampled, uint32_t
 void launch_build_r_pos(const IndexView &ix, const uint32_t *r_sa, uint32_t *out, hipStream_t st);
 void launch_build_text(const IndexView &ix, uint32_t *out, hipStream_t st);
 void launch_build_wlkt(const IndexView &ix, uint32_t len, uint4 *out, hipStream_t st);
-void launch_build_refs(const uint32_t *ref, uint64_t ref_words, uint32_t stride, uint32_t *out, hipStream_t st);    // the 16 staggered mixRef copies
 
 } // namespace salt

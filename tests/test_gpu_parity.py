@@ -273,7 +273,7 @@ def test_gpu_one_workspace_takes_batches_of_growing_read_length():
     ora.close(); aln.close(); idx.destroy()
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_gpu_verifiers_never_dereference_a_wrapped_locate(mode):
     """Candidates at or beyond mixRef.l -- `pos - offset` that wrapped below 0 passes the reference's range check (alnse.c:672-673)
     and is only dropped by the candidate rule (alnse.c:762) -- must come back as "no hit" from every verifier without being used as an
@@ -291,8 +291,8 @@ def test_gpu_verifiers_never_dereference_a_wrapped_locate(mode):
     for q in range(8):
         m = masks[q::8]
         words[:len(m)] |= m << np.uint32(4 * q)
-    Ls = [100, 120, 37, 8, 64] if mode % 5 in (0, 1, 3) else [150, 248, 121]
-    if mode % 5 == 0:
+    Ls = [100, 120, 37, 8, 64] if mode in (0, 1, 3) else [150, 248, 121]
+    if mode == 0:
         Ls += [300]
     reads, cands, coffs, want = [], [], [0], []
     for L in Ls * 8:
