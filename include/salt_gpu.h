@@ -171,6 +171,20 @@ int  salt_gpu_ws_pe_overflow(salt_gpu_ws_t *ws, uint32_t *n);
  * k_pe_final, out[4] = the overflow count above; the rest is internal. */
 int  salt_gpu_ws_pe_counts(salt_gpu_ws_t *ws, uint32_t out[8]);
 
+/* ---- FASTQ text in, SAM text out ------------------------------------------------------------------------------------
+ * query_read_seq (query.c:146-239) + alnse_core1 + aln_samse / sam_add_xa / sam_add_md_nm (sam.c:87-328) for one block of whole,
+ * strict 4-line FASTQ records: the block is parsed, aligned and formatted on the device; the host only hands over the text and
+ * gets the SAM records of the block back (one line per read, input order, a skipped read = an empty line).  `fastq` should be
+ * page-locked (salt_gpu_host_alloc) and must end with a newline; *sam points into a page-locked buffer the workspace owns and
+ * stays valid until the next call on it.  Needs the contig table (bntann1_t offset + name per sequence, bntseq.h) for RNAME / POS.
+ * Multi-line FASTQ records are not read here (SALT_E_INVAL names the record); callers fall back to their host parser. */
+typedef struct { int32_t print_xa_cigar, print_nm_md; const char *rg_id; } salt_text_opt_t;      /* -c, -d, -g */
+int  salt_gpu_index_set_contigs(salt_gpu_index_t *ix, int32_t n, const int64_t *offsets, const char *const *names);
+int  salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, const salt_text_opt_t *topt, const char *fastq, uint64_t n_bytes,
+                            const char **sam, uint64_t *sam_bytes, uint32_t *n_reads);
+int  salt_gpu_host_alloc(uint64_t bytes, void **ptr);      /* page-locked host memory for the text buffers */
+void salt_gpu_host_free(void *ptr);
+
 /* Same work on device-resident buffers; only enqueues on `hip_stream` (a hipStream_t, NULL = default). */
 int  salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, uint32_t n_reads,
                                 uint32_t max_read_len, const void *d_seqs, const void *d_offs,

@@ -29,6 +29,8 @@ void          salt_index_free(salt_index_t *ix);
 const salt_host_index_t *salt_index_host_view(const salt_index_t *ix);
 int32_t       salt_index_seed_len(const salt_index_t *ix);
 int32_t       salt_index_n_seqs(const salt_index_t *ix);
+/* sequence i of <P>.C.ann (bntann1_t, bntseq.h): its offset in the concatenated genome, length and name -- what salt_gpu_index_set_contigs takes */
+int           salt_index_seq(const salt_index_t *ix, int32_t i, int64_t *offset, int32_t *len, const char **name);
 const uint8_t *salt_index_pac(const salt_index_t *ix, uint64_t *l_pac);   /* <P>.C.pac bytes (bntseq.c 2-bit packing) for salt_gpu_index_set_pac */
 const char   *salt_host_last_error(void);
 

@@ -9,6 +9,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <algorithm>
 #include "salt_kernels.h"
 #include <rccl/rccl.h>
 
@@ -28,6 +29,7 @@ struct salt_gpu_index {
     ImageHeader hdr;               // host copy
     IndexView view;
     uint8_t *d_pac = nullptr; uint64_t l_pac = 0;      // 2-bit genome for the PE singleton rescue (not part of the image)
+    int64_t *d_c_off = nullptr; uint32_t *d_c_name_off = nullptr; char *d_c_names = nullptr; int32_t n_contigs = 0;     // contig table for the SAM kernels
 };
 
 struct salt_gpu_ws {
@@ -46,6 +48,10 @@ struct salt_gpu_ws {
     PePair *d_pairs = nullptr; PeSwReq *d_req = nullptr; PeSwRes *d_swres = nullptr; uint32_t *d_pctl = nullptr;
     uint8_t *d_sw_scr = nullptr; uint64_t sw_scr_bytes = 0; uint32_t sw_blocks = 0; uint32_t pe_pairs_cap = 0;
     uint32_t *d_pcq = nullptr;                         // k_cigar items of the gapped, not rescued mates
+    // FASTQ text in / SAM text out (allocated on first use, grown on demand)
+    uint8_t *d_raw = nullptr; uint64_t raw_cap = 0; uint32_t *d_tile = nullptr; uint64_t tile_cap = 0; uint32_t *d_lines = nullptr; uint64_t lines_cap = 0;
+    FqRec *d_rec = nullptr; uint32_t *d_tctl = nullptr, *d_samoff = nullptr; void *d_scan = nullptr; size_t scan_bytes = 0;
+    char *d_sam = nullptr, *h_sam = nullptr; uint64_t sam_cap = 0; char *d_rg = nullptr; std::string rg;
     uint32_t heavy_blocks = 2048;
     int all_heavy = 0;
     hipStream_t stream = nullptr;
@@ -189,6 +195,7 @@ extern "C" void salt_gpu_index_detach(salt_gpu_index_t *ix)
     if (!ix) return;
     if (ix->owns && ix->image) { hipSetDevice(ix->device); hipFree(ix->image); }
     if (ix->d_pac) { hipSetDevice(ix->device); hipFree(ix->d_pac); }
+    if (ix->d_c_off) { hipSetDevice(ix->device); hipFree(ix->d_c_off); hipFree(ix->d_c_name_off); hipFree(ix->d_c_names); }
     delete ix;
 }
 
@@ -298,6 +305,8 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
     if (!ws) return;
     hipSetDevice(ws->ix->device);
     hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_heads); if (ws->h_heads) hipHostFree(ws->h_heads); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gap);
+    hipFree(ws->d_raw); hipFree(ws->d_tile); hipFree(ws->d_lines); hipFree(ws->d_rec); hipFree(ws->d_tctl); hipFree(ws->d_samoff); hipFree(ws->d_scan); hipFree(ws->d_sam); hipFree(ws->d_rg);
+    if (ws->h_sam) hipHostFree(ws->h_sam);
     hipFree(ws->d_pe_scr); hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres); hipFree(ws->d_pctl); hipFree(ws->d_sw_scr); hipFree(ws->d_pcq);
     if (ws->stream) hipStreamDestroy(ws->stream);
     for (auto &e : ws->ev) if (e) hipEventDestroy(e);
@@ -451,6 +460,127 @@ extern "C" int salt_gpu_align_se(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uin
     if (rc) return rc;
     return fetch_results(ws, n_reads, results, ws->stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// FASTQ text in, SAM text out
+// ---------------------------------------------------------------------------------------------
+extern "C" int salt_gpu_index_set_contigs(salt_gpu_index_t *ix, int32_t n, const int64_t *offsets, const char *const *names)
+{
+    if (!ix || n <= 0 || !offsets || !names) return fail(SALT_E_INVAL, "bad contig table");
+    HIPCHK(hipSetDevice(ix->device));
+    std::vector<uint32_t> noff((size_t)n + 1, 0); std::string blob;
+    for (int i = 0; i < n; ++i) { if (!names[i]) return fail(SALT_E_INVAL, "contig without a name"); blob += names[i]; noff[(size_t)i + 1] = (uint32_t)blob.size(); }
+    if (ix->d_c_off) { hipFree(ix->d_c_off); hipFree(ix->d_c_name_off); hipFree(ix->d_c_names); ix->d_c_off = nullptr; ix->d_c_name_off = nullptr; ix->d_c_names = nullptr; ix->n_contigs = 0; }
+    HIPCHK(hipMalloc((void **)&ix->d_c_off, (size_t)n * 8));
+    HIPCHK(hipMalloc((void **)&ix->d_c_name_off, ((size_t)n + 1) * 4));
+    HIPCHK(hipMalloc((void **)&ix->d_c_names, blob.size() + 1));
+    HIPCHK(hipMemcpy(ix->d_c_off, offsets, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->d_c_name_off, noff.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->d_c_names, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    ix->n_contigs = n;
+    return SALT_OK;
+}
+
+extern "C" int salt_gpu_host_alloc(uint64_t bytes, void **ptr)
+{
+    if (!ptr || !bytes) return fail(SALT_E_INVAL, "null argument");
+    HIPCHK(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return SALT_OK;
+}
+extern "C" void salt_gpu_host_free(void *ptr) { if (ptr) hipHostFree(ptr); }
+
+#define REGROW(ptr, cap, need, type) do { if ((need) > (cap)) { HIPCHK(hipStreamSynchronize(st)); hipFree(ptr); (ptr) = nullptr; (cap) = 0; \
+    const uint64_t want_ = (need) + (need) / 4; HIPCHK(hipMalloc((void **)&(ptr), want_ * sizeof(type))); (cap) = want_; } } while (0)
+
+extern "C" int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_text_opt_t *to, const char *fastq, uint64_t n_bytes,
+                                      const char **sam, uint64_t *sam_bytes, uint32_t *n_reads)
+{
+    if (!ws || !o || !to || !fastq || !sam || !sam_bytes || !n_reads) return fail(SALT_E_INVAL, "null argument");
+    *sam = nullptr; *sam_bytes = 0; *n_reads = 0;
+    if (n_bytes == 0) return SALT_OK;
+    if (n_bytes >= 0xFFFFFFF0ull) return fail(SALT_E_CAPACITY, "FASTQ block of 4 GiB or more");
+    if (fastq[n_bytes - 1] != '\n') return fail(SALT_E_INVAL, "FASTQ block must end with a newline");
+    salt_gpu_index *ix = ws->ix;
+    if (!ix->d_c_off) return fail(SALT_E_INVAL, "SAM text needs the contig table: call salt_gpu_index_set_contigs first");
+    HIPCHK(hipSetDevice(ix->device));
+    hipStream_t st = ws->stream;
+    // ---- the raw block and its lines ----
+    REGROW(ws->d_raw, ws->raw_cap, n_bytes + 64, uint8_t);
+    const uint64_t n_tiles = (n_bytes + FQ_TILE - 1) / FQ_TILE;
+    if (!ws->d_tctl) HIPCHK(hipMalloc((void **)&ws->d_tctl, 16));
+    {   // tile counters + scan scratch follow the raw capacity
+        const uint64_t tiles_cap = ws->raw_cap / FQ_TILE + 4;
+        REGROW(ws->d_tile, ws->tile_cap, tiles_cap, uint32_t);
+        const size_t need = text_scan_bytes(std::max<uint64_t>(ws->tile_cap, (uint64_t)ws->max_reads + 2));
+        if (need > ws->scan_bytes) { HIPCHK(hipStreamSynchronize(st)); hipFree(ws->d_scan); ws->d_scan = nullptr; ws->scan_bytes = 0; HIPCHK(hipMalloc(&ws->d_scan, need)); ws->scan_bytes = need; }
+    }
+    HIPCHK(hipMemcpyAsync(ws->d_raw, fastq, n_bytes, hipMemcpyHostToDevice, st));
+    // newline count first: the line table is sized by it
+    uint32_t n_nl = 0;
+    HIPCHK(launch_fq_count(ws->d_raw, n_bytes, ws->d_tile, ws->d_scan, ws->scan_bytes, st));
+    HIPCHK(hipMemcpyAsync(&n_nl, ws->d_tile + n_tiles, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_nl % 4 != 0) return fail(SALT_E_INVAL, "FASTQ block does not hold whole 4-line records (" + std::to_string(n_nl) + " lines)");
+    const uint32_t n_rec = n_nl / 4;
+    if (n_rec > ws->max_reads) return fail(SALT_E_CAPACITY, "more reads in the block (" + std::to_string(n_rec) + ") than the workspace holds");
+    if (n_rec == 0) return SALT_OK;
+    REGROW(ws->d_lines, ws->lines_cap, (uint64_t)n_nl + 8, uint32_t);
+    HIPCHK(launch_fq_lines(ws->d_raw, n_bytes, ws->d_tile, ws->d_lines, st));
+    // ---- records, offsets, codes ----
+    if (!ws->d_rec) HIPCHK(hipMalloc((void **)&ws->d_rec, (uint64_t)ws->max_reads * sizeof(FqRec)));
+    HIPCHK(launch_fq_parse(ws->d_raw, ws->d_lines, n_rec, ws->d_rec, ws->d_offs, ws->d_tctl, ws->d_scan, ws->scan_bytes, st));
+    uint32_t ctl[4] = { 0, 0, 0, 0 }, bases = 0;
+    HIPCHK(hipMemcpyAsync(ctl, ws->d_tctl, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&bases, ws->d_offs + n_rec, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (ctl[0]) {
+        const char *what = ctl[0] & 1 ? "a record does not start with '@'" : ctl[0] & 2 ? "the third line of a record does not start with '+'"
+                         : ctl[0] & 4 ? "sequence and quality lengths differ" : "empty read";
+        return fail(SALT_E_INVAL, std::string("input is not 4-line FASTQ at record ") + std::to_string(ctl[2]) + " of the block: " + what);
+    }
+    if ((uint64_t)bases > ws->max_bases) {
+        HIPCHK(hipStreamSynchronize(st));
+        hipFree(ws->d_seqs); ws->d_seqs = nullptr;
+        HIPCHK(hipMalloc((void **)&ws->d_seqs, (uint64_t)bases + bases / 4 + 64));
+        ws->max_bases = (uint64_t)bases + bases / 4;
+    }
+    HIPCHK(launch_fq_codes(ws->d_raw, ws->d_rec, ws->d_offs, n_rec, ws->d_seqs, st));
+    // ---- align ----
+    int rc = align_resident_impl(ws, o, n_rec, ctl[1], ws->d_seqs, ws->d_offs, ws->d_results, st, 0);
+    if (rc) return rc;
+    // ---- SAM text ----
+    const std::string rg = to->rg_id ? to->rg_id : "";
+    if (rg != ws->rg || (!rg.empty() && !ws->d_rg)) {
+        HIPCHK(hipStreamSynchronize(st));
+        hipFree(ws->d_rg); ws->d_rg = nullptr;
+        if (!rg.empty()) { HIPCHK(hipMalloc((void **)&ws->d_rg, rg.size() + 1)); HIPCHK(hipMemcpy(ws->d_rg, rg.data(), rg.size(), hipMemcpyHostToDevice)); }
+        ws->rg = rg;
+    }
+    if (!ws->d_samoff) HIPCHK(hipMalloc((void **)&ws->d_samoff, ((uint64_t)ws->max_reads + 2) * 4));
+    SamDev d;
+    d.raw = ws->d_raw; d.rec = ws->d_rec; d.seqs = ws->d_seqs; d.offs = ws->d_offs; d.res = ws->d_results;
+    d.c_off = ix->d_c_off; d.c_name_off = ix->d_c_name_off; d.c_names = ix->d_c_names; d.n_contigs = ix->n_contigs;
+    d.text = ix->view.text; d.ref = ix->view.ref; d.xa_cigar = to->print_xa_cigar; d.nm_md = to->print_nm_md;
+    d.rg = ws->d_rg; d.rg_len = to->rg_id ? (int32_t)rg.size() : 0;
+    if (to->rg_id && rg.empty()) return fail(SALT_E_INVAL, "empty read group id");
+    HIPCHK(launch_sam_len(d, n_rec, ws->d_samoff, ws->d_scan, ws->scan_bytes, st));
+    uint32_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, ws->d_samoff + n_rec, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if ((uint64_t)total + 64 > ws->sam_cap) {
+        hipFree(ws->d_sam); ws->d_sam = nullptr; if (ws->h_sam) { hipHostFree(ws->h_sam); ws->h_sam = nullptr; } ws->sam_cap = 0;
+        const uint64_t want = (uint64_t)total + total / 4 + 64;
+        HIPCHK(hipMalloc((void **)&ws->d_sam, want));
+        HIPCHK(hipHostMalloc((void **)&ws->h_sam, want, hipHostMallocDefault));
+        ws->sam_cap = want;
+    }
+    HIPCHK(launch_sam_write(d, n_rec, ws->d_samoff, ws->d_sam, st));
+    HIPCHK(hipMemcpyAsync(ws->h_sam, ws->d_sam, total, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *sam = ws->h_sam; *sam_bytes = total; *n_reads = n_rec;
+    return SALT_OK;
+}
+#undef REGROW
 
 extern "C" int salt_gpu_index_replicate(salt_gpu_index_t *src, const int *devices, int n, salt_gpu_index_t **out)
 {

@@ -104,6 +104,24 @@ void launch_diag_verify(const uint32_t *ref, uint32_t ref_len, uint32_t n_cases,
 void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const uint32_t *kdiff, const uint8_t *seqs,
                     const uint32_t *offs, int32_t *out, uint16_t *cig, void *lvtab, hipStream_t st);
 
+// ---- FASTQ text in, SAM text out (salt_text.hip) ----
+struct FqRec { uint32_t name_off, name_len, seq_off, len, qual_off; };        // one 4-line record: offsets into the raw block
+struct SamDev {                                                               // what the SAM kernels read (by value)
+    const uint8_t *raw; const FqRec *rec; const uint8_t *seqs; const uint32_t *offs; const salt_result_t *res;
+    const int64_t *c_off; const uint32_t *c_name_off; const char *c_names; int32_t n_contigs;      // contigs (bntann1_t: offset, name)
+    const uint32_t *text, *ref;                                                // 2-bit genome, mixRef
+    int32_t xa_cigar, nm_md; const char *rg; int32_t rg_len;
+};
+size_t text_scan_bytes(uint64_t max_items);
+hipError_t launch_fq_count(const uint8_t *raw, uint64_t n, uint32_t *tile_cnt, void *tmp, size_t tmp_bytes, hipStream_t st);
+hipError_t launch_fq_lines(const uint8_t *raw, uint64_t n, const uint32_t *tile_off, uint32_t *line_start, hipStream_t st);
+hipError_t launch_fq_parse(const uint8_t *raw, const uint32_t *line_start, uint32_t n_rec, FqRec *rec, uint32_t *offs, uint32_t *ctl,
+                           void *tmp, size_t tmp_bytes, hipStream_t st);
+hipError_t launch_fq_codes(const uint8_t *raw, const FqRec *rec, const uint32_t *offs, uint32_t n_rec, uint8_t *seqs, hipStream_t st);
+hipError_t launch_sam_len(const SamDev &d, uint32_t n, uint32_t *off, void *tmp, size_t tmp_bytes, hipStream_t st);
+hipError_t launch_sam_write(const SamDev &d, uint32_t n, const uint32_t *off, char *out, hipStream_t st);
+static const uint32_t FQ_TILE = 1024;                                          // bytes per newline-count tile (k_fq_count)
+
 // attach-time re-packing + expansion kernels (salt_index.hip)
 void launch_pack_c_occ(const uint32_t *bwt, uint64_t bwt_words, uint32_t seq_len, uint64_t n_blocks, COcc *out, uint32_t *err, hipStream_t st);
 void launch_pack_r_occ(const uint32_t *code, uint64_t code_words, const uint32_t *minor, uint64_t minor_words, const uint32_t *major, uint64_t major_words,

@@ -184,6 +184,14 @@ extern "C" const salt_host_index_t *salt_index_host_view(const salt_index_t *ix)
 extern "C" int32_t salt_index_seed_len(const salt_index_t *ix) { return ix->seed_len; }
 extern "C" const uint8_t *salt_index_pac(const salt_index_t *ix, uint64_t *l_pac) { if (l_pac) *l_pac = (uint64_t)ix->l_pac; return ix->pac.data(); }
 extern "C" int32_t salt_index_n_seqs(const salt_index_t *ix) { return (int32_t)ix->anns.size(); }
+extern "C" int salt_index_seq(const salt_index_t *ix, int32_t i, int64_t *offset, int32_t *len, const char **name)
+{
+    if (!ix || i < 0 || (size_t)i >= ix->anns.size()) return -1;
+    if (offset) *offset = ix->anns[(size_t)i].offset;
+    if (len) *len = ix->anns[(size_t)i].len;
+    if (name) *name = ix->anns[(size_t)i].name.c_str();
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------------------
 // SAM text

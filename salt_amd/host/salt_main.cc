@@ -10,7 +10,10 @@
 // Flags the reference parses but ignores stay ignored (-n -e -M -O -E -l -X).  -p <mate1> <mate2>: paired end
 // (alnpe_core, Align_src/alnpe.c:530-661) through salt_gpu_align_pe.
 #include "../../include/salt_host.h"
+#include <fcntl.h>
 #include <getopt.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 #include <cctype>
 #include <cstdio>
@@ -317,6 +320,158 @@ int usage()
     return 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Single end, plain 4-line FASTQ in a regular file: the text path.  FASTQ text goes to the GPU as it lies in the file, SAM text comes
+// back (salt_gpu_align_se_text: parse, align and format are kernels), and the host only moves bytes:
+//   every worker claims the next chunk of the file (pread into page-locked memory), cuts it at record boundaries -- a record starts
+//   at a line that begins with '@' and whose next-but-one line begins with '+' (a quality line may begin with '@', but then the
+//   line two further on is a sequence) --, calls the device, and writes its SAM block at the offset the blocks before it add up to
+//   (pwrite, in parallel, when stdout is a regular file; in turn otherwise).  Output order = input order, as the reference's puts
+//   loop gives it (alnse.c:1433-1439).
+// ---------------------------------------------------------------------------------------------
+struct TextRun {
+    int fd = -1; uint64_t file_size = 0, chunk = 0;
+    std::atomic<uint64_t> next_chunk{ 0 };
+    // output sequencing: block k may learn its offset once block k - 1 has published its end, and (stream mode) write once k - 1 has written
+    std::mutex mu; std::condition_variable cv;
+    uint64_t sized = 0, written = 0; uint64_t out_off = 0; long reads_done = 0;
+    bool out_seekable = false; int out_fd = 1;
+    std::atomic<bool> failed{ false };
+};
+
+static const uint64_t TEXT_SLACK = 1u << 20;             // how far past a chunk's end a worker looks for the next record start (longest record it can cut)
+
+// first record start at or after `from` in buf[0..n): a line start whose line begins with '@' and whose next-but-one line begins with '+'.
+// `from` itself counts only when the byte before it is a newline (or it is the start of the file).  Returns n when there is none.
+static uint64_t next_record_start(const char *buf, uint64_t n, uint64_t from, bool from_is_line_start)
+{
+    uint64_t p = from;
+    if (!from_is_line_start) { const char *nl = (const char *)memchr(buf + p, '\n', n - p); if (!nl) return n; p = (uint64_t)(nl - buf) + 1; }
+    while (p < n) {
+        const char *n1 = (const char *)memchr(buf + p, '\n', n - p);
+        if (!n1) return n;
+        const uint64_t l1 = (uint64_t)(n1 - buf) + 1;
+        if (buf[p] == '@' && l1 < n) {
+            const char *n2 = (const char *)memchr(buf + l1, '\n', n - l1);
+            if (!n2) return n;
+            const uint64_t l2 = (uint64_t)(n2 - buf) + 1;
+            if (l2 < n && buf[l2] == '+') return p;
+            if (l2 >= n) return n;
+        }
+        p = l1;
+    }
+    return n;
+}
+
+static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector<salt_gpu_index_t *> &gix, int n_gpus, int n_workers_per_gpu,
+                       const salt_aln_opt_t &ao, const salt_sam_opt_t &so, double t0)
+{
+    TextRun R;
+    R.fd = open(fn_reads, O_RDONLY);
+    if (R.fd < 0) { fprintf(stderr, "[query_open]: file %s open fail!\n", fn_reads); return 1; }
+    struct stat sb;
+    if (fstat(R.fd, &sb) != 0) { fprintf(stderr, "[salt] cannot stat %s\n", fn_reads); return 1; }
+    R.file_size = (uint64_t)sb.st_size;
+    { const char *e = getenv("SALT_CHUNK_MB"); int mb = e ? atoi(e) : 32; if (mb < 1) mb = 1; if (mb > 1024) mb = 1024; R.chunk = (uint64_t)mb << 20; }
+    if (const char *e = getenv("SALT_CHUNK_BYTES")) { long v = atol(e); if (v >= 256) R.chunk = (uint64_t)v; }      // tests: many chunks on a small file
+    fflush(stdout);
+    struct stat ob;
+    R.out_seekable = fstat(1, &ob) == 0 && S_ISREG(ob.st_mode) && !(fcntl(1, F_GETFL) & O_APPEND);      // pwrite ignores its offset on O_APPEND files
+    if (R.out_seekable) { off_t cur = lseek(1, 0, SEEK_CUR); if (cur < 0) R.out_seekable = false; else R.out_off = (uint64_t)cur; }
+    // contig table for RNAME / POS on the device
+    {
+        const int n = salt_index_n_seqs(ix);
+        std::vector<int64_t> off((size_t)n); std::vector<const char *> nm((size_t)n);
+        for (int i = 0; i < n; ++i) salt_index_seq(ix, i, &off[(size_t)i], nullptr, &nm[(size_t)i]);
+        for (int g = 0; g < n_gpus; ++g)
+            if (salt_gpu_index_set_contigs(gix[(size_t)g], n, off.data(), nm.data())) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
+    }
+    const int n_workers = n_gpus * n_workers_per_gpu;
+    const uint32_t max_reads = (uint32_t)((R.chunk + TEXT_SLACK) / 32);
+    const salt_text_opt_t to = { so.print_xa_cigar, so.print_nm_md, so.rg_id };
+    const uint64_t n_chunks = (R.file_size + R.chunk - 1) / R.chunk;
+    std::vector<std::thread> workers;
+    std::atomic<double> t_read{ 0 }, t_gpu{ 0 }, t_write{ 0 };
+    auto set_failed = [&]() { { std::lock_guard<std::mutex> lk(R.mu); R.failed = true; } R.cv.notify_all(); };
+    for (int wk = 0; wk < n_workers; ++wk)
+        workers.emplace_back([&, wk]() {
+            salt_gpu_ws_t *ws = nullptr; char *buf = nullptr;
+            const uint64_t cap = R.chunk + 2 * TEXT_SLACK + 64;
+            if (salt_gpu_ws_create(gix[(size_t)(wk / n_workers_per_gpu)], max_reads, (uint64_t)max_reads * 160, &ws) || salt_gpu_host_alloc(cap, (void **)&buf)) {
+                fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); set_failed(); return;
+            }
+            for (;;) {
+                const uint64_t k = R.next_chunk.fetch_add(1);
+                if (k >= n_chunks || R.failed) break;
+                // bytes [lo - 1, hi + slack) of the file: one byte of context in front (is `lo` a line start?), slack behind (where does the last record end?)
+                const uint64_t lo = k * R.chunk, hi = std::min(R.file_size, lo + R.chunk);
+                const uint64_t rd_lo = lo ? lo - 1 : 0, rd_hi = std::min(R.file_size, hi + TEXT_SLACK);
+                double tr0 = now();
+                uint64_t got = 0;
+                while (got < rd_hi - rd_lo) {
+                    ssize_t r = pread(R.fd, buf + got, rd_hi - rd_lo - got, (off_t)(rd_lo + got));
+                    if (r <= 0) break;
+                    got += (uint64_t)r;
+                }
+                if (got != rd_hi - rd_lo) { fprintf(stderr, "[salt] short read on %s\n", fn_reads); set_failed(); break; }
+                t_read = t_read + (now() - tr0);
+                uint64_t n = got;
+                if (rd_hi == R.file_size && n && buf[n - 1] != '\n') buf[n++] = '\n';          // a last record without its newline
+                const uint64_t b0 = lo - rd_lo;                                                  // offset of file byte `lo` in buf
+                const uint64_t beg = next_record_start(buf, n, b0, lo == 0 || buf[b0 - 1] == '\n');
+                uint64_t end = n;
+                if (hi < R.file_size) end = next_record_start(buf, n, hi - rd_lo, buf[hi - rd_lo - 1] == '\n');
+                if (hi < R.file_size && end == n) { fprintf(stderr, "[salt] a FASTQ record longer than %llu bytes near offset %llu\n", (unsigned long long)TEXT_SLACK, (unsigned long long)hi); set_failed(); break; }
+                const uint64_t beg2 = std::min(beg, end);
+                const char *sam = nullptr; uint64_t sam_bytes = 0; uint32_t n_reads = 0;
+                double tg0 = now();
+                if (end > beg2 && salt_gpu_align_se_text(ws, &ao, &to, buf + beg2, end - beg2, &sam, &sam_bytes, &n_reads)) {
+                    fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); set_failed(); break;
+                }
+                t_gpu = t_gpu + (now() - tg0);
+                // my offset = the end of block k - 1
+                uint64_t my_off = 0;
+                {
+                    std::unique_lock<std::mutex> lk(R.mu);
+                    R.cv.wait(lk, [&] { return R.failed || R.sized == k; });
+                    if (R.failed) break;
+                    my_off = R.out_off; R.out_off += sam_bytes; R.sized = k + 1;
+                    if (R.out_seekable) { R.reads_done += n_reads; fprintf(stderr, "%ld reads have been aligned!\n", R.reads_done); }
+                    R.cv.notify_all();
+                    if (!R.out_seekable) {                                                       // a pipe: blocks are written in turn
+                        R.cv.wait(lk, [&] { return R.failed || R.written == k; });
+                        if (R.failed) break;
+                    }
+                }
+                double tw0 = now();
+                bool ok = true;
+                for (uint64_t w = 0; w < sam_bytes && ok; ) {
+                    ssize_t r = R.out_seekable ? pwrite(1, sam + w, sam_bytes - w, (off_t)(my_off + w)) : write(1, sam + w, sam_bytes - w);
+                    if (r <= 0) ok = false; else w += (uint64_t)r;
+                }
+                t_write = t_write + (now() - tw0);
+                if (!ok) { fprintf(stderr, "[salt] write error on the SAM stream\n"); set_failed(); break; }
+                if (!R.out_seekable) {
+                    std::lock_guard<std::mutex> lk(R.mu);
+                    R.written = k + 1; R.reads_done += n_reads;
+                    fprintf(stderr, "%ld reads have been aligned!\n", R.reads_done);
+                    R.cv.notify_all();
+                }
+            }
+            salt_gpu_host_free(buf);
+            salt_gpu_ws_destroy(ws);
+        });
+    for (auto &w : workers) w.join();
+    if (R.out_seekable && !R.failed) lseek(1, (off_t)R.out_off, SEEK_SET);
+    close(R.fd);
+    const double dt = now() - t0;
+    fprintf(stderr, "[alnse_core]: total %lf sec escaped\n", dt);
+    fprintf(stderr, "[salt] text path: %d worker(s), chunk %llu MiB, %s output; seconds summed over workers: read %.3f device call %.3f write %.3f\n", n_workers,
+            (unsigned long long)(R.chunk >> 20), R.out_seekable ? "seekable (parallel pwrite)" : "stream (in turn)", t_read.load(), t_gpu.load(), t_write.load());
+    fprintf(stderr, "[salt] %ld reads, %.3f Mreads/s end to end (FASTQ -> SAM, %d GPU(s))\n", R.reads_done, dt > 0 ? R.reads_done / dt / 1e6 : 0.0, n_gpus);
+    return R.failed ? 1 : 0;
+}
+
 } // namespace
 
 int main(int argc, char **argv)
@@ -374,6 +529,32 @@ int main(int argc, char **argv)
         for (int i = 0; i < n_gpus; ++i)
             if (salt_gpu_index_set_pac(gix[(size_t)i], pac, l_pac)) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
     }
+    auto print_header = [&]() -> bool {                  // aln_samhead (sam.c:56-84)
+        std::vector<char> hb(16 << 20);
+        int w = salt_sam_header(ix, &so, hb.data(), hb.size());
+        if (w < 0) { fprintf(stderr, "[salt] SAM header too large\n"); return false; }
+        fwrite(hb.data(), 1, (size_t)w, stdout);
+        time_t tt = time(nullptr); struct tm *tmv = localtime(&tt);
+        printf("@PG\tID:snpaln\tPN:snpaln\tCL:\"%s\"\tDS:%d-%d-%d\tVN:0.1beta\n", cmd.c_str(), tmv->tm_year + 1900, tmv->tm_mon + 1, tmv->tm_mday);
+        return true;
+    };
+    // Single end + a plain (not gzipped) strict 4-line FASTQ in a regular file: the text path -- parse, align and format on the device
+    // (run_se_text).  Everything else (paired end, gzip, pipes, multi-line records) goes through the host pipeline below.
+    // SALT_HOST_PIPELINE=1 forces the latter.
+    if (!pe && !(getenv("SALT_HOST_PIPELINE") && atoi(getenv("SALT_HOST_PIPELINE")))) {
+        struct stat sb; unsigned char magic[2] = { 0, 0 };
+        bool plain = stat(fn_reads, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0;
+        if (plain) { FILE *f = fopen(fn_reads, "rb"); plain = f && fread(magic, 1, 2, f) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b); if (f) fclose(f); }
+        if (plain && sniff_four_line(fn_reads)) {
+            fprintf(stderr, "%lf sec escaped.\n", now() - t0);
+            if (!print_header()) return 1;
+            const int wpg = n_threads / n_gpus >= 8 ? 4 : n_threads / n_gpus >= 4 ? 3 : 2;
+            const int rc = run_se_text(fn_reads, ix, gix, n_gpus, wpg, ao, so, now());
+            for (int i = n_gpus - 1; i >= 0; --i) salt_gpu_index_detach(gix[(size_t)i]);
+            salt_index_free(ix);
+            return rc;
+        }
+    }
     // workers per GPU: each takes a batch through parse -> device -> format, so several batches overlap on the host
     const int WPG = n_threads / n_gpus >= 32 ? 4 : n_threads / n_gpus >= 12 ? 3 : 2;
     std::vector<salt_gpu_ws_t *> ws((size_t)n_gpus * WPG, nullptr);
@@ -392,14 +573,7 @@ int main(int argc, char **argv)
         gzbuffer(fp2, 1 << 20);
     }
 
-    {   // header (aln_samhead, sam.c:56-84)
-        std::vector<char> hb(1 << 20);
-        int w = salt_sam_header(ix, &so, hb.data(), hb.size());
-        if (w < 0) { fprintf(stderr, "[salt] SAM header too large\n"); return 1; }
-        fwrite(hb.data(), 1, (size_t)w, stdout);
-        time_t tt = time(nullptr); struct tm *tmv = localtime(&tt);
-        printf("@PG\tID:snpaln\tPN:snpaln\tCL:\"%s\"\tDS:%d-%d-%d\tVN:0.1beta\n", cmd.c_str(), tmv->tm_year + 1900, tmv->tm_mon + 1, tmv->tm_mday);
-    }
+    if (!print_header()) return 1;
 
     // ---- pipeline: reader -> per-GPU workers -> ordered writer ----
     std::mutex mu; std::condition_variable cv;

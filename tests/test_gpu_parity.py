@@ -657,3 +657,46 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     assert out.returncode == 0, out.stderr[-600:]
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["steps"] == 4
+
+
+@pytest.mark.parametrize("case", ["se_default", "se_r1_m500", "se_refonly", "se_r5_s4_m16", "se_plain_t4"])
+def test_cli_text_path_and_host_pipeline_give_the_reference_sam(case, tmp_path):
+    """The two SE pipelines of `salt` against the reference's SAM: the text path (FASTQ parsed and SAM formatted by kernels; here with
+    chunks of a few KB so that hundreds of chunk boundaries fall inside records, to a pipe and to a regular file = parallel pwrite) and
+    the host pipeline (SALT_HOST_PIPELINE=1: the parser that also reads gzip / multi-line records)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt = os.path.join(root, "salt_amd", "bin", "salt")
+    args = read_cases()[case]
+    want = open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
+    strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    cmd = [salt] + args + [os.path.join(LAMBDA, "idx"), os.path.join(LAMBDA, "reads_se.fq")]
+    for env in (dict(os.environ, SALT_CHUNK_BYTES="3001"), dict(os.environ, SALT_CHUNK_BYTES="70000"), dict(os.environ, SALT_HOST_PIPELINE="1")):
+        out = subprocess.run(cmd, capture_output=True, env=env)
+        assert out.returncode == 0, out.stderr[-400:]
+        assert strip(out.stdout) == want, (case, env.get("SALT_CHUNK_BYTES"), env.get("SALT_HOST_PIPELINE"))
+        if "SALT_HOST_PIPELINE" not in env:
+            assert b"text path" in out.stderr
+    f = tmp_path / "out.sam"
+    with open(f, "wb") as fo:
+        out = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, SALT_CHUNK_BYTES="5000"))
+    assert out.returncode == 0 and b"parallel pwrite" in out.stderr, out.stderr[-400:]
+    assert strip(open(f, "rb").read()) == want
+
+
+def test_cli_text_path_reads_crlf_and_a_last_record_without_newline(tmp_path):
+    """CRLF line ends and a file that ends without a newline, through the text path (chunked) and the host pipeline alike."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt = os.path.join(root, "salt_amd", "bin", "salt")
+    src = open(os.path.join(LAMBDA, "reads_se.fq"), "rb").read().splitlines()[:800]
+    fq = tmp_path / "crlf.fq"
+    fq.write_bytes(b"\r\n".join(src))                      # no newline after the last quality line
+    cmd = [salt, "-d", "-c", os.path.join(LAMBDA, "idx"), str(fq)]
+    strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    a = subprocess.run(cmd, capture_output=True, env=dict(os.environ, SALT_CHUNK_BYTES="4000"))
+    b = subprocess.run(cmd, capture_output=True, env=dict(os.environ, SALT_HOST_PIPELINE="1"))
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-300:], b.stderr[-300:])
+    assert b"text path" in a.stderr and strip(a.stdout) == strip(b.stdout)
+    want = open(os.path.join(LAMBDA, "expect_se_default.sam"), "rb").read().split(b"\n")
+    got = strip(a.stdout).split(b"\n")
+    n_hdr = sum(1 for l in want if l.startswith(b"@"))
+    assert got[:n_hdr + 200] == want[:n_hdr + 200]
