@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--batches", type=int, default=int(os.environ.get("SALT_BENCH_BATCHES", "8")), help="distinct resident read batches the steps rotate through")
     ap.add_argument("--cpu-sample", type=int, default=1000000, help="reads given to the CPU baseline / parity check")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--e2e-reads", type=int, default=4000000, help="reads of the end-to-end leg (`salt` binary, FASTQ -> SAM); 0 = skip")
+    ap.add_argument("--e2e-reads", type=int, default=16000000, help="reads of the end-to-end leg (`salt` binary, FASTQ -> SAM); 0 = skip")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (experiments; default: the workload's own batch)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("SALT_BENCH_STREAMS", "4")),
                     help="workspaces / HIP streams per GPU the steps are dealt to round-robin (salt runs 2-4 align workers per GPU)")
@@ -356,16 +356,18 @@ def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log):
     err = p.stderr.decode(errors="replace")
     if p.returncode != 0:
         raise RuntimeError("salt exited %d: %s" % (p.returncode, err[-200:]))
-    align_s = None
+    align_s, detail = None, None
     for line in err.splitlines():
         if line.startswith("[alnse_core]: total"):
             align_s = float(line.split()[2])
+        if line.startswith("[salt] text path:") or line.startswith("[salt] host phases"):
+            detail = line[7:]
     sam_bytes = os.path.getsize(sam)
     os.unlink(sam); os.unlink(fq)
     return {"value": round(n / align_s / 1e6, 3) if align_s else None, "unit": "Mreads/s", "reads": n, "threads": threads,
             "what": "salt -d -c -t %d <idx> reads.fq > out.sam: FASTQ text in, SAM text out (%.2f GB), PCIe and host I/O included; clock = the binary's "
                     "[alnse_core] total (first batch submitted to last SAM byte written; index load + attach excluded, as SURVEY 8d defines it)" % (threads, sam_bytes / 1e9),
-            "align_wall_s": align_s, "process_wall_s": round(wall, 2), "fastq_write_s": round(t_write, 2)}
+            "align_wall_s": align_s, "process_wall_s": round(wall, 2), "fastq_write_s": round(t_write, 2), "pipeline": detail}
 
 
 if __name__ == "__main__":

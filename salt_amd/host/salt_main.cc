@@ -548,7 +548,8 @@ int main(int argc, char **argv)
         if (plain && sniff_four_line(fn_reads)) {
             fprintf(stderr, "%lf sec escaped.\n", now() - t0);
             if (!print_header()) return 1;
-            const int wpg = n_threads / n_gpus >= 8 ? 4 : n_threads / n_gpus >= 4 ? 3 : 2;
+            int wpg = n_threads / n_gpus >= 16 ? 8 : n_threads / n_gpus >= 8 ? 4 : n_threads / n_gpus >= 4 ? 3 : 2;      // text-path workers per GPU: each preads, calls the device, pwrites
+            if (const char *e = getenv("SALT_TEXT_WORKERS")) { int v = atoi(e); if (v >= 1 && v <= 32) wpg = v; }
             const int rc = run_se_text(fn_reads, ix, gix, n_gpus, wpg, ao, so, now());
             for (int i = n_gpus - 1; i >= 0; --i) salt_gpu_index_detach(gix[(size_t)i]);
             salt_index_free(ix);

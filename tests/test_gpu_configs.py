@@ -114,3 +114,29 @@ def test_config4_grch38_scale_pairs_equal_the_oracle(grch38):
     bad, mapped, rescued, res, want = _pe_parity(grch38, 20_000, seed=4)
     assert len(bad) == 0, (len(bad), _detail(bad, res, want))
     assert mapped > 0.97 and rescued > 150, (mapped, rescued)
+
+
+def test_config3_cli_fastq_to_sam_equals_the_oracle_cli(grch38, tmp_path):
+    """The drop-in command on the GRCh38-scale index, end to end: `salt -d -c idx reads.fq > out.sam` (text path: FASTQ parsed and SAM
+    formatted by kernels, parallel pread / pwrite, chunks of 8 MiB so that several workers and chunk boundaries take part) against
+    the oracle CLI's SAM for the same 300 000 reads, byte for byte (the @PG line carries the command line and is dropped)."""
+    import subprocess
+    from salt_amd import workload
+    w = grch38["w"]
+    n = 300_000
+    seqs, _, _, _ = workload.make_reads_hash(grch38["genome"], grch38["site"], n, 100, seed=9, batch=0)
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "wb") as f:
+        f.write(workload.fastq_bytes(seqs.cpu().numpy(), n, 100))
+    got_fn, want_fn = str(tmp_path / "gpu.sam"), str(tmp_path / "cpu.sam")
+    with open(got_fn, "wb") as fo:
+        p = subprocess.run([os.path.join(ROOT, "salt_amd", "bin", "salt"), "-d", "-c", "-t", "32", w["prefix"], fq], stdout=fo, stderr=subprocess.PIPE,
+                           env=dict(os.environ, SALT_CHUNK_MB="8"))
+    assert p.returncode == 0 and b"text path" in p.stderr, p.stderr[-400:]
+    with open(want_fn, "wb") as fo:
+        q = subprocess.run([os.path.join(ROOT, "oracle", "salt_oracle"), "-d", "-c", "-t", str(min(os.cpu_count() or 1, 64)), w["prefix"], fq], stdout=fo, stderr=subprocess.PIPE)
+    assert q.returncode == 0, q.stderr[-400:]
+    strip = lambda fn: [l for l in open(fn, "rb").read().split(b"\n") if not l.startswith(b"@PG")]
+    g, c = strip(got_fn), strip(want_fn)
+    bad = [i for i in range(min(len(g), len(c))) if g[i] != c[i]]
+    assert len(g) == len(c) and not bad, (len(g), len(c), len(bad), [(g[i][:160], c[i][:160]) for i in bad[:2]])

@@ -659,8 +659,18 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["steps"] == 4
 
 
+@pytest.fixture(scope="module")
+def lambda_cli_index(tmp_path_factory):
+    """The lambda fixture indexed by salt-idx (the committed index lacks the 64 MiB .C.lkt)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prefix = str(tmp_path_factory.mktemp("lamidx") / "idx")
+    subprocess.run([os.path.join(root, "salt_amd", "bin", "salt-idx"), "-k", "19", os.path.join(LAMBDA, "genome.fa"), os.path.join(LAMBDA, "snps.txt"), prefix],
+                   check=True, stderr=subprocess.DEVNULL)
+    return prefix
+
+
 @pytest.mark.parametrize("case", ["se_default", "se_r1_m500", "se_refonly", "se_r5_s4_m16", "se_plain_t4"])
-def test_cli_text_path_and_host_pipeline_give_the_reference_sam(case, tmp_path):
+def test_cli_text_path_and_host_pipeline_give_the_reference_sam(case, lambda_cli_index, tmp_path):
     """The two SE pipelines of `salt` against the reference's SAM: the text path (FASTQ parsed and SAM formatted by kernels; here with
     chunks of a few KB so that hundreds of chunk boundaries fall inside records, to a pipe and to a regular file = parallel pwrite) and
     the host pipeline (SALT_HOST_PIPELINE=1: the parser that also reads gzip / multi-line records)."""
@@ -669,7 +679,7 @@ def test_cli_text_path_and_host_pipeline_give_the_reference_sam(case, tmp_path):
     args = read_cases()[case]
     want = open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
     strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
-    cmd = [salt] + args + [os.path.join(LAMBDA, "idx"), os.path.join(LAMBDA, "reads_se.fq")]
+    cmd = [salt] + args + [lambda_cli_index, os.path.join(LAMBDA, "reads_se.fq")]
     for env in (dict(os.environ, SALT_CHUNK_BYTES="3001"), dict(os.environ, SALT_CHUNK_BYTES="70000"), dict(os.environ, SALT_HOST_PIPELINE="1")):
         out = subprocess.run(cmd, capture_output=True, env=env)
         assert out.returncode == 0, out.stderr[-400:]
@@ -683,14 +693,14 @@ def test_cli_text_path_and_host_pipeline_give_the_reference_sam(case, tmp_path):
     assert strip(open(f, "rb").read()) == want
 
 
-def test_cli_text_path_reads_crlf_and_a_last_record_without_newline(tmp_path):
+def test_cli_text_path_reads_crlf_and_a_last_record_without_newline(lambda_cli_index, tmp_path):
     """CRLF line ends and a file that ends without a newline, through the text path (chunked) and the host pipeline alike."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     salt = os.path.join(root, "salt_amd", "bin", "salt")
     src = open(os.path.join(LAMBDA, "reads_se.fq"), "rb").read().splitlines()[:800]
     fq = tmp_path / "crlf.fq"
     fq.write_bytes(b"\r\n".join(src))                      # no newline after the last quality line
-    cmd = [salt, "-d", "-c", os.path.join(LAMBDA, "idx"), str(fq)]
+    cmd = [salt, "-d", "-c", lambda_cli_index, str(fq)]
     strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
     a = subprocess.run(cmd, capture_output=True, env=dict(os.environ, SALT_CHUNK_BYTES="4000"))
     b = subprocess.run(cmd, capture_output=True, env=dict(os.environ, SALT_HOST_PIPELINE="1"))
