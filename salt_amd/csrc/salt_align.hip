@@ -454,7 +454,7 @@ struct LvTables { short L[LVK][64]; char A[LVK][64]; };
 static constexpr int LLV_K = 12;                 // handles k <= 12 (reads up to 129 bp at k = L/10)
 static constexpr int LLV_TW = 22;                // words per lane: up to 168 text nibbles (+1 pad word): reads up to 164 bases
 static constexpr int LLV_W = 2 * LLV_K + 3;      // diagonals -k-1 .. k+1
-static constexpr int LLV_N = 32;                 // candidates per round (lanes 0..31)
+static constexpr int LLV_N = 64;                 // candidates per round: one per lane
 struct LaneLv { uint32_t T[LLV_N * LLV_TW]; uint8_t rows[2][LLV_W][LLV_N]; };
 struct LvBytes { uint8_t T[MAXL + 4 + 64]; uint8_t P[MAXL + 64]; };
 struct WaveLds {                                 // ~10.7 KB: 14-15 one-wave blocks per CU

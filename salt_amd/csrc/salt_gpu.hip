@@ -285,7 +285,7 @@ extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint
         // Half of that by default: the persistent kernels are latency bound, so alone they lose 3 % with 6 waves per CU instead of
         // 12, while the kernels of the other batches in flight (other workspaces / streams) find room: +8 % on the 4-stream step
         // (measured: 3 -> 670, 4 -> 693, 6 -> 705, 8 -> 686, 12 -> 654 Mreads/s)
-        if (per_cu > 6) per_cu = 6;
+        if (per_cu > 8) per_cu = 8;
         if (const char *e2 = getenv("SALT_GPU_HEAVY_PER_CU")) { int v = atoi(e2); if (v > 0 && (uint32_t)v <= heavy_blocks_per_cu()) per_cu = (uint32_t)v; }
         ws->heavy_blocks = (uint32_t)prop.multiProcessorCount * per_cu;    // persistent one-wave blocks
         CHKW(hipMalloc(&ws->d_lvtab, (uint64_t)ws->heavy_blocks * lv_table_bytes()));
