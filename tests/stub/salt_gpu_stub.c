@@ -1,0 +1,91 @@
+/* tests/stub/salt_gpu_stub.c -- TEST INFRASTRUCTURE: a stand-in for libsalt_gpu.so without a GPU, so that the host side of the `salt`
+ * binary (option handling, dealing of chunks to the workers of several "GPUs", ordered output) can be tested in the build container.
+ * Device d is a label; the per-batch work is done by the CPU oracle (oracle/salt_oracle.c, linked in) and its own SAM writer.
+ * Only the entry points the text path of `salt` uses are real; the others fail loudly.  Never shipped, never loaded by salt_amd/. */
+#include "../../include/salt_gpu.h"
+#include "../../oracle/salt_oracle.h"
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct salt_gpu_index { int device; so_index_t *ora; int owner; };
+struct salt_gpu_ws { struct salt_gpu_index *ix; char *sam; size_t cap; };
+static __thread char g_err[256];
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+
+const char *salt_gpu_last_error(void) { return g_err; }
+static int fail(const char *m) { snprintf(g_err, sizeof g_err, "stub: %s", m); return SALT_E_INVAL; }
+
+int salt_gpu_index_attach(const salt_host_index_t *h, int device, salt_gpu_index_t **out)
+{
+    (void)h;
+    const char *p = getenv("SALT_STUB_PREFIX");
+    if (!p) return fail("SALT_STUB_PREFIX is not set");
+    struct salt_gpu_index *ix = calloc(1, sizeof *ix);
+    ix->device = device; ix->ora = so_index_load(p); ix->owner = 1;
+    if (!ix->ora) { free(ix); return fail("cannot load the index for the oracle"); }
+    *out = ix;
+    return SALT_OK;
+}
+int salt_gpu_index_replicate(salt_gpu_index_t *src, const int *devices, int n, salt_gpu_index_t **out)
+{
+    out[0] = src;
+    for (int i = 1; i < n; ++i) { struct salt_gpu_index *ix = calloc(1, sizeof *ix); ix->device = devices[i]; ix->ora = src->ora; ix->owner = 0; out[i] = ix; }
+    return SALT_OK;
+}
+void salt_gpu_index_detach(salt_gpu_index_t *ix) { if (!ix) return; if (ix->owner) so_index_free(ix->ora); free(ix); }
+int salt_gpu_index_set_pac(salt_gpu_index_t *ix, const uint8_t *pac, uint64_t l_pac) { (void)ix; (void)pac; (void)l_pac; return SALT_OK; }
+int salt_gpu_index_set_contigs(salt_gpu_index_t *ix, int32_t n, const int64_t *offsets, const char *const *names) { (void)ix; (void)n; (void)offsets; (void)names; return SALT_OK; }
+int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint64_t max_bases, salt_gpu_ws_t **out)
+{
+    (void)max_reads; (void)max_bases;
+    struct salt_gpu_ws *ws = calloc(1, sizeof *ws); ws->ix = ix; *out = ws; return SALT_OK;
+}
+void salt_gpu_ws_destroy(salt_gpu_ws_t *ws) { if (ws) { free(ws->sam); free(ws); } }
+int salt_gpu_host_alloc(uint64_t bytes, void **ptr) { *ptr = malloc(bytes); return *ptr ? SALT_OK : SALT_E_NOMEM; }
+void salt_gpu_host_free(void *ptr) { free(ptr); }
+int salt_gpu_align_se(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint32_t n, const uint8_t *s, const uint32_t *f, salt_result_t *r)
+{ (void)ws; (void)o; (void)n; (void)s; (void)f; (void)r; return fail("salt_gpu_align_se is not part of the stub"); }
+int salt_gpu_align_pe(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_pe_opt_t *pe, uint32_t n, const uint8_t *s, const uint32_t *f, salt_result_t *r)
+{ (void)ws; (void)o; (void)pe; (void)n; (void)s; (void)f; (void)r; return fail("salt_gpu_align_pe is not part of the stub"); }
+
+static uint8_t nt4(int c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
+
+int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_text_opt_t *to, const char *fq, uint64_t n_bytes,
+                           const char **sam, uint64_t *sam_bytes, uint32_t *n_reads)
+{
+    *sam = NULL; *sam_bytes = 0; *n_reads = 0;
+    if (n_bytes == 0) return SALT_OK;
+    if (fq[n_bytes - 1] != '\n') return fail("block must end with a newline");
+    so_opt_t so; so_opt_default(ws->ix->ora, &so);
+    so.l_overlap = o->l_overlap; so.max_seed = o->max_seed; so.max_locate = o->max_locate; so.seed_only_ref = o->seed_only_ref;
+    so.print_xa_cigar = to->print_xa_cigar; so.print_nm_md = to->print_nm_md; so.rg_id = to->rg_id;
+    size_t used = 0; uint32_t n = 0;
+    uint64_t p = 0;
+    while (p < n_bytes) {
+        const char *l[5]; l[0] = fq + p;
+        for (int k = 1; k <= 4; ++k) { const char *nl = memchr(l[k - 1], '\n', (size_t)(fq + n_bytes - l[k - 1])); if (!nl) return fail("block does not hold whole 4-line records"); l[k] = nl + 1; }
+        if (l[0][0] != '@' || l[2][0] != '+') return fail("not 4-line FASTQ");
+        char name[512]; size_t nl_ = 0;
+        for (const char *c = l[0] + 1; c < l[1] - 1 && *c != ' ' && !(*c >= 9 && *c <= 13) && nl_ < sizeof name - 1; ++c) name[nl_++] = *c;
+        if (nl_ > 2 && name[nl_ - 2] == '/' && name[nl_ - 1] >= '0' && name[nl_ - 1] <= '9') nl_ -= 2;
+        name[nl_] = 0;
+        size_t L = (size_t)(l[2] - 1 - l[1]); while (L && l[1][L - 1] == '\r') --L;
+        uint8_t seq[4096]; char qual[4097];
+        if (L == 0 || L >= sizeof seq) return fail("read length outside the stub's range");
+        for (size_t i = 0; i < L; ++i) { seq[i] = nt4((unsigned char)l[1][i]); qual[i] = l[3][i]; }
+        qual[L] = 0;
+        so_result_t res;
+        so_align_se1(ws->ix->ora, &so, seq, (int)L, &res, NULL);
+        if (used + 8 * L + 8192 > ws->cap) { ws->cap = (used + 8 * L + 8192) * 2; ws->sam = realloc(ws->sam, ws->cap); }
+        int w = so_sam_se(ws->ix->ora, &so, name, seq, (int)L, qual, &res, ws->sam + used, ws->cap - used);
+        if (w < 0) return fail("SAM record too long");
+        used += (size_t)w; ws->sam[used++] = '\n';
+        ++n; p = (uint64_t)(l[4] - fq);
+    }
+    const char *log = getenv("SALT_STUB_LOG");
+    if (log) { pthread_mutex_lock(&g_mu); FILE *f = fopen(log, "a"); if (f) { fprintf(f, "%d %u\n", ws->ix->device, n); fclose(f); } pthread_mutex_unlock(&g_mu); }
+    *sam = ws->sam; *sam_bytes = used; *n_reads = n;
+    return SALT_OK;
+}
