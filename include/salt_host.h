@@ -87,6 +87,15 @@ int salt_idx_build_mem(const salt_idx_contig_t *contigs, int n_contigs, const sa
 int salt_idx_suffix_array_cpu(const uint8_t *text, uint64_t n, int bits, uint32_t *sa_out);
 const char *salt_idx_last_error(void);
 
+/* N3 -- insert-size window from the first batch of a paired-end run (`salt -p -b 0`; the reference prints "infer isize func haven't
+ * been implemented" there and stops, Align_src/alnpe.c:586-589, so the definition is this build's; oracle/salt_oracle.c states it).
+ * res: the 2 * n_pairs mates (pair i = rows 2i, 2i+1) aligned as SINGLE-END reads (salt_gpu_align_se).  A pair counts when both mates
+ * map gap-free without alternative hits, on opposite strands of one sequence, forward mate first, template <= 100000; from the
+ * sorted templates: quartiles, mean / sd inside [q1 - 2 iqr, q3 + 2 iqr] (integers, sd rounded up), window = mean -+ 4 sd widened
+ * to [q1 - 3 iqr, q3 + 3 iqr].  Returns 0, or -1 when fewer than 25 pairs count (*n_used tells how many did). */
+int salt_isize_infer(const salt_index_t *ix, uint32_t n_pairs, const uint32_t *offs, const salt_result_t *res,
+                     uint32_t *min_tlen, uint32_t *max_tlen, uint32_t *n_used);
+
 /* "<len><op>..." text of a binary CIGAR (ops as in salt_result_t); returns bytes written or -1 */
 int salt_cigar_text(const uint16_t *ops, int n_ops, char *buf, size_t cap);
 

@@ -1685,3 +1685,69 @@ int so_ssw_unit(int aware, const uint8_t *ref_syms, int refLen, const uint8_t *c
     free(ref); free(read);
     return res.n_cigar;
 }
+
+/* ---- N3: insert-size window inferred from the first batch -----------------------------------------------------------------
+ * The reference has no such function: `-b 0` makes alnpe_core print "infer isize func haven't been implemented" and stop
+ * (Align_src/alnpe.c:586-589).  DEFINITION (ours, deterministic, integer arithmetic only; restated independently in
+ * salt_amd/host/salt_host.cc):
+ *   pairs used   the mates of the first batch are aligned one by one as single-end reads (alnse_overlap_alt + query_set_hits); a pair
+ *                counts when both mates are mapped gap-free, neither has an alternative hit, they lie on opposite strands of the same
+ *                sequence with the forward mate first, and the template t = pos(reverse) + L(reverse) - pos(forward) is <= 100000
+ *   estimate     t sorted; q1 = t[n/4], q3 = t[3n/4], iqr = q3 - q1; over the values inside [q1 - 2 iqr, q3 + 2 iqr]: mean (rounded) and
+ *                sd (square root of the integer variance, rounded up); window = [mean - 4 sd, mean + 4 sd], widened to
+ *                [q1 - 3 iqr, q3 + 3 iqr] where that reaches further; lower end at least 1.  Fewer than 25 usable pairs: no estimate. */
+static int cmp_tlen(const void *a, const void *b) { uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b; return x < y ? -1 : x > y; }
+int so_isize_estimate(uint32_t *t, int n, uint32_t *min_tlen, uint32_t *max_tlen)
+{
+    if (n < 25) return -1;
+    qsort(t, (size_t)n, sizeof *t, cmp_tlen);
+    const uint64_t q1 = t[n / 4], q3 = t[(size_t)3 * n / 4], iqr = q3 - q1;
+    const uint64_t lo = q1 > 2 * iqr ? q1 - 2 * iqr : 0, hi = q3 + 2 * iqr;
+    uint64_t m = 0, sum = 0; int i;
+    for (i = 0; i < n; ++i) if (t[i] >= lo && t[i] <= hi) { ++m; sum += t[i]; }
+    const uint64_t mean = (sum + m / 2) / m;
+    uint64_t var = 0;
+    for (i = 0; i < n; ++i) if (t[i] >= lo && t[i] <= hi) { const uint64_t d = t[i] > mean ? t[i] - mean : mean - t[i]; var += d * d; }
+    var /= m;
+    uint64_t sd = 0;
+    while ((sd + 1) * (sd + 1) <= var) ++sd;
+    if (sd * sd < var) ++sd;
+    uint64_t a = mean > 4 * sd ? mean - 4 * sd : 1, b = mean + 4 * sd;
+    const uint64_t a2 = q1 > 3 * iqr ? q1 - 3 * iqr : 1, b2 = q3 + 3 * iqr;
+    if (a2 < a) a = a2;
+    if (b2 > b) b = b2;
+    if (a < 1) a = 1;
+    *min_tlen = (uint32_t)a; *max_tlen = (uint32_t)b;
+    return 0;
+}
+/* the templates of the usable pairs of a batch (mates interleaved: pair i = reads 2i, 2i+1, already aligned as single-end reads) */
+int so_isize_templates(const so_index_t *ix, int n_pairs, const uint32_t *offs, const so_result_t *res, uint32_t *t_out)
+{
+    int n = 0, i;
+    for (i = 0; i < n_pairs; ++i) {
+        const so_result_t *a = res + 2 * i, *b = a + 1;
+        if (a->pos == 0xFFFFFFFFu || b->pos == 0xFFFFFFFFu || a->is_gap != 0 || b->is_gap != 0) continue;
+        if (a->n_hits[0] + a->n_hits[1] + b->n_hits[0] + b->n_hits[1] != 0) continue;
+        if (a->strand == b->strand || a->strand > 1 || b->strand > 1) continue;
+        const so_result_t *f = a->strand == 0 ? a : b, *r = a->strand == 0 ? b : a;
+        const uint32_t lr = r == a ? offs[2 * i + 1] - offs[2 * i] : offs[2 * i + 2] - offs[2 * i + 1];
+        if (r->pos < f->pos) continue;
+        if (coor_rid(ix, f->pos) != coor_rid(ix, r->pos)) continue;
+        const uint64_t t = (uint64_t)r->pos + lr - f->pos;
+        if (t > 100000) continue;
+        t_out[n++] = (uint32_t)t;
+    }
+    return n;
+}
+int so_infer_isize(const so_index_t *ix, const so_opt_t *o, int n_pairs, const uint8_t *seqs, const uint32_t *offs, int n_threads,
+                   uint32_t *min_tlen, uint32_t *max_tlen, int *n_used)
+{
+    so_result_t *res = xcalloc((size_t)2 * n_pairs, sizeof *res);
+    uint32_t *t = xcalloc((size_t)n_pairs + 1, sizeof *t);
+    so_align_se_batch(ix, o, 2 * n_pairs, seqs, offs, res, n_threads, NULL);
+    const int n = so_isize_templates(ix, n_pairs, offs, res, t);
+    if (n_used) *n_used = n;
+    const int rc = so_isize_estimate(t, n, min_tlen, max_tlen);
+    free(res); free(t);
+    return rc;
+}

@@ -113,6 +113,12 @@ void so_align_pe_batch(const so_index_t *, const so_opt_t *, uint32_t min_tlen, 
                        const uint32_t *offs, so_result_t *res, int n_threads);
 void so_index_arrays(const so_index_t *, so_arrays_t *);
 
+/* N3: insert-size window from the first batch (definition in salt_oracle.c; the reference prints "not implemented", alnpe.c:586-589) */
+int so_isize_estimate(uint32_t *t, int n, uint32_t *min_tlen, uint32_t *max_tlen);      /* sorts t; -1 when n < 25 */
+int so_isize_templates(const so_index_t *, int n_pairs, const uint32_t *offs, const so_result_t *res, uint32_t *t_out);
+int so_infer_isize(const so_index_t *, const so_opt_t *, int n_pairs, const uint8_t *seqs, const uint32_t *offs, int n_threads,
+                   uint32_t *min_tlen, uint32_t *max_tlen, int *n_used);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,33 @@ int main(int argc, char **argv)
         if (!f1 || !f2) { fprintf(stderr, "[salt_oracle] cannot open read files\n"); return 1; }
         static char l1[1 << 16], l2[1 << 16];
         char *hdr = malloc(1 << 20), *sam = malloc(1 << 17);
+        if (max_tlen == 0) {                                    /* N3: -b 0 = infer the window from the first batch (N_SEQS / 2 pairs, aln.h:27) */
+            gzFile g1 = gzopen(argv[optind + 1], "r"), g2 = gzopen(argv[optind + 2], "r");
+            const int MAXP = 50000; int np = 0; size_t cap = 1 << 24, at = 0;
+            uint8_t *bs = malloc(cap); uint32_t *bo = malloc(4 * (2 * (size_t)MAXP + 1));
+            bo[0] = 0;
+            while (np < MAXP) {
+                gzFile gg[2] = { g1, g2 }; int k, okp = 1;
+                for (k = 0; k < 2 && okp; ++k) {
+                    if (!gets_trim(gg[k], l1, 1 << 16) || !gets_trim(gg[k], l1, 1 << 16)) { okp = 0; break; }
+                    const size_t L = strlen(l1);
+                    if (at + L > cap) { cap = 2 * (at + L); bs = realloc(bs, cap); }
+                    for (size_t i = 0; i < L; ++i) bs[at + i] = nt4(l1[i]);
+                    at += L; bo[2 * np + k + 1] = (uint32_t)at;
+                    if (!gets_trim(gg[k], l1, 1 << 16) || !gets_trim(gg[k], l1, 1 << 16)) { okp = 0; break; }
+                }
+                if (!okp) break;
+                ++np;
+            }
+            gzclose(g1); gzclose(g2);
+            int used = 0;
+            if (np == 0 || so_infer_isize(ix, &o, np, bs, bo, n_threads, &min_tlen, &max_tlen, &used) != 0) {
+                fprintf(stderr, "[alnpe_core]: cannot infer the insert size: %d usable pairs in the first batch (25 needed); give -a / -b\n", used);
+                return 1;
+            }
+            fprintf(stderr, "[alnpe_core]: insert size window [%u, %u] inferred from %d pairs\n", min_tlen, max_tlen, used);
+            free(bs); free(bo);
+        }
         if (so_sam_header(ix, &o, hdr, 1 << 20) < 0) return 1;
         fputs(hdr, stdout);
         for (;;) {

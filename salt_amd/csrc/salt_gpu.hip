@@ -322,7 +322,7 @@ static int check_opt(const salt_gpu_index *ix, const salt_aln_opt_t *o, uint32_t
     if (max_len > SALT_MAX_READ_LEN) return fail(SALT_E_INVAL, "read longer than SALT_MAX_READ_LEN (512)");
     uint32_t spr = 1;
     if (max_len >= (uint32_t)o->l_seed) spr = (max_len - (uint32_t)o->l_seed) / (uint32_t)o->l_overlap + 1;
-    if (spr > SALT_MAX_SEED_SLOTS) return fail(SALT_E_INVAL, "more than 128 seeds per strand: raise -r or shorten the reads");
+    if (spr > SALT_MAX_SEED_SLOTS) return fail(SALT_E_INVAL, "more seeds per strand than SALT_MAX_SEED_SLOTS (512): raise -r or shorten the reads");
     *spr_out = spr;
     return SALT_OK;
 }

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <fstream>
 #include <sstream>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -283,6 +284,44 @@ void put_md_nm(Out &o, const salt_index *ix, const uint8_t *sq, const salt_resul
 }
 
 } // namespace
+
+extern "C" int salt_isize_infer(const salt_index_t *ix, uint32_t n_pairs, const uint32_t *offs, const salt_result_t *res,
+                                uint32_t *min_tlen, uint32_t *max_tlen, uint32_t *n_used)
+{
+    std::vector<uint32_t> t;
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+        const salt_result_t &a = res[2 * (size_t)i], &b = res[2 * (size_t)i + 1];
+        if (a.skipped || b.skipped || a.pos == 0xFFFFFFFFu || b.pos == 0xFFFFFFFFu || a.is_gap || b.is_gap) continue;
+        if (a.n_hits[0] || a.n_hits[1] || b.n_hits[0] || b.n_hits[1]) continue;
+        if (a.strand > 1 || b.strand > 1 || a.strand == b.strand) continue;
+        const bool a_fwd = a.strand == 0;
+        const salt_result_t &f = a_fwd ? a : b, &r = a_fwd ? b : a;
+        const uint32_t len_r = a_fwd ? offs[2 * (size_t)i + 2] - offs[2 * (size_t)i + 1] : offs[2 * (size_t)i + 1] - offs[2 * (size_t)i];
+        if (r.pos < f.pos || seq_id(ix, f.pos) != seq_id(ix, r.pos)) continue;
+        const uint64_t tl = (uint64_t)r.pos + len_r - f.pos;
+        if (tl <= 100000) t.push_back((uint32_t)tl);
+    }
+    if (n_used) *n_used = (uint32_t)t.size();
+    const size_t n = t.size();
+    if (n < 25) return -1;
+    std::sort(t.begin(), t.end());
+    const uint64_t q1 = t[n / 4], q3 = t[3 * n / 4], iqr = q3 - q1;
+    const uint64_t lo = q1 > 2 * iqr ? q1 - 2 * iqr : 0, hi = q3 + 2 * iqr;
+    uint64_t m = 0, sum = 0;
+    for (uint32_t v : t) if (v >= lo && v <= hi) { ++m; sum += v; }
+    const uint64_t mean = (sum + m / 2) / m;
+    uint64_t var = 0;
+    for (uint32_t v : t) if (v >= lo && v <= hi) { const uint64_t d = v > mean ? v - mean : mean - v; var += d * d; }
+    var /= m;
+    uint64_t sd = 0;
+    while ((sd + 1) * (sd + 1) <= var) ++sd;                  // floor(sqrt(var)) ...
+    if (sd * sd < var) ++sd;                                  // ... rounded up
+    uint64_t wa = mean > 4 * sd ? mean - 4 * sd : 1, wb = mean + 4 * sd;
+    wa = std::min<uint64_t>(wa, q1 > 3 * iqr ? q1 - 3 * iqr : 1);
+    wb = std::max<uint64_t>(wb, q3 + 3 * iqr);
+    *min_tlen = (uint32_t)std::max<uint64_t>(wa, 1); *max_tlen = (uint32_t)wb;
+    return 0;
+}
 
 extern "C" int salt_cigar_text(const uint16_t *ops, int n_ops, char *buf, size_t cap)
 {

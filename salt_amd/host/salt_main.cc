@@ -556,6 +556,35 @@ int main(int argc, char **argv)
             return rc;
         }
     }
+    if (pe && po.max_tlen == 0) {
+        // N3: -b 0 = infer the insert-size window from the first batch (N_SEQS / 2 pairs), the mates aligned as single-end reads
+        // (salt_isize_infer; the reference prints "infer isize func haven't been implemented" here, alnpe.c:586-589)
+        gzFile g1 = gzopen(fn_reads, "r"), g2 = gzopen(fn_mates, "r");
+        if (!g1 || !g2) { fprintf(stderr, "[query_open]: file %s open fail!\n", g1 ? fn_mates : fn_reads); return 1; }
+        RawReader r1(g1, !sniff_four_line(fn_reads)), r2(g2, !sniff_four_line(fn_mates));
+        Batch b1, b2; Pool pool(n_threads < 16 ? n_threads : 16);
+        const int got = r1.take(b1.raw, N_SEQS / 2, b1.rec);
+        if (got == 0 || r2.take(b2.raw, got, b2.rec) != got) { fprintf(stderr, "[salt] the two read files hold different numbers of reads\n"); return 1; }
+        parse_batch(b1.raw, b1, pool); parse_batch(b2.raw, b2, pool);
+        std::vector<uint8_t> iseq(b1.seqs.size() + b2.seqs.size()); std::vector<uint32_t> ioff(2 * (size_t)got + 1, 0);
+        for (int i = 0; i < got; ++i) {
+            const uint32_t l0 = b1.offs[(size_t)i + 1] - b1.offs[(size_t)i], l1 = b2.offs[(size_t)i + 1] - b2.offs[(size_t)i];
+            memcpy(iseq.data() + ioff[2 * (size_t)i], b1.seqs.data() + b1.offs[(size_t)i], l0); ioff[2 * (size_t)i + 1] = ioff[2 * (size_t)i] + l0;
+            memcpy(iseq.data() + ioff[2 * (size_t)i + 1], b2.seqs.data() + b2.offs[(size_t)i], l1); ioff[2 * (size_t)i + 2] = ioff[2 * (size_t)i + 1] + l1;
+        }
+        gzclose(g1); gzclose(g2);
+        salt_gpu_ws_t *w0 = nullptr;
+        std::vector<salt_result_t> r((size_t)2 * got);
+        if (salt_gpu_ws_create(gix[0], (uint32_t)(2 * got), (uint64_t)iseq.size() + 64, &w0) ||
+            salt_gpu_align_se(w0, &ao, (uint32_t)(2 * got), iseq.data(), ioff.data(), r.data())) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
+        salt_gpu_ws_destroy(w0);
+        uint32_t used = 0;
+        if (salt_isize_infer(ix, (uint32_t)got, ioff.data(), r.data(), &po.min_tlen, &po.max_tlen, &used)) {
+            fprintf(stderr, "[alnpe_core]: cannot infer the insert size: %u usable pairs in the first batch (25 needed); give -a / -b\n", used);
+            return 1;
+        }
+        fprintf(stderr, "[alnpe_core]: insert size window [%u, %u] inferred from %u pairs\n", po.min_tlen, po.max_tlen, used);
+    }
     // workers per GPU: each takes a batch through parse -> device -> format, so several batches overlap on the host
     const int WPG = n_threads / n_gpus >= 32 ? 4 : n_threads / n_gpus >= 12 ? 3 : 2;
     std::vector<salt_gpu_ws_t *> ws((size_t)n_gpus * WPG, nullptr);

@@ -323,7 +323,7 @@ def test_gpu_verifiers_never_dereference_a_wrapped_locate(mode):
 
 
 def test_gpu_rejects_what_it_cannot_do():
-    """Loud errors instead of silent fallbacks: -m above 1024, reads above 512 bp, too many seed slots."""
+    """Loud errors instead of silent fallbacks: -m above 1024, reads above 512 bp."""
     import salt_amd
     idx = salt_amd.Index.reload(os.path.join(LAMBDA, "idx"))
     aln = salt_amd.GpuAligner(idx, device=0, max_reads=8, max_bases=8192)
@@ -332,10 +332,23 @@ def test_gpu_rejects_what_it_cannot_do():
         aln.alnse_core1(salt_amd.AlnOpt(l_seed=idx.l_seed), seq, np.array([0, 600], dtype=np.uint32))
     with pytest.raises(salt_amd.SaltError):
         aln.alnse_core1(salt_amd.AlnOpt(l_seed=idx.l_seed, max_locate=5000), seq[:100], np.array([0, 100], dtype=np.uint32))
-    with pytest.raises(salt_amd.SaltError):
-        aln.alnse_core1(salt_amd.AlnOpt(l_seed=idx.l_seed, l_overlap=1), seq[:300], np.array([0, 300], dtype=np.uint32))
     aln.close()
     idx.destroy()
+
+
+def test_gpu_stride_one_seeding_on_long_reads_matches_oracle():
+    """-r 1 on reads of 150 ... 300 bases: up to 282 seed slots per strand (the first round stopped at 128), with -m 500 and the
+    default cap: every field against the oracle."""
+    import salt_amd
+    names, seqs, offs, quals = salt_amd.read_fastq(os.path.join(LAMBDA, "reads_ragged.fq"))
+    lens = np.diff(offs.astype(np.int64))
+    sel = [i for i in range(len(lens)) if lens[i] >= 150][:120]
+    assert len(sel) >= 60 and max(lens[sel]) >= 290
+    rs = [seqs[offs[i]:offs[i + 1]] for i in sel]
+    o = np.zeros(len(rs) + 1, dtype=np.uint32); o[1:] = np.cumsum([len(r) for r in rs])
+    for optargs in (["-r", "1"], ["-r", "1", "-m", "500", "-s", "10"], ["-r", "2", "-v"]):
+        res, want, bad = _oracle_compare(os.path.join(LAMBDA, "idx"), np.concatenate(rs), o, optargs)
+        assert len(bad) == 0, (optargs, bad[:5])
 
 
 def _sequential_rule(pos, val, bound, vmax, in_range):

@@ -229,3 +229,30 @@ def test_gpu_pe_long_mates_match_oracle(tiny_pe, L, window):
     detail = [(int(i), [(f, res[f][i].tolist(), want[f][i].tolist()) for f in ("pos", "strand", "n_diff", "is_gap", "mapq", "b0", "b1", "seq_start", "seq_end")]) for i in bad[:4]]
     assert len(bad) == 0, (len(bad), detail)
     assert pc[0] > 50 and pc[4] == 0, pc                # rescues ran, none overflowed
+
+
+def test_cli_pe_infers_the_insert_window_like_the_oracle(tmp_path):
+    """`salt -p -b 0`: the window is inferred from the first batch (N3; the reference prints "not implemented" there).  The product CLI and
+    the oracle CLI must announce the same window and print the same SAM."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt, salt_idx = os.path.join(root, "salt_amd", "bin", "salt"), os.path.join(root, "salt_amd", "bin", "salt-idx")
+    oracle = os.path.join(root, "oracle", "salt_oracle")
+    prefix = str(tmp_path / "idx")
+    subprocess.run([salt_idx, "-k", "19", os.path.join(LAMBDA, "genome.fa"), os.path.join(LAMBDA, "snps.txt"), prefix], check=True, stderr=subprocess.DEVNULL)
+    files = [os.path.join(LAMBDA, "reads_pe_1.fq"), os.path.join(LAMBDA, "reads_pe_2.fq")]
+    got = subprocess.run([salt, "-d", "-c", "-p", "-b", "0", prefix] + files, capture_output=True)
+    want = subprocess.run([oracle, "-d", "-c", "-p", "-b", "0", "-t", "8", prefix] + files, capture_output=True)
+    assert got.returncode == 0 and want.returncode == 0, (got.stderr[-300:], want.stderr[-300:])
+    line = lambda err: [l for l in err.decode().splitlines() if "insert size window" in l]
+    assert line(got.stderr) and line(got.stderr) == line(want.stderr), (line(got.stderr), line(want.stderr))
+    strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    assert strip(got.stdout) == strip(want.stdout)
+    # too few pairs: a loud error, not a guess
+    few = []
+    for k, fn in enumerate(files):
+        p = tmp_path / ("few_%d.fq" % k)
+        p.write_bytes(b"".join(open(fn, "rb").readlines()[:40]))
+        few.append(str(p))
+    bad = subprocess.run([salt, "-p", "-b", "0", prefix] + few, capture_output=True)
+    assert bad.returncode == 1 and b"cannot infer the insert size" in bad.stderr
