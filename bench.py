@@ -31,7 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-RANDOM_SECTOR_GBS = 2900.0     # measured: random 64-byte sectors from a 16 GiB table, tools/ubench/gather (profiles/r02/gather_rate.txt: 2.5-3.06 TB/s)
+RANDOM_REQ_GPS = 45.0          # measured: random 64-byte requests per second (in G) the memory system serves from tables of 8-128 GiB,
+                               # tools/ubench/gather (profiles/r02/gather_rate.txt: 38-48 G/s, i.e. 2.4-3.1 TB/s of sectors; 55 G/s from 1-2 GiB)
 SECTOR = 64                    # bytes a random access moves at least (one L2 / fabric sector)
 
 
@@ -276,17 +277,26 @@ def main():
                                         "word pair, 16 B per verify lane-load, packed read records, 32 B per seed interval pair, result rows; counted by the kernels"})
         tr = prof.get("hbm_bytes_per_launch", {}).get(dom)
         roof["traffic"] = tr
+        pk = prof.get("per_kernel_mean", {})
         if tr:
             roof["traffic_GBps"] = round(tr / (serial_kms[dom] / 1e3) / 1e9, 1)
             roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE of profiles/r02 (separate --pmc passes), raw: tools/ubench/gather shows FETCH_SIZE = 64.0 B per random "
                                     "4/16/32/64-byte record, i.e. exact for these gather shapes (no x2 streaming correction applies)")
-            roof["random_sector_ceiling_GBps"] = RANDOM_SECTOR_GBS
-            roof["traffic_frac_of_random_sector_ceiling"] = round(tr / (serial_kms[dom] / 1e3) / 1e9 / RANDOM_SECTOR_GBS, 3)
-            alltr = prof.get("hbm_bytes_per_launch", {})
+        rq = pk.get(dom, {}).get("TCC_EA0_RDREQ_sum")
+        if rq:
+            # what actually limits these kernels: the RATE of random 64-byte requests, not their bytes (a second adjacent sector per window is free)
+            roof["random_requests"] = {"per_launch": int(rq), "G_per_s": round(rq / (serial_kms[dom] / 1e3) / 1e9, 1), "ceiling_G_per_s": RANDOM_REQ_GPS,
+                                       "frac_of_ceiling": round(rq / (serial_kms[dom] / 1e3) / 1e9 / RANDOM_REQ_GPS, 3),
+                                       "whole_step_G_per_s_wall": round(sum(v.get("TCC_EA0_RDREQ_sum", 0) for v in pk.values()) / (dt / args.steps) / 1e9, 1),
+                                       "source": "TCC_EA0_RDREQ_sum per launch (profiles/r02/pmc_tcc_*.csv) / this run's HIP-event time; ceiling: tools/ubench/gather"}
+        alltr = prof.get("hbm_bytes_per_launch", {})
+        if alltr:
             roof["whole_step_traffic_GBps_wall"] = round(sum(alltr.values()) / (dt / args.steps) / 1e9, 1)
         ir = prof.get("issue", {}).get(dom)
         if ir:
             roof["issue_bound"] = ir
+        roof["limiter"] = ("random 64-byte memory requests: the step issues ~95 M of them per 10^6 reads (W-mer gathers, Occ blocks, suffix-array rows, candidate windows) "
+                           "and the chip serves 38-48 G/s at this footprint; bytes (frac of the 8 TB/s peak) and vector issue slots (issue_bound.valu_issue_frac) are far from their limits")
         roof["counters"] = {k: int(v) for k, v in ctr.items() if k.startswith("d_")}
         out["roofline"] = roof
 
