@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-RANDOM_REQ_GPS = 45.0          # measured: random 64-byte requests per second (in G) the memory system serves from tables of 8-128 GiB,
+RANDOM_REQ_GPS = 48.0          # measured: random 64-byte requests per second (in G) the memory system serves from tables of 8-128 GiB,
                                # tools/ubench/gather (profiles/r02/gather_rate.txt: 38-48 G/s, i.e. 2.4-3.1 TB/s of sectors; 55 G/s from 1-2 GiB)
 SECTOR = 64                    # bytes a random access moves at least (one L2 / fabric sector)
 
