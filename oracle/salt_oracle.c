@@ -627,7 +627,7 @@ int so_ed_mismatch(const uint32_t *ref, uint32_t pos, const uint8_t *seq, uint32
 /* V4 / C1: Landau-Vishkin on masks (LandauVishkin.c:19-122, 176-470; editdistance.c:174-284)  */
 /* ------------------------------------------------------------------------------------------ */
 #define LV_MAXK 31
-typedef struct { uint8_t *t, *p; int tlen, plen; } so_lvbuf_t;
+typedef struct { uint8_t *t, *p; int tlen, plen; int eq; } so_lvbuf_t;     /* eq: a base matches when the bytes are EQUAL (polish's stock LV) instead of mask & one-hot != 0 */
 
 /* unpack text masks and one-hot pattern into zero-padded byte buffers (editdistance.c:183-227) */
 static void lv_unpack(const uint32_t *ref, uint32_t pos, uint32_t l_ref, const uint8_t *seq, uint32_t L,
@@ -640,7 +640,7 @@ static void lv_unpack(const uint32_t *ref, uint32_t pos, uint32_t l_ref, const u
     b->t = xcalloc(tcap + 64, 1); b->p = xcalloc(pcap + 64, 1);
     for (i = 0; i < l_ref; ++i) b->t[i] = (uint8_t)ref_nib(ref, pos + i);
     for (i = 0; i < L; ++i) b->p[i] = seq[i] > 3 ? 15 : (uint8_t)(1u << seq[i]);
-    b->tlen = (int)l_ref; b->plen = (int)L;
+    b->tlen = (int)l_ref; b->plen = (int)L; b->eq = 0;
 }
 
 /* length of the matching run that starts at pattern offset `from` on diagonal d, capped at end */
@@ -648,7 +648,8 @@ static inline int lv_run(const so_lvbuf_t *b, int d, int from, int end)
 {
     int i = from;
     if (i >= end) return end;
-    while (i < end && (b->p[i] & b->t[d + i]) != 0) ++i;
+    if (b->eq) while (i < end && b->p[i] == b->t[d + i]) ++i;
+    else while (i < end && (b->p[i] & b->t[d + i]) != 0) ++i;
     return i;
 }
 
@@ -720,6 +721,12 @@ static int lv_cigar(const so_lvbuf_t *b, int k, char *out, int cap)
             }
             L[e][LV_MAXK + d] = (short)best;
             if (best != b->plen) continue;
+            if (b->eq) {                                       /* the stock LV first tries e plain mismatches on diagonal 0 (Polish_src/lv.c:274-296; commented out in Align_src) */
+                int straight = 0, q;
+                for (q = 0; q < end0; ++q) if (b->p[q] != b->t[q]) ++straight;
+                straight += b->plen - end0;
+                if (straight == e) { if (!cig_put(&out, &cap, b->plen, 'M')) return -2; return e; }
+            }
             /* trace back, then emit forward, merging =/X into M */
             int cd = d, ce;
             for (ce = e; ce >= 1; --ce) {
@@ -1750,4 +1757,270 @@ int so_infer_isize(const so_index_t *ix, const so_opt_t *o, int n_pairs, const u
     const int rc = so_isize_estimate(t, n, min_tlen, max_tlen);
     free(res); free(t);
     return rc;
+}
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* N4: polish (Polish_src/polish.c:448-762, samParser.c, lv.c = stock SNAP Landau-Vishkin)      */
+/* ------------------------------------------------------------------------------------------ */
+/* `polish [-s] [-p] <idx> <SAM>`: every record's primary hit and XA hits are re-scored against the 2-bit genome -- plain edit
+ * distance (k = 13) or Smith-Waterman (+2 / -2, gaps 3 / 1) --, the best becomes the record's alignment (MAPQ 60 when it is the
+ * only scored hit, else 0), its CIGAR is generated, and a bare SAM record is printed.  Quirks kept: strtok field splitting (empty
+ * fields vanish); only the FIRST optional field that contains "XA" is read and nothing behind it; the reference window length
+ * shrinks for good once a hit is clipped at the genome end and the window buffer keeps the previous hit's bytes there
+ * (polish.c:84-92, 461-466); an empty line ends the input (samParser.c:87-90); QUAL is followed by a tab in two of its four cases
+ * (polish.c:236-247); isize = |pos0 - pos1|, negative for the mate on the reverse strand; the pair window is fixed at 350..650
+ * (polish.c:148-149).  Reads with bases other than A C G T print "ACGT"[4] or memory past it in the reference: undefined, not
+ * restated (the fixtures and tests leave such reads out). */
+#define PL_UNMAPPED (-100000)
+#define PL_MAX_DISTANCE 13
+typedef struct { char *chrom; uint32_t pos, offset; int score; } pl_hit_t;
+typedef struct { pl_hit_t *a; size_t n, m; } pl_hits_t;
+typedef struct {
+    char *buf, *name, *qual, *seq; int flag, l_seq, strand, primary, b0, b1;
+    uint8_t *nst[2];                         /* [0] the read as sequenced, [1] its reverse complement (after the 0x10 swap) */
+    pl_hits_t h[2];
+    char cigar[1024];
+} pl_sam_t;
+static const int8_t PL_SCORE_MAT[25] = { 2, -2, -2, -2, 0,  -2, 2, -2, -2, 0,  -2, -2, 2, -2, 0,  -2, -2, -2, 2, 0,  0, 0, 0, 0, 0 };
+
+static void pl_push(pl_hits_t *h, char *chrom, uint32_t pos)
+{
+    if (h->n == h->m) { h->m = h->m ? 2 * h->m : 32; h->a = realloc(h->a, h->m * sizeof *h->a); }
+    h->a[h->n].chrom = chrom; h->a[h->n].pos = pos; h->a[h->n].offset = 0; h->a[h->n].score = 0; ++h->n;
+}
+static char *pl_readline(FILE *fp)
+{
+    size_t l = 0, m = 1024; int c;
+    char *line = xcalloc(m, 1);
+    while ((c = fgetc(fp)) != EOF && c != '\n') { if (l + 2 > m) { m *= 2; line = realloc(line, m); } line[l++] = (char)c; }
+    line[l] = 0;
+    return line;
+}
+static pl_sam_t *pl_read(FILE *fp)                            /* sam_readline (samParser.c:84-190) */
+{
+    char *line = pl_readline(fp), *save = NULL;
+    if (line[0] == 0) { free(line); return NULL; }
+    pl_sam_t *s = xcalloc(1, sizeof *s);
+    s->buf = line;
+    s->name = strtok_r(line, "\t", &save);
+    s->flag = atoi(strtok_r(NULL, "\t", &save));
+    char *chrom = strtok_r(NULL, "\t", &save);
+    uint32_t pos = (uint32_t)strtoul(strtok_r(NULL, "\t", &save), NULL, 10);
+    if ((s->flag & 4) == 0 && strcmp(chrom, "*") != 0) pl_push(&s->h[(s->flag & 0x10) ? 1 : 0], chrom, pos);
+    strtok_r(NULL, "\t", &save);                              /* MAPQ */
+    strtok_r(NULL, "\t", &save);                              /* CIGAR */
+    strtok_r(NULL, "\t", &save); strtok_r(NULL, "\t", &save); strtok_r(NULL, "\t", &save);      /* MRNM MPOS ISIZE */
+    s->seq = strtok_r(NULL, "\t", &save); s->l_seq = (int)strlen(s->seq);
+    s->b0 = s->b1 = PL_UNMAPPED;
+    uint8_t *f = xcalloc((size_t)(s->l_seq + 15) / 8 * 8 + 8, 1), *r = xcalloc((size_t)(s->l_seq + 15) / 8 * 8 + 8, 1);
+    int i;
+    for (i = 0; i < s->l_seq; ++i) { int c = s->seq[i]; f[i] = c == 'A' || c == 'a' ? 0 : c == 'C' || c == 'c' ? 1 : c == 'G' || c == 'g' ? 2 : c == 'T' || c == 't' ? 3 : c == '-' ? 5 : 4; }
+    for (i = 0; i < s->l_seq; ++i) r[i] = (uint8_t)(3 - f[s->l_seq - i - 1]);
+    if (s->flag & 0x10) { s->nst[0] = r; s->nst[1] = f; } else { s->nst[0] = f; s->nst[1] = r; }
+    s->qual = strtok_r(NULL, "\t", &save);
+    char *opt = strtok_r(NULL, "\t", &save);
+    while (opt) {
+        if (strstr(opt, "XA")) {                             /* "XA:Z:chr,+pos,cigar,nd;..." -- nothing behind this field is looked at */
+            char *sv2 = NULL, *multi = strtok_r(opt, ":", &sv2);
+            multi = strtok_r(NULL, ":", &sv2); multi = strtok_r(NULL, ":", &sv2);
+            while (multi && *multi) {
+                char *semi = strchr(multi, ';');
+                if (semi) *semi = 0;
+                size_t l_aln = strlen(multi);
+                if (l_aln == 0) break;
+                char *sv3 = NULL, *achrom = strtok_r(multi, ",", &sv3), *apos = strtok_r(NULL, ",", &sv3);
+                if (apos[0] != '-') pl_push(&s->h[0], achrom, (uint32_t)strtoul(apos, NULL, 10));
+                else pl_push(&s->h[1], achrom, (uint32_t)strtoul(apos + 1, NULL, 10));
+                if (!semi) break;
+                multi += l_aln + 1;
+            }
+            break;
+        }
+        opt = strtok_r(NULL, "\t", &save);
+    }
+    return s;
+}
+static void pl_free(pl_sam_t *s) { if (!s) return; free(s->h[0].a); free(s->h[1].a); free(s->nst[0]); free(s->nst[1]); free(s->buf); free(s); }
+static int pl_cmp_hit(const void *a, const void *b) { uint32_t x = ((const pl_hit_t *)a)->offset, y = ((const pl_hit_t *)b)->offset; return x < y ? -1 : x > y; }
+static int pl_tid(const so_index_t *ix, const char *chrom)
+{
+    int i;
+    for (i = 0; i < ix->n_seqs; ++i) if (strcmp(ix->anns[i].name, chrom) == 0) return i;
+    fprintf(stderr, "[polish] unknown sequence %s\n", chrom); exit(1);
+}
+/* __get_refseq (polish.c:84-92): l bases from the 2-bit genome, clipped at its end; bytes behind the clipped length keep what they held */
+static int pl_refseq(uint8_t *buf, int l, const so_index_t *ix, uint32_t start)
+{
+    int i;
+    if ((int64_t)start > ix->l_pac) { fprintf(stderr, "[Error]: Out of reference length!\n"); exit(1); }
+    if ((int64_t)start + l > ix->l_pac) l = (int)(ix->l_pac - (int64_t)start);
+    for (i = 0; i < l; ++i) buf[i] = (uint8_t)pac_base(ix->pac, start + (uint32_t)i);
+    return l;
+}
+/* all hits of one record: offsets, sort, unique, scores (polish.c:461-497 / 690-713) */
+static void pl_score_hits(const so_index_t *ix, pl_sam_t *s, int use_sw)
+{
+    int l_ref = s->l_seq, i; size_t j;
+    uint8_t *ref = xcalloc((size_t)(s->l_seq + 15) / 8 * 8 + 64, 1);
+    for (i = 0; i < 2; ++i) {
+        pl_hits_t *h = &s->h[i];
+        for (j = 0; j < h->n; ++j) h->a[j].offset = (uint32_t)ix->anns[pl_tid(ix, h->a[j].chrom)].offset + h->a[j].pos - 1;
+        qsort(h->a, h->n, sizeof *h->a, pl_cmp_hit);          /* equal offsets are equal hits: the sort's stability does not matter */
+        if (h->n) { size_t n = 1; for (j = 1; j < h->n; ++j) if (h->a[j].offset != h->a[n - 1].offset) h->a[n++] = h->a[j]; h->n = n; }
+        for (j = 0; j < h->n; ++j) {
+            l_ref = pl_refseq(ref, l_ref, ix, h->a[j].offset);
+            if (use_sw) {
+                so_aend_t b[2];
+                int16_t *prof = ssw_profile((const int8_t *)s->nst[i], PL_SCORE_MAT, s->l_seq, 5);
+                ssw_word((const int8_t *)ref, 0, l_ref, s->l_seq, 3, 1, prof, (uint16_t)-1, s->l_seq, b);
+                free(prof);
+                h->a[j].score = b[0].score;
+            } else {
+                so_lvbuf_t lb = { ref, s->nst[i], l_ref, s->l_seq, 1 };
+                const int d = lv_distance(&lb, PL_MAX_DISTANCE);
+                h->a[j].score = d == -1 ? PL_UNMAPPED : -d;
+            }
+        }
+    }
+    free(ref);
+}
+/* best / second best of one record (polish.c:718-737) */
+static void pl_pick(pl_sam_t *s)
+{
+    int best0 = PL_UNMAPPED, best1 = PL_UNMAPPED, i; size_t j;
+    s->strand = -1; s->primary = -1;
+    for (i = 0; i < 2; ++i)
+        for (j = 0; j < s->h[i].n; ++j) {
+            const int sc = s->h[i].a[j].score;
+            if (sc == PL_UNMAPPED) continue;
+            if (sc > best1) { best1 = sc; if (best1 > best0) { int t = best0; best0 = best1; best1 = t; s->strand = i; s->primary = (int)j; } }
+        }
+    s->b0 = best0; s->b1 = best1;
+}
+/* gen_cigar (polish.c:190-249) */
+static void pl_gen_cigar(const so_index_t *ix, pl_sam_t *s, int use_sw)
+{
+    uint8_t *ref = xcalloc((size_t)(s->l_seq + 15) / 8 * 8 + 64, 1);
+    const int l_ref = pl_refseq(ref, s->l_seq, ix, s->h[s->strand].a[s->primary].offset);
+    const int d = s->h[s->strand].a[s->primary].score;
+    s->cigar[0] = 0;
+    if (use_sw) {
+        so_ssw_t r; int j; char *o = s->cigar;
+        ssw_align2((const int8_t *)s->nst[s->strand], s->l_seq, PL_SCORE_MAT, 5, (const int8_t *)ref, l_ref, 3, 1, s->l_seq / 2, &r);
+        if (r.score1 != d) { fprintf(stderr, "push cigar error!\n"); exit(1); }
+        if (r.read_begin1 != 0) o += sprintf(o, "%dS", r.read_begin1);
+        for (j = 0; j < r.n_cigar; ++j) o += sprintf(o, "%u%c", r.cigar[j] >> 4, "MID"[r.cigar[j] & 15]);
+        if (r.read_end1 + 1 != s->l_seq) o += sprintf(o, "%dS", s->l_seq - r.read_end1 - 1);
+    } else if (d == -PL_MAX_DISTANCE) strcpy(s->cigar, "*");
+    else {
+        so_lvbuf_t lb = { ref, s->nst[s->strand], l_ref, s->l_seq, 1 };
+        if (lv_cigar(&lb, -d, s->cigar, (int)sizeof s->cigar) != -d) { fprintf(stderr, "push cigar error!\n"); exit(1); }
+    }
+    free(ref);
+}
+static void pl_seq_qual(FILE *out, const pl_sam_t *s)
+{
+    int i;
+    const uint8_t *q = s->strand == 0 ? s->nst[0] : s->nst[1];
+    for (i = 0; i < s->l_seq; ++i) fputc("ACGT"[q[i] & 3], out);        /* reads with other bases are undefined in the reference */
+    fputc('\t', out);
+    const int rev_in = (s->flag & 0x10) != 0;
+    if ((rev_in && s->strand == 0) || (!rev_in && s->strand != 0)) for (i = s->l_seq - 1; i >= 0; --i) fputc(s->qual[i], out);
+    else fprintf(out, "%s\t", s->qual);
+    fputc('\n', out);
+}
+/* the pair window of polish.c:148-179: two pointers over the forward hits of one mate and the reverse hits of the other */
+static unsigned pl_pairing(pl_hits_t *fw, pl_hits_t *bw)
+{
+    unsigned n = 0; size_t i = 0, j = 0;
+    if (fw->n == 0 || bw->n == 0) return 0;
+    while (i < fw->n && j < bw->n) {
+        const uint32_t a = fw->a[i].offset, b = bw->a[j].offset, r = a > b ? a - b : b - a;
+        if (a > b || r < 350) ++j;
+        else if (r > 650) ++i;
+        else { pl_hit_t t = fw->a[n]; fw->a[n] = fw->a[i]; fw->a[i] = t; t = bw->a[n]; bw->a[n] = bw->a[j]; bw->a[j] = t; ++i; ++j; ++n; }
+    }
+    return n;
+}
+static void pl_print_mate(FILE *out, const pl_sam_t *me, const pl_sam_t *mate, int first, int proper)
+{
+    const int map0 = me->strand != -1, map1 = mate->strand != -1;
+    const uint32_t pos0 = map0 ? me->h[me->strand].a[me->primary].pos : 0, pos1 = map1 ? mate->h[mate->strand].a[mate->primary].pos : 0;
+    const char *c0 = map0 ? me->h[me->strand].a[me->primary].chrom : NULL, *c1 = map1 ? mate->h[mate->strand].a[mate->primary].chrom : NULL;
+    unsigned flag = 1;
+    if (proper) flag |= 2;
+    if (me->strand == 1) flag |= 0x10;
+    if (mate->strand == 1) flag |= 0x20;
+    flag |= first ? 0x40 : 0x80;
+    if (!map0) flag |= 4;
+    if (first) { if (!map1) flag |= 8; } else { if (!map1) flag |= 4; }              /* the second record sets UNMAPPED for either mate (polish.c:383-384) */
+    fprintf(out, "%s\t%u\t", first ? me->name : mate->name, flag & 0xFF);          /* both records carry the FIRST mate's name; flag is an unsigned char there */
+    if (!map0) fprintf(out, "*\t0\t"); else fprintf(out, "%s\t%u\t", c0, pos0);
+    fprintf(out, me->b1 == PL_UNMAPPED && me->b0 != PL_UNMAPPED ? "60\t" : "0\t");
+    if (map0) fprintf(out, "%s\t", me->cigar); else fprintf(out, "*\t");
+    if (!map1) fprintf(out, "*\t0\t");
+    else if (!map0 || strcmp(c0, c1) != 0) fprintf(out, "%s\t%u\t", c1, pos1);
+    else fprintf(out, "=\t%u\t", pos1);
+    if (map0 && map1) { const int a = (int)(pos0 < pos1 ? pos1 - pos0 : pos0 - pos1); fprintf(out, "%d\t", me->strand == 0 ? a : -a); }
+    else fprintf(out, "0\t");
+    pl_seq_qual(out, me);
+}
+int so_polish(const so_index_t *ix, const char *sam_path, int use_sw, int paired, FILE *out)
+{
+    FILE *fp = fopen(sam_path, "r");
+    if (!fp) { fprintf(stderr, "[Error]: Can't open file %s\n", sam_path); return 1; }
+    {   /* sam_skipHeader (samParser.c:43-55) */
+        char b[1024];
+        while (fgets(b, sizeof b, fp)) if (b[0] != '@') { fseek(fp, -(long)strlen(b), SEEK_CUR); break; }
+    }
+    if (!paired) {
+        pl_sam_t *s;
+        while ((s = pl_read(fp)) != NULL) {
+            pl_score_hits(ix, s, use_sw);
+            pl_pick(s);
+            if (s->strand != -1) pl_gen_cigar(ix, s, use_sw);
+            const int mapped = s->strand != -1;
+            unsigned flag = 0x40 | (s->strand == 1 ? 0x10 : 0) | (mapped ? 0 : 4);
+            fprintf(out, "%s\t%u\t", s->name, flag);
+            if (!mapped) fprintf(out, "*\t0\t"); else fprintf(out, "%s\t%u\t", s->h[s->strand].a[s->primary].chrom, s->h[s->strand].a[s->primary].pos);
+            fprintf(out, s->b1 == PL_UNMAPPED && s->b0 != PL_UNMAPPED ? "60\t" : "0\t");
+            if (mapped) fprintf(out, "%s\t", s->cigar); else fprintf(out, "*\t");
+            fprintf(out, "*\t0\t0\t");
+            pl_seq_qual(out, s);
+            pl_free(s);
+        }
+    } else {
+        pl_sam_t *s0 = pl_read(fp), *s1 = pl_read(fp);
+        while (s0 && s1) {
+            pl_score_hits(ix, s0, use_sw); pl_score_hits(ix, s1, use_sw);
+            const unsigned n0 = pl_pairing(&s0->h[0], &s1->h[1]), n1 = pl_pairing(&s1->h[0], &s0->h[1]);
+            const int proper = n0 + n1 != 0;
+            if (!proper) { pl_pick(s0); pl_pick(s1); }
+            else {                                            /* best pair (polish.c:600-640) */
+                int best0 = PL_UNMAPPED, best1 = PL_UNMAPPED; unsigned i;
+                s0->strand = s1->strand = s0->primary = s1->primary = -1;
+                for (i = 0; i < n0; ++i) {
+                    const int sc = s0->h[0].a[i].score + s1->h[1].a[i].score;
+                    if (sc == PL_UNMAPPED) continue;
+                    if (sc > best1) { best1 = sc; if (best1 > best0) { int t = best0; best0 = best1; best1 = t; s0->strand = 0; s1->strand = 1; s0->primary = s1->primary = (int)i; } }
+                }
+                for (i = 0; i < n1; ++i) {
+                    const int sc = s0->h[1].a[i].score + s1->h[0].a[i].score;
+                    if (sc == PL_UNMAPPED) continue;
+                    if (sc > best1) { best1 = sc; if (best1 > best0) { int t = best0; best0 = best1; best1 = t; s0->strand = 1; s1->strand = 0; s0->primary = s1->primary = (int)i; } }
+                }
+                s0->b0 = s1->b0 = best0; s0->b1 = s1->b1 = best1;
+            }
+            if (s0->strand != -1 && s0->primary != -1) pl_gen_cigar(ix, s0, use_sw);
+            if (s1->strand != -1 && s1->primary != -1) pl_gen_cigar(ix, s1, use_sw);
+            pl_print_mate(out, s0, s1, 1, proper);
+            pl_print_mate(out, s1, s0, 0, proper);
+            pl_free(s0); pl_free(s1);
+            s0 = pl_read(fp); s1 = pl_read(fp);
+        }
+        pl_free(s0); pl_free(s1);
+    }
+    fclose(fp);
+    return 0;
 }

@@ -14,6 +14,7 @@
 #define SALT_ORACLE_H
 #include <stdint.h>
 #include <stddef.h>
+#include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -118,6 +119,9 @@ int so_isize_estimate(uint32_t *t, int n, uint32_t *min_tlen, uint32_t *max_tlen
 int so_isize_templates(const so_index_t *, int n_pairs, const uint32_t *offs, const so_result_t *res, uint32_t *t_out);
 int so_infer_isize(const so_index_t *, const so_opt_t *, int n_pairs, const uint8_t *seqs, const uint32_t *offs, int n_threads,
                    uint32_t *min_tlen, uint32_t *max_tlen, int *n_used);
+
+/* N4: the reference's SAM post-processor `polish [-s] [-p] <idx> <SAM>` (Polish_src/polish.c:448-762); records to `out` */
+int so_polish(const so_index_t *, const char *sam_path, int use_sw, int paired, FILE *out);
 
 #ifdef __cplusplus
 }
