@@ -247,6 +247,20 @@ int  salt_gpu_diag_lv(const uint32_t *ref_words, uint32_t ref_len, uint32_t n_ca
 int  salt_gpu_diag_ssw(uint32_t n_cases, const uint8_t *aware, const uint8_t *ref_syms, const uint32_t *ref_offs,
                        const uint8_t *codes, const uint32_t *read_offs, int32_t *out6, uint16_t *cigars, uint16_t *n_cigar);
 
+/* ---- polish (row N4): the re-scoring step of the reference's SAM post-processor (Polish_src/polish.c:461-497 scores, 190-249 CIGAR) ---
+ * For every item = (read, strand, offset into the 2-bit genome): the plain edit distance between the read (strand 1: its reverse
+ * complement) and the `tlen` bases at `offset`, by stock Landau-Vishkin with bound k (computeEditDistance, Polish_src/lv.c; -1 = more than
+ * k), and with want_cigar the CIGAR of computeEditDistanceWithCigar (useM; binary ops as in salt_result_t).  `pool`: explicit windows
+ * (pool_stride code bytes each) for the few items whose window the reference clips at the genome end and pads with what its buffer
+ * held before (polish.c:84-92); item.pool = 0xFFFFFFFF for everything else.  salt_amd/host/polish_main.cc is the caller. */
+typedef struct { uint32_t read, offset, pool; uint16_t tlen; uint8_t strand, k; } salt_polish_item_t;
+typedef struct salt_gpu_polish salt_gpu_polish_t;
+int  salt_gpu_polish_open(int device, const uint8_t *pac, uint64_t l_pac, salt_gpu_polish_t **out);
+void salt_gpu_polish_close(salt_gpu_polish_t *p);
+int  salt_gpu_polish_lv(salt_gpu_polish_t *p, const uint8_t *codes, const uint32_t *offs, uint32_t n_reads, const salt_polish_item_t *items,
+                        uint32_t n_items, const uint8_t *pool, uint32_t pool_stride, uint32_t n_pool, int want_cigar,
+                        int32_t *dist, uint16_t *cigars, uint8_t *n_cigar);
+
 /* ---- index construction on the device (salt-idx's heavy steps; row N1) ----------------------------------------------
  * Replaces, for texts of any length the 32-bit formats admit (n < 2^32 - 16): bwt_bwtgen / Rbwt_bwt_bwtgen (Index_src/bwt_gen.c,
  * 4bit_bwt_gen.c:1044-1130), bwt_bwtupdate_core (bwtmisc.c:121-143), bwt_cal_sa (bwt.c:48-68), LKT_build_lookuptable

@@ -2417,6 +2417,97 @@ void launch_diag_verify(const uint32_t *ref, uint32_t ref_len, uint32_t n_cases,
     if (n_cases) hipLaunchKernelGGL(k_diag_verify, dim3(n_cases), dim3(64), 0, st, ref, ref_len, n_cases, seqs, offs, cand, coffs, mode, out);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_polish (row N4): the re-scoring step of the reference's SAM post-processor (Polish_src/polish.c:461-497, 190-249).
+// One wave per item = (read, strand, genome offset): the plain edit distance (k <= 13) between the read and the bases at that offset
+// -- stock Landau-Vishkin on EQUAL bytes (Polish_src/lv.c), which lv_wave computes when both strings are one-hot: equal <=> AND != 0
+// -- and, for the items that ask for it, the CIGAR (computeEditDistanceWithCigar with useM: first "e plain mismatches on diagonal 0 ->
+// <L>M", lv.c:274-296, then the traceback).  The reference's window buffer is calloc'ed, so what lies behind the text reads as 'A'
+// (code 0) there; a window clipped at the genome end keeps the previous hit's bytes behind the clip (polish.c:84-92): the host hands
+// those few windows over explicitly (`pool`).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_polish(const uint8_t *__restrict__ pac, const uint8_t *__restrict__ codes, const uint32_t *__restrict__ offs, const salt_polish_item_t *__restrict__ items,
+         uint32_t n_items, const uint8_t *__restrict__ pool, uint32_t pool_stride, int want_cigar, int32_t *__restrict__ dist,
+         uint16_t *__restrict__ cigars, uint8_t *__restrict__ n_cigar, LvTables *__restrict__ tabs)
+{
+    __shared__ LvBytes s;
+    __shared__ int s_n;
+    const uint32_t lane = lane_id();
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const salt_polish_item_t x = items[it];
+        const uint32_t o = offs[x.read], L = offs[x.read + 1] - o, tl = x.tlen;
+        WSYNC();
+        for (uint32_t i = lane; i < L + 48; i += 64) {
+            uint8_t pv = 1;                                                    // behind the read: calloc'ed zeros = 'A'
+            if (i < L) { const uint8_t c = x.strand ? codes[o + L - 1 - i] : codes[o + i]; pv = c < 4 ? (uint8_t)(1u << (x.strand ? 3 - c : c)) : (uint8_t)(x.strand ? 0x20 : 0x10); }
+            s.P[i] = pv;
+        }
+        for (uint32_t i = lane; i < L + 48; i += 64) {
+            uint8_t tv = 1;
+            if (x.pool != 0xFFFFFFFFu) { if (i < pool_stride) tv = (uint8_t)(1u << (pool[(uint64_t)x.pool * pool_stride + i] & 3u)); }
+            else if (i < tl) { const uint64_t l = (uint64_t)x.offset + i; tv = (uint8_t)(1u << ((pac[l >> 2] >> ((~l & 3u) << 1)) & 3u)); }
+            s.T[i] = tv;
+        }
+        WSYNC();
+        int d_fin = 0;
+        LvTables *tab = want_cigar ? tabs + blockIdx.x : nullptr;
+        const int e = lv_wave(s.T, (int)tl, s.P, (int)L, (int)x.k, tab, d_fin);
+        if (lane == 0) dist[it] = e;
+        if (want_cigar) {
+            __threadfence_block();
+            WSYNC();
+            // e plain mismatches on diagonal 0?  (lv.c:274-296)
+            const int end0 = (int)(L < tl ? L : tl);
+            int straight = 0;
+            for (int i = (int)lane; i < end0; i += 64) straight += s.P[i] != s.T[i];
+            for (int w = 32; w > 0; w >>= 1) straight += __shfl_xor(straight, w);
+            straight += (int)L - end0;
+            if (lane == 0) {
+                int n = 0;
+                uint16_t *cg = cigars + (uint64_t)it * SALT_MAX_CIGAR_OPS;
+                if (e == 0 || (e > 0 && straight == e)) cg[n++] = (uint16_t)((L << 4) | 0u);
+                else if (e > 0) {
+                    char act[LVK + 1]; int matched[LVK + 1];
+                    int cd = d_fin;
+                    for (int ce = e; ce >= 1; --ce) {
+                        const char a = tab->A[ce][cd + 31];
+                        act[ce] = a;
+                        const int cur = tab->L[ce][cd + 31];
+                        if (a == 'I') { matched[ce] = cur - tab->L[ce - 1][cd + 1 + 31] - 1; cd += 1; }
+                        else if (a == 'D') { matched[ce] = cur - tab->L[ce - 1][cd - 1 + 31]; cd -= 1; }
+                        else { matched[ce] = cur - tab->L[ce - 1][cd + 31] - 1; }
+                    }
+                    int acc = tab->L[0][31];
+                    int ce = 1;
+                    while (ce <= e) {
+                        const char a = act[ce]; int cnt = 1;
+                        while (ce + 1 <= e && matched[ce] == 0 && act[ce + 1] == a) { ++cnt; ++ce; }
+                        if (a == 'X') acc += cnt;
+                        else {
+                            if (acc != 0 && n < SALT_MAX_CIGAR_OPS) cg[n++] = (uint16_t)((acc << 4) | 0);
+                            acc = 0;
+                            if (n < SALT_MAX_CIGAR_OPS) cg[n++] = (uint16_t)((cnt << 4) | (a == 'I' ? 1 : 2));
+                        }
+                        if (matched[ce] > 0) acc += matched[ce];
+                        ++ce;
+                    }
+                    if (acc != 0 && n < SALT_MAX_CIGAR_OPS) cg[n++] = (uint16_t)((acc << 4) | 0);
+                }
+                n_cigar[it] = (uint8_t)n;
+                s_n = n;
+            }
+            WSYNC();
+        }
+    }
+}
+void launch_polish(const uint8_t *pac, const uint8_t *codes, const uint32_t *offs, const salt_polish_item_t *items, uint32_t n_items, const uint8_t *pool,
+                   uint32_t pool_stride, int want_cigar, int32_t *dist, uint16_t *cigars, uint8_t *n_cigar, void *tabs, uint32_t n_blocks, hipStream_t st)
+{
+    if (n_items) hipLaunchKernelGGL(k_polish, dim3(n_blocks), dim3(64), 0, st, pac, codes, offs, items, n_items, pool, pool_stride, want_cigar, dist, cigars, n_cigar,
+                                    static_cast<LvTables *>(tabs));
+}
+
 // first 128 bytes of every result row, densely packed (what the host needs of nearly every row)
 __global__ void __launch_bounds__(256)
 k_heads(const salt_result_t *__restrict__ res, uint32_t n, uint4 *__restrict__ heads)

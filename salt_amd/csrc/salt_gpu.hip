@@ -582,6 +582,67 @@ extern "C" int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
 }
 #undef REGROW
 
+// ---------------------------------------------------------------------------------------------
+// polish (row N4)
+// ---------------------------------------------------------------------------------------------
+struct salt_gpu_polish { int device = 0; uint8_t *d_pac = nullptr; uint64_t l_pac = 0; void *d_tabs = nullptr; uint32_t n_blocks = 0; };
+
+extern "C" int salt_gpu_polish_open(int device, const uint8_t *pac, uint64_t l_pac, salt_gpu_polish_t **out)
+{
+    if (!pac || !out || l_pac == 0) return fail(SALT_E_INVAL, "null argument");
+    int n_dev = 0;
+    HIPCHK(hipGetDeviceCount(&n_dev));
+    if (n_dev <= 0) return fail(SALT_E_HIP, "no HIP device visible: polish cannot run (there is no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    salt_gpu_polish *p = new salt_gpu_polish();
+    p->device = device; p->l_pac = l_pac;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_pac, l_pac / 4 + 8);
+    if (e == hipSuccess) e = hipMemcpy(p->d_pac, pac, l_pac / 4 + 1, hipMemcpyHostToDevice);
+    p->n_blocks = (uint32_t)prop.multiProcessorCount * 8u;
+    if (e == hipSuccess) e = hipMalloc(&p->d_tabs, (uint64_t)p->n_blocks * lv_table_bytes());
+    if (e != hipSuccess) { hipFree(p->d_pac); hipFree(p->d_tabs); delete p; return fail(SALT_E_HIP, std::string("polish open: ") + hipGetErrorString(e)); }
+    *out = p;
+    return SALT_OK;
+}
+extern "C" void salt_gpu_polish_close(salt_gpu_polish_t *p) { if (!p) return; hipSetDevice(p->device); hipFree(p->d_pac); hipFree(p->d_tabs); delete p; }
+
+extern "C" int salt_gpu_polish_lv(salt_gpu_polish_t *p, const uint8_t *codes, const uint32_t *offs, uint32_t n_reads, const salt_polish_item_t *items,
+                                  uint32_t n_items, const uint8_t *pool, uint32_t pool_stride, uint32_t n_pool, int want_cigar,
+                                  int32_t *dist, uint16_t *cigars, uint8_t *n_cigar)
+{
+    if (!p || !codes || !offs || !items || !dist || (want_cigar && (!cigars || !n_cigar)) || (n_pool && !pool)) return fail(SALT_E_INVAL, "null argument");
+    if (n_items == 0) return SALT_OK;
+    for (uint32_t i = 0; i < n_items; ++i) {                   // shapes the kernel assumes, checked before anything is launched
+        const salt_polish_item_t &x = items[i];
+        if (x.read >= n_reads) return fail(SALT_E_INVAL, "polish item names a read outside the batch");
+        const uint32_t L = offs[x.read + 1] - offs[x.read];
+        if (L == 0 || L > SALT_MAX_READ_LEN || x.tlen > L || x.k >= 31) return fail(SALT_E_INVAL, "polish item: read length / window / bound outside the kernel's range");
+        if (x.pool == 0xFFFFFFFFu) { if ((uint64_t)x.offset + x.tlen > p->l_pac) return fail(SALT_E_INVAL, "polish item: window beyond the genome"); }
+        else if (x.pool >= n_pool || pool_stride < L) return fail(SALT_E_INVAL, "polish item: explicit window outside the pool");
+    }
+    HIPCHK(hipSetDevice(p->device));
+    uint8_t *d_codes = nullptr, *d_pool = nullptr, *d_nc = nullptr; uint32_t *d_offs = nullptr; salt_polish_item_t *d_items = nullptr; int32_t *d_dist = nullptr; uint16_t *d_cig = nullptr;
+    const uint64_t bases = offs[n_reads];
+    auto done = [&](int rc) { hipFree(d_codes); hipFree(d_pool); hipFree(d_nc); hipFree(d_offs); hipFree(d_items); hipFree(d_dist); hipFree(d_cig); return rc; };
+#define PCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return done(fail(SALT_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_))); } while (0)
+    PCHK(hipMalloc((void **)&d_codes, bases + 64)); PCHK(hipMemcpy(d_codes, codes, bases, hipMemcpyHostToDevice));
+    PCHK(hipMalloc((void **)&d_offs, ((uint64_t)n_reads + 1) * 4)); PCHK(hipMemcpy(d_offs, offs, ((uint64_t)n_reads + 1) * 4, hipMemcpyHostToDevice));
+    PCHK(hipMalloc((void **)&d_items, (uint64_t)n_items * sizeof(salt_polish_item_t))); PCHK(hipMemcpy(d_items, items, (uint64_t)n_items * sizeof(salt_polish_item_t), hipMemcpyHostToDevice));
+    if (n_pool) { PCHK(hipMalloc((void **)&d_pool, (uint64_t)n_pool * pool_stride + 8)); PCHK(hipMemcpy(d_pool, pool, (uint64_t)n_pool * pool_stride, hipMemcpyHostToDevice)); }
+    PCHK(hipMalloc((void **)&d_dist, (uint64_t)n_items * 4));
+    if (want_cigar) { PCHK(hipMalloc((void **)&d_cig, (uint64_t)n_items * SALT_MAX_CIGAR_OPS * 2)); PCHK(hipMalloc((void **)&d_nc, n_items)); PCHK(hipMemset(d_nc, 0, n_items)); }
+    const uint32_t blocks = n_items < p->n_blocks ? n_items : p->n_blocks;
+    launch_polish(p->d_pac, d_codes, d_offs, d_items, n_items, d_pool, pool_stride, want_cigar, d_dist, d_cig, d_nc, p->d_tabs, blocks, nullptr);
+    PCHK(hipGetLastError());
+    PCHK(hipDeviceSynchronize());
+    PCHK(hipMemcpy(dist, d_dist, (uint64_t)n_items * 4, hipMemcpyDeviceToHost));
+    if (want_cigar) { PCHK(hipMemcpy(cigars, d_cig, (uint64_t)n_items * SALT_MAX_CIGAR_OPS * 2, hipMemcpyDeviceToHost)); PCHK(hipMemcpy(n_cigar, d_nc, n_items, hipMemcpyDeviceToHost)); }
+#undef PCHK
+    return done(SALT_OK);
+}
+
 extern "C" int salt_gpu_index_replicate(salt_gpu_index_t *src, const int *devices, int n, salt_gpu_index_t **out)
 {
     if (!src || !devices || !out || n < 1 || devices[0] != src->device) return fail(SALT_E_INVAL, "bad replicate arguments");

@@ -95,6 +95,8 @@ void launch_pe_final(const IndexView &ix, const PackGeom &pg, uint32_t n_pairs, 
                      const PeSwRes *sw, void *lvtab, uint32_t *citems, uint32_t *cctl, uint32_t n_blocks, hipStream_t st);   // cctl[0] count, cctl[1] head
 
 uint32_t heavy_blocks_per_cu();
+void launch_polish(const uint8_t *pac, const uint8_t *codes, const uint32_t *offs, const salt_polish_item_t *items, uint32_t n_items, const uint8_t *pool,
+                   uint32_t pool_stride, int want_cigar, int32_t *dist, uint16_t *cigars, uint8_t *n_cigar, void *tabs, uint32_t n_blocks, hipStream_t st);
 void launch_heads(const salt_result_t *res, uint32_t n, uint8_t *heads, hipStream_t st);   // heads[i] = first 128 bytes of res[i]
 void launch_diag_rule(uint32_t n_cases, const uint32_t *pos, const uint8_t *val, const uint32_t *offs, const uint32_t *bound_in,
                       uint32_t L, uint32_t ref_len, int mode, uint32_t *out, hipStream_t st);

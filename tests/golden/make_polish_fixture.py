@@ -46,7 +46,7 @@ CASES = (("expect_polish_se_lv.sam", [], "expect_se_default.sam"), ("expect_poli
 def main():
     idx = os.path.join(L, "idx")
     for f in os.listdir(L):
-        if f.startswith("expect_polish") or f == "polish_pe_in.sam":
+        if f.startswith("expect_polish") or f in ("polish_pe_in.sam", "polish_edge_in.sam"):
             os.unlink(os.path.join(L, f))
     for out, args, src in CASES:
         with tempfile.NamedTemporaryFile("wb", suffix=".sam", delete=False) as t:
@@ -56,6 +56,16 @@ def main():
         os.unlink(t.name)
         data = open(os.path.join(L, out), "rb").read()
         print(out, "rc", p.returncode, len(data), "records", data.count(b"\n"), "NUL bytes", data.count(b"\0"), p.stderr.decode()[-200:])
+    # hand-made edge cases (tests/polish_edge.py): many XA hits, both contigs, hits clipped at the genome end
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from polish_edge import edge_records
+    src = os.path.join(L, "polish_edge_in.sam")
+    open(src, "w").write("@HD\tVN:1\n" + "\n".join(edge_records()) + "\n")
+    for out, args in (("expect_polish_edge_se.sam", []), ("expect_polish_edge_pe.sam", ["-p"])):
+        with open(os.path.join(L, out), "wb") as f:
+            p = subprocess.run([POLISH] + args + [idx, src], stdout=f, stderr=subprocess.PIPE)
+        print(out, "rc", p.returncode, os.path.getsize(os.path.join(L, out)), p.stderr.decode()[-200:])
 
 
 if __name__ == "__main__":

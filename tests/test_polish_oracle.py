@@ -21,3 +21,11 @@ def test_polish_oracle_equals_the_reference(out, args, src, oracle_lib, tmp_path
     p = subprocess.run([os.path.join(ROOT, "oracle", "polish_oracle")] + list(args) + [os.path.join(LAMBDA, "idx"), str(sam)], capture_output=True)
     assert p.returncode == 0, p.stderr[-300:]
     assert p.stdout == open(os.path.join(LAMBDA, out), "rb").read()
+
+
+@pytest.mark.parametrize("out,args", [("expect_polish_edge_se.sam", []), ("expect_polish_edge_pe.sam", ["-p"])])
+def test_polish_oracle_equals_the_reference_on_edge_cases(out, args, oracle_lib):
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "polish_oracle"], check=True, stdout=subprocess.DEVNULL)
+    p = subprocess.run([os.path.join(ROOT, "oracle", "polish_oracle")] + args + [os.path.join(LAMBDA, "idx"), os.path.join(LAMBDA, "polish_edge_in.sam")], capture_output=True)
+    assert p.returncode == 0, p.stderr[-300:]
+    assert p.stdout == open(os.path.join(LAMBDA, out), "rb").read()
