@@ -261,6 +261,12 @@ int  salt_gpu_polish_lv(salt_gpu_polish_t *p, const uint8_t *codes, const uint32
                         uint32_t n_items, const uint8_t *pool, uint32_t pool_stride, uint32_t n_pool, int want_cigar,
                         int32_t *dist, uint16_t *cigars, uint8_t *n_cigar);
 
+/* polish -s: the same items by Smith-Waterman (ssw_init + ssw_align over polish's own matrix: +2 / -2, N 0, gaps 3 / 1; polish.c:48-52,
+ * 209-222, 509-510).  score[i] = score1; with want_cigar also read_span[2i], [2i+1] = read_begin1, read_end1 (the soft clips) and the
+ * banded traceback's CIGAR.  item.tlen is the (possibly clipped) window length; item.pool and item.k are not used. */
+int  salt_gpu_polish_sw(salt_gpu_polish_t *p, const uint8_t *codes, const uint32_t *offs, uint32_t n_reads, const salt_polish_item_t *items,
+                        uint32_t n_items, int want_cigar, int32_t *score, int32_t *read_span, uint16_t *cigars, uint16_t *n_cigar);
+
 /* ---- index construction on the device (salt-idx's heavy steps; row N1) ----------------------------------------------
  * Replaces, for texts of any length the 32-bit formats admit (n < 2^32 - 16): bwt_bwtgen / Rbwt_bwt_bwtgen (Index_src/bwt_gen.c,
  * 4bit_bwt_gen.c:1044-1130), bwt_bwtupdate_core (bwtmisc.c:121-143), bwt_cal_sa (bwt.c:48-68), LKT_build_lookuptable

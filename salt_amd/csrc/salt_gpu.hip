@@ -643,6 +643,59 @@ extern "C" int salt_gpu_polish_lv(salt_gpu_polish_t *p, const uint8_t *codes, co
     return done(SALT_OK);
 }
 
+extern "C" int salt_gpu_polish_sw(salt_gpu_polish_t *p, const uint8_t *codes, const uint32_t *offs, uint32_t n_reads, const salt_polish_item_t *items,
+                                  uint32_t n_items, int want_cigar, int32_t *score, int32_t *read_span, uint16_t *cigars, uint16_t *n_cigar)
+{
+    if (!p || !codes || !offs || !items || !score || (want_cigar && (!read_span || !cigars || !n_cigar))) return fail(SALT_E_INVAL, "null argument");
+    if (n_items == 0) return SALT_OK;
+    uint32_t max_len = 1;
+    std::vector<PeSwReq> h_req(n_items);
+    for (uint32_t i = 0; i < n_items; ++i) {                   // shapes the kernel assumes, checked before anything is launched
+        const salt_polish_item_t &x = items[i];
+        if (x.read >= n_reads) return fail(SALT_E_INVAL, "polish item names a read outside the batch");
+        const uint32_t L = offs[x.read + 1] - offs[x.read];
+        if (L == 0 || L > SALT_MAX_READ_LEN || x.tlen == 0 || x.tlen > L) return fail(SALT_E_INVAL, "polish item: read length / window outside the kernel's range");
+        if ((uint64_t)x.offset + x.tlen > p->l_pac) return fail(SALT_E_INVAL, "polish item: window beyond the genome");
+        if (L > max_len) max_len = L;
+        h_req[i] = PeSwReq{ x.offset, x.offset + x.tlen - 1u, x.read, (uint8_t)(x.strand ? 1 : 0), 2, (uint16_t)(want_cigar ? 0 : 1) };
+    }
+    HIPCHK(hipSetDevice(p->device));
+    uint8_t *d_codes = nullptr, *d_scr = nullptr; uint32_t *d_offs = nullptr, *d_ctl = nullptr; PeSwReq *d_req = nullptr; PeSwRes *d_res = nullptr;
+    const uint64_t bases = offs[n_reads];
+    auto done = [&](int rc) { hipFree(d_codes); hipFree(d_scr); hipFree(d_offs); hipFree(d_ctl); hipFree(d_req); hipFree(d_res); return rc; };
+#define PCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return done(fail(SALT_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_))); } while (0)
+    PCHK(hipMalloc((void **)&d_codes, bases + 64)); PCHK(hipMemcpy(d_codes, codes, bases, hipMemcpyHostToDevice));
+    PCHK(hipMalloc((void **)&d_offs, ((uint64_t)n_reads + 1) * 4)); PCHK(hipMemcpy(d_offs, offs, ((uint64_t)n_reads + 1) * 4, hipMemcpyHostToDevice));
+    PCHK(hipMalloc((void **)&d_req, (uint64_t)n_items * sizeof(PeSwReq))); PCHK(hipMemcpy(d_req, h_req.data(), (uint64_t)n_items * sizeof(PeSwReq), hipMemcpyHostToDevice));
+    PCHK(hipMalloc((void **)&d_res, (uint64_t)n_items * sizeof(PeSwRes)));
+    SwGeom geom = sw_geom(max_len, max_len, p->n_blocks / 8u);
+    if ((uint64_t)geom.n_blocks * 8u > (uint64_t)n_items + 7u) geom.n_blocks = (n_items + 7u) / 8u;
+    PCHK(hipMalloc((void **)&d_scr, (uint64_t)geom.n_blocks * 8 * geom.group_bytes));
+    const uint32_t ctl[3] = { n_items, 0, 0 };
+    PCHK(hipMalloc((void **)&d_ctl, 12)); PCHK(hipMemcpy(d_ctl, ctl, 12, hipMemcpyHostToDevice));
+    IndexView v; memset(&v, 0, sizeof v);
+    v.ref_len = (uint32_t)p->l_pac;                            // k_sw's range check; mode 2 reads the 2-bit genome only
+    launch_sw(v, p->d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 1, d_ctl + 2, d_scr, geom, max_len, nullptr);
+    PCHK(hipGetLastError());
+    PCHK(hipDeviceSynchronize());
+    uint32_t h_ctl[3];
+    PCHK(hipMemcpy(h_ctl, d_ctl, 12, hipMemcpyDeviceToHost));
+    if (h_ctl[2]) return done(fail(SALT_E_INVAL, "polish -s: an alignment needs a wider band or more CIGAR operations than this build holds"));
+    std::vector<PeSwRes> h_res(n_items);
+    PCHK(hipMemcpy(h_res.data(), d_res, (uint64_t)n_items * sizeof(PeSwRes), hipMemcpyDeviceToHost));
+#undef PCHK
+    for (uint32_t i = 0; i < n_items; ++i) {
+        const PeSwRes &r = h_res[i];
+        score[i] = r.score1;
+        if (want_cigar) {
+            read_span[2 * (uint64_t)i] = r.read_begin; read_span[2 * (uint64_t)i + 1] = r.read_end;
+            n_cigar[i] = r.n_cigar;
+            memcpy(cigars + (uint64_t)i * SALT_MAX_CIGAR_OPS, r.cigar, sizeof r.cigar);
+        }
+    }
+    return done(SALT_OK);
+}
+
 extern "C" int salt_gpu_index_replicate(salt_gpu_index_t *src, const int *devices, int n, salt_gpu_index_t **out)
 {
     if (!src || !devices || !out || n < 1 || devices[0] != src->device) return fail(SALT_E_INVAL, "bad replicate arguments");

@@ -79,7 +79,8 @@ struct SwGeom {
     uint32_t maxcol_bytes, group_bytes, n_blocks;
 };
 SwGeom sw_geom(uint32_t max_len, uint64_t max_window, uint32_t cus);
-struct PeSwReq { uint32_t start, end, mate; uint8_t strand, aware; uint16_t pad; };          // mate: index of the rescued mate (2p or 2p+1)
+struct PeSwReq { uint32_t start, end, mate; uint8_t strand, aware; uint16_t pad; };          // mate: index of the rescued mate (2p or 2p+1);
+                                                                                            // aware: 0 plain, 1 SNP-aware, 2 polish matrix; pad bit 0: score only
 struct PeSwRes { int32_t score1, score2, ref_begin, ref_end, read_begin, read_end; uint32_t start, strand; uint16_t n_cigar, ok; uint16_t cigar[SALT_MAX_CIGAR_OPS]; };
 struct PePair { uint32_t req0; uint8_t n_req; uint8_t rescued[2]; uint8_t pad; };             // requests req0 .. req0+n_req-1, in the order tried
 void launch_pair(uint32_t n_pairs, uint32_t min_tlen, uint32_t max_tlen, uint32_t l_pac, const uint32_t *offs, salt_result_t *res,

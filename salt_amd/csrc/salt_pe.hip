@@ -17,8 +17,10 @@ namespace salt {
 
 // score of a reference symbol against a read base code (0..3, 4 = N) as ssw_init builds its profile from
 // score_mat2 indexed [ref*16 + (1<<code)] (aware, alnpe.c:58-73,283) or score_mat [ref*5 + code] (alnpe.c:52-56)
-__device__ __forceinline__ int sw_score(bool aware, uint32_t ref, uint32_t code)
+// aware = 2: polish's own matrix (+2 / -2, N scores 0; Polish_src/polish.c:48-52) over the 2-bit genome
+__device__ __forceinline__ int sw_score(int aware, uint32_t ref, uint32_t code)
 {
+    if (aware == 2) return (ref > 3 || code > 3) ? 0 : (ref == code ? 2 : -2);
     if (aware) {
         if (code > 3) return -3;                              // 1<<4 = 16 indexes column 0 of the next row: always -3
         const uint32_t bit = 1u << code;                      // only rows 1,2,4,8 of the (transposed) matrix are non-trivial
@@ -38,15 +40,15 @@ struct SwLds {                       // per 8-lane group: views into the block's
 __device__ __forceinline__ uint32_t sw_group_bytes(uint32_t seg) { return 4u * seg * 16u + ((8u * seg + 15u) & ~15u); }
 
 
-__device__ __forceinline__ uint32_t ref_symbol(const IndexView &ix, const uint8_t *pac, bool aware, uint32_t p)
+__device__ __forceinline__ uint32_t ref_symbol(const IndexView &ix, const uint8_t *pac, int aware, uint32_t p)
 {
-    if (aware) return (ix.ref[p >> 3] >> (4 * (p & 7u))) & 15u;
+    if (aware == 1) return (ix.ref[p >> 3] >> (4 * (p & 7u))) & 15u;
     return (pac[p >> 2] >> ((~p & 3u) << 1)) & 3u;
 }
 
 // one striped pass; all 8 lanes of the group call it together.  rd(q): read code at position q of this pass.
 template <class ReadAt>
-__device__ void sw_word_pass(const IndexView &ix, const uint8_t *pac, bool aware, SwLds &s, uint32_t ref0, int ref_dir, int refLen,
+__device__ void sw_word_pass(const IndexView &ix, const uint8_t *pac, int aware, SwLds &s, uint32_t ref0, int ref_dir, int refLen,
                              int readLen, ReadAt rd, int terminate, uint16_t *maxColumn, int &out_max, int &out_end_ref, int &out_end_read)
 {
     const int lane = (int)(threadIdx.x & 7u);
@@ -124,7 +126,7 @@ __device__ __forceinline__ int dpp_max8(int x)
 // ~25 VALU instructions per stripe and nothing else.  One buffer suffices for H: the old H[j] is read (it feeds stripe j+1)
 // right before the new one overwrites it.  Same operations in the same order as above, so the same lazy-F behaviour.
 template <int SEG, class ReadAt>
-__device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint8_t *pac, bool aware, uint32_t ref0, int ref_dir, int refLen,
+__device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint8_t *pac, int aware, uint32_t ref0, int ref_dir, int refLen,
                                                  int readLen, ReadAt rd, int terminate, uint16_t *maxColumn, uint16_t *maxColumnLds,
                                                  int &out_max, int &out_end_ref, int &out_end_read, uint32_t *dbg_cols = nullptr)
 {
@@ -147,18 +149,21 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
     const int begin = ref_dir ? refLen - 1 : 0, end = ref_dir ? -1 : refLen, step = ref_dir ? -1 : 1;
     // the window's symbols come from 32-bit words (8 masks of the mixRef, or 16 bases of the 2-bit genome); the word after the
     // one in use is already on its way, so a column never waits for memory
-    const uint32_t *words = aware ? ix.ref : reinterpret_cast<const uint32_t *>(pac);
-    const uint32_t wshift = aware ? 3u : 4u;
+    const bool masks = aware == 1;                               // 4-bit allele masks (mixRef) or the 2-bit genome
+    const uint32_t *words = masks ? ix.ref : reinterpret_cast<const uint32_t *>(pac);
+    const uint32_t wshift = masks ? 3u : 4u;
+    const int bias = aware == 2 ? 2 : 3;                         // the smallest score of the matrix in use, negated
     uint32_t w_idx = (ref0 + (uint32_t)begin) >> wshift;
     uint32_t w_cur = words[w_idx], w_next = words[(int64_t)w_idx + step < 0 ? 0 : w_idx + step];
     for (int i = begin; i != end; i += step) {
         const uint32_t p = ref0 + (uint32_t)i;
         if ((p >> wshift) != w_idx) { w_idx = p >> wshift; w_cur = w_next; w_next = words[(int64_t)w_idx + step < 0 ? 0 : w_idx + step]; }
-        const uint32_t sym = aware ? (w_cur >> (4u * (p & 7u))) & 15u
+        const uint32_t sym = masks ? (w_cur >> (4u * (p & 7u))) & 15u
                                    : (((w_cur >> (8u * ((p >> 2) & 3u))) & 0xFFu) >> ((~p & 3u) << 1)) & 3u;
-        // profile fields of this column (sw_score for the six codes, + 3)
-        uint32_t prof4 = 3u << 20;
-        if (aware) { if (sym == 1u || sym == 2u || sym == 4u || sym == 8u) prof4 |= 4u << (4u * (uint32_t)(__ffs((int)sym) - 1)); }
+        // profile fields of this column (sw_score for the six codes, + bias)
+        uint32_t prof4 = (uint32_t)bias << 20;
+        if (aware == 2) prof4 |= (2u << 16) | (4u << (4u * sym));
+        else if (masks) { if (sym == 1u || sym == 2u || sym == 4u || sym == 8u) prof4 |= 4u << (4u * (uint32_t)(__ffs((int)sym) - 1)); }
         else prof4 |= sym > 3u ? 0x22222u : ((2u << 16) | (4u << (4u * sym)));
         int vF = 0, vMaxColumn = 0;
         int last = 0;
@@ -169,7 +174,7 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
 #pragma unroll
         for (int j = 0; j < SEG; ++j) {
             if (j < segLen) {
-                int h = vH + (int)((prof4 >> sh[j]) & 15u) - 3;
+                int h = vH + (int)((prof4 >> sh[j]) & 15u) - bias;
                 int e = E[j];
                 h = h > e ? h : e; h = h > vF ? h : vF;
                 vMaxColumn = vMaxColumn > h ? vMaxColumn : h;
@@ -231,7 +236,7 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
 // again (the left neighbour's H, the upper-left H, this cell's E / F directions) stays in a register: the only loads are the two
 // upper-row values, so the lane never waits for its own stores to come back from memory.
 static constexpr int SW_LDS_BAND = 128, SW_LDS_REF = 512;
-__device__ int sw_banded(const IndexView &ix, const uint8_t *pac, bool aware, uint32_t ref0, const uint8_t *read, int refLen, int readLen,
+__device__ int sw_banded(const IndexView &ix, const uint8_t *pac, int aware, uint32_t ref0, const uint8_t *read, int refLen, int readLen,
                          int score, int band_width, int32_t *ghb, int32_t *geb, int32_t *ghc, int32_t *lrows, const uint8_t *lref,
                          int8_t *direction, uint32_t dir_cap, uint16_t *cig, int cig_cap)
 {
@@ -353,7 +358,7 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
         PeSwRes out; out.score1 = 0; out.score2 = 0; out.ref_begin = -1; out.ref_end = 0; out.read_begin = -1; out.read_end = 0; out.n_cigar = 0; out.ok = 0; out.start = rq.start; out.strand = rq.strand;
         const uint32_t off = offs[rq.mate], L = offs[rq.mate + 1] - off;
         const int refLen = (int)(rq.end - rq.start + 1);
-        const bool aware = rq.aware != 0;
+        const int aware = rq.aware;                                 // 0 plain, 1 SNP-aware, 2 polish matrix
         const bool sane = rq.start < ix.ref_len && refLen > 0;
         const bool fits = sane && (uint64_t)refLen * 2u <= maxcol_bytes && L <= seg * 8u;
         if (sane && !fits && lane == 0) atomicAdd(overflow, 1u);
@@ -382,6 +387,11 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
                 edge = end_ref1 + maskLen > refLen ? refLen : end_ref1 + maskLen;
                 for (int i = edge + (int)lane; i < refLen; i += 8) { int v = mc_in_lds ? mc_lds[i] : maxColumn[i]; score2 = score2 > v ? score2 : v; }
                 for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(score2, o, 8); score2 = score2 > t ? score2 : t; }
+            }
+            if (rq.pad & 1u) {                                       // score only (polish's first pass over every hit: ssw_align flag 0)
+                out.score1 = max1; out.score2 = score2; out.ref_end = end_ref1; out.read_end = end_read1;
+                if (lane == 0) res[it] = out;
+                continue;
             }
             const unsigned long long t1 = dbg_skip_tb & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
             // reverse pass from the end point to find the beginning (ssw.c:817-830)

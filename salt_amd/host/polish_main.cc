@@ -8,8 +8,9 @@
 // salt_gpu_polish_lv (two device calls per batch of records: all hits, then the winners).  No CPU re-scoring path exists.
 // Quirks kept (each cited at its place): strtok-style field splitting, only the first optional field containing "XA" is read, the
 // window length that shrinks for good at the genome end, the tab behind QUAL in two of four cases, the second record of a pair carrying
-// the first mate's name, an empty line ending the input.  `-s` (Smith-Waterman re-scoring with +2 / -2 scores) is not built: the mate-rescue
-// kernel k_sw is specialised for salt's +1 / -3 matrices; the option is refused loudly.
+// the first mate's name, an empty line ending the input.  `-s` re-scores by Smith-Waterman instead (+2 / -2, N 0, gaps 3 / 1): the same
+// two device calls go to salt_gpu_polish_sw, which runs the mate-rescue kernel k_sw with polish's matrix; soft clips come from the
+// alignment's read span (polish.c:209-222).
 #include "../../include/salt_host.h"
 #include <getopt.h>
 #include <algorithm>
@@ -90,7 +91,7 @@ struct Ctx {
 };
 
 // one batch: scores of every hit, the winners, their CIGARs, the records
-bool run_batch(Ctx &C, std::vector<Rec> &recs, bool paired)
+bool run_batch(Ctx &C, std::vector<Rec> &recs, bool paired, bool use_sw)
 {
     const uint32_t n = (uint32_t)recs.size();
     std::vector<uint8_t> codes; std::vector<uint32_t> offs(n + 1, 0);
@@ -123,7 +124,7 @@ bool run_batch(Ctx &C, std::vector<Rec> &recs, bool paired)
                 if ((uint64_t)x.offset > C.l_pac) { fprintf(stderr, "[Error]: Out of reference length!\n"); return false; }
                 if ((uint64_t)x.offset + (uint64_t)l_ref > C.l_pac) l_ref = (int)(C.l_pac - x.offset);
                 salt_polish_item_t itx; itx.read = r.read; itx.offset = x.offset; itx.pool = 0xFFFFFFFFu; itx.tlen = (uint16_t)l_ref; itx.strand = (uint8_t)s; itx.k = (uint8_t)MAX_DISTANCE;
-                if (l_ref < r.l_seq) {                          // rare: the window as the reference's buffer holds it -- fresh bases up to the clip, the bases of the
+                if (l_ref < r.l_seq && !use_sw) {               // rare: the window as the reference's buffer holds it -- fresh bases up to the clip, the bases of the
                     if (!dirty && prev_full != 0xFFFFFFFFu)     // last unclipped window behind it (the buffer is written in place, polish.c:84-92) -- handed over explicitly
                         for (int j = 0; j < r.l_seq; ++j) { const uint64_t l = (uint64_t)prev_full + (uint64_t)j; buf[(size_t)j] = (uint8_t)((C.pac[l >> 2] >> ((~l & 3) << 1)) & 3); }
                     for (int j = 0; j < l_ref; ++j) { const uint64_t l = (uint64_t)x.offset + (uint64_t)j; buf[(size_t)j] = (uint8_t)((C.pac[l >> 2] >> ((~l & 3) << 1)) & 3); }
@@ -137,9 +138,16 @@ bool run_batch(Ctx &C, std::vector<Rec> &recs, bool paired)
         }
     }
     std::vector<int32_t> dist(items.size(), -1);
+    if (use_sw) {                                               // ssw_align flag 0: score1 of the forward pass (polish.c:509-512); always a score
+        if (!items.empty() && salt_gpu_polish_sw(C.gp, codes.data(), offs.data(), n, items.data(), (uint32_t)items.size(), 0, dist.data(), nullptr, nullptr, nullptr)) {
+            fprintf(stderr, "[polish] %s\n", salt_gpu_last_error()); return false;
+        }
+        for (Rec &r : recs) for (int s = 0; s < 2; ++s) for (Hit &x : r.h[s]) x.score = dist[x.item];
+    } else {
     if (!items.empty() && salt_gpu_polish_lv(C.gp, codes.data(), offs.data(), n, items.data(), (uint32_t)items.size(), pool.data(), stride, (uint32_t)(pool.size() / stride), 0,
                                             dist.data(), nullptr, nullptr)) { fprintf(stderr, "[polish] %s\n", salt_gpu_last_error()); return false; }
     for (Rec &r : recs) for (int s = 0; s < 2; ++s) for (Hit &x : r.h[s]) x.score = dist[x.item] == -1 ? UNMAPPED : -dist[x.item];
+    }
     // ---- winners ----
     auto pick = [](Rec &r) {                                    // polish.c:718-737
         int best0 = UNMAPPED, best1 = UNMAPPED;
@@ -189,15 +197,28 @@ bool run_batch(Ctx &C, std::vector<Rec> &recs, bool paired)
     for (Rec &r : recs) {
         if (r.strand == -1 || r.primary == -1) continue;
         const Hit &x = r.h[r.strand][(size_t)r.primary];
-        if (x.score == -MAX_DISTANCE) { r.cigar = "*"; continue; }                        // polish.c:231-233
-        if (x.score == UNMAPPED) { fprintf(stderr, "[polish] %s: the mate of a proper pair has no alignment within %d edits (the reference runs its CIGAR routine with k = 100000 here)\n", r.name, MAX_DISTANCE); return false; }
-        salt_polish_item_t itx; itx.read = r.read; itx.offset = x.offset; itx.pool = 0xFFFFFFFFu; itx.strand = (uint8_t)r.strand; itx.k = (uint8_t)(-x.score);
+        if (!use_sw && x.score == -MAX_DISTANCE) { r.cigar = "*"; continue; }             // polish.c:231-233
+        if (!use_sw && x.score == UNMAPPED) { fprintf(stderr, "[polish] %s: the mate of a proper pair has no alignment within %d edits (the reference runs its CIGAR routine with k = 100000 here)\n", r.name, MAX_DISTANCE); return false; }
+        salt_polish_item_t itx; itx.read = r.read; itx.offset = x.offset; itx.pool = 0xFFFFFFFFu; itx.strand = (uint8_t)r.strand; itx.k = use_sw ? 0 : (uint8_t)(-x.score);
         int l_ref = r.l_seq;
         if ((uint64_t)x.offset + (uint64_t)l_ref > C.l_pac) l_ref = (int)(C.l_pac - x.offset);
         itx.tlen = (uint16_t)l_ref;
         owner.push_back(r.read); citems.push_back(itx);
     }
-    if (!citems.empty()) {
+    if (!citems.empty() && use_sw) {                            // ssw_align flag 2 with filters = the hit's score (polish.c:209-222)
+        std::vector<int32_t> cd(citems.size()), span(2 * citems.size()); std::vector<uint16_t> cg(citems.size() * SALT_MAX_CIGAR_OPS), nc(citems.size());
+        if (salt_gpu_polish_sw(C.gp, codes.data(), offs.data(), n, citems.data(), (uint32_t)citems.size(), 1, cd.data(), span.data(), cg.data(), nc.data())) {
+            fprintf(stderr, "[polish] %s\n", salt_gpu_last_error()); return false;
+        }
+        for (size_t k = 0; k < citems.size(); ++k) {
+            Rec &r = recs[owner[k]];
+            if (cd[k] != r.h[r.strand][(size_t)r.primary].score) { fprintf(stderr, "push cigar error!\n"); return false; }      // polish.c:211-214
+            char tmp[16];
+            if (span[2 * k] != 0) { snprintf(tmp, sizeof tmp, "%dS", span[2 * k]); r.cigar += tmp; }
+            for (int j = 0; j < nc[k]; ++j) { const uint16_t op = cg[k * SALT_MAX_CIGAR_OPS + (size_t)j]; snprintf(tmp, sizeof tmp, "%u%c", op >> 4, "MID"[op & 3]); r.cigar += tmp; }
+            if (span[2 * k + 1] + 1 != r.l_seq) { snprintf(tmp, sizeof tmp, "%dS", r.l_seq - span[2 * k + 1] - 1); r.cigar += tmp; }
+        }
+    } else if (!citems.empty()) {
         std::vector<int32_t> cd(citems.size()); std::vector<uint16_t> cg(citems.size() * SALT_MAX_CIGAR_OPS); std::vector<uint8_t> nc(citems.size());
         if (salt_gpu_polish_lv(C.gp, codes.data(), offs.data(), n, citems.data(), (uint32_t)citems.size(), nullptr, stride, 0, 1, cd.data(), cg.data(), nc.data())) {
             fprintf(stderr, "[polish] %s\n", salt_gpu_last_error()); return false;
@@ -261,7 +282,7 @@ bool run_batch(Ctx &C, std::vector<Rec> &recs, bool paired)
 int usage()
 {
     fprintf(stderr, "\npolish  [OPT]  <index.prefix>  <SAM>\n\nOPT:    -h, --help  print help\n        -p, --pe    paired end mode\n"
-                    "        (-s / --sw, Smith-Waterman re-scoring, is not built in this implementation)\n\n");
+                    "        -s, --sw    re-score by Smith-Waterman instead of edit distance\n\n");
     return 0;
 }
 
@@ -270,10 +291,10 @@ int usage()
 int main(int argc, char **argv)
 {
     static const struct option lo[] = { { "sw", 0, 0, 's' }, { "help", 0, 0, 'h' }, { "pe", 0, 0, 'p' }, { 0, 0, 0, 0 } };
-    int c, paired = 0;
+    int c, paired = 0, use_sw = 0;
     while ((c = getopt_long(argc, argv, "shp", lo, nullptr)) >= 0) {
         if (c == 'p') paired = 1;
-        else if (c == 's') { fprintf(stderr, "[polish] -s (Smith-Waterman re-scoring) is not built; the default Landau-Vishkin mode is\n"); return 1; }
+        else if (c == 's') use_sw = 1;
         else if (c == 'h') return usage();
         else { fprintf(stderr, "Unkown argument!\n"); usage(); return 1; }
     }
@@ -298,10 +319,10 @@ int main(int argc, char **argv)
         recs.emplace_back();
         recs.back().line.assign(line, (size_t)got);
         if (!parse(recs.back())) { fprintf(stderr, "[polish] malformed SAM record: %.60s\n", line); ok = false; break; }
-        if (recs.size() == BATCH) { if (!(ok = run_batch(C, recs, paired != 0))) break; recs.clear(); }
+        if (recs.size() == BATCH) { if (!(ok = run_batch(C, recs, paired != 0, use_sw != 0))) break; recs.clear(); }
     }
     if (ok && paired && (recs.size() & 1)) recs.pop_back();     // a last record without its mate is dropped (polish.c:455-456, 652-653)
-    if (ok && !recs.empty()) ok = run_batch(C, recs, paired != 0);
+    if (ok && !recs.empty()) ok = run_batch(C, recs, paired != 0, use_sw != 0);
     free(line); fclose(fp);
     salt_gpu_polish_close(C.gp);
     salt_index_free(C.ix);

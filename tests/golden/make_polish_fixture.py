@@ -43,6 +43,10 @@ CASES = (("expect_polish_se_lv.sam", [], "expect_se_default.sam"), ("expect_poli
          ("expect_polish_pe_sw.sam", ["-p", "-s"], "expect_pe_default.sam"))
 
 
+EDGE_CASES = (("expect_polish_edge_se.sam", []), ("expect_polish_edge_pe.sam", ["-p"]),
+              ("expect_polish_edge_se_sw.sam", ["-s"]), ("expect_polish_edge_pe_sw.sam", ["-p", "-s"]))
+
+
 def main():
     idx = os.path.join(L, "idx")
     for f in os.listdir(L):
@@ -62,7 +66,7 @@ def main():
     from polish_edge import edge_records
     src = os.path.join(L, "polish_edge_in.sam")
     open(src, "w").write("@HD\tVN:1\n" + "\n".join(edge_records()) + "\n")
-    for out, args in (("expect_polish_edge_se.sam", []), ("expect_polish_edge_pe.sam", ["-p"])):
+    for out, args in EDGE_CASES:
         with open(os.path.join(L, out), "wb") as f:
             p = subprocess.run([POLISH] + args + [idx, src], stdout=f, stderr=subprocess.PIPE)
         print(out, "rc", p.returncode, os.path.getsize(os.path.join(L, out)), p.stderr.decode()[-200:])

@@ -1,6 +1,7 @@
 """N4 -- the product's `polish` (salt_amd/host/polish_main.cc; every edit distance and CIGAR by k_polish on the GPU) against the outputs
-of the REAL reference `polish` committed under tests/golden/lambda/expect_polish_*_lv.sam, and against the oracle's restatement on
-inputs the fixtures do not hold: windows clipped at the genome end (the reference's shrinking window + stale buffer), many XA hits."""
+(default) or by k_sw with polish's matrix (-s)) against the outputs of the REAL reference `polish` committed under
+tests/golden/lambda/expect_polish_*.sam, including hand-made edge cases: windows clipped at the genome end (the reference's shrinking
+window + stale buffer), many XA hits."""
 import os
 import subprocess
 import sys
@@ -12,7 +13,7 @@ from conftest import GOLDEN, LAMBDA, ROOT
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, GOLDEN)
-from make_polish_fixture import CASES, polish_input          # noqa: E402
+from make_polish_fixture import CASES, EDGE_CASES, polish_input          # noqa: E402
 
 POLISH = os.path.join(ROOT, "salt_amd", "bin", "polish")
 
@@ -25,7 +26,7 @@ def lam_index(tmp_path_factory):
     return prefix
 
 
-@pytest.mark.parametrize("out,args,src", [c for c in CASES if "-s" not in c[1]])
+@pytest.mark.parametrize("out,args,src", CASES)
 def test_polish_equals_the_reference(out, args, src, lam_index, tmp_path):
     sam = tmp_path / "in.sam"
     sam.write_bytes(polish_input(os.path.join(LAMBDA, src), "-p" in args))
@@ -34,20 +35,19 @@ def test_polish_equals_the_reference(out, args, src, lam_index, tmp_path):
     assert p.stdout == open(os.path.join(LAMBDA, out), "rb").read()
 
 
-def test_polish_refuses_what_it_does_not_build(lam_index, tmp_path):
-    sam = tmp_path / "in.sam"
-    sam.write_bytes(polish_input(os.path.join(LAMBDA, "expect_se_default.sam"), False))
-    p = subprocess.run([POLISH, "-s", lam_index, str(sam)], capture_output=True)
-    assert p.returncode == 1 and b"not built" in p.stderr and p.stdout == b""
+def test_polish_needs_the_gpu_library_entry_points():
+    """both scoring modes are device calls: the binary links salt_gpu_polish_lv and salt_gpu_polish_sw and nothing that scores on the host"""
+    syms = subprocess.run(["nm", "-D", "--undefined-only", POLISH], capture_output=True, text=True).stdout
+    assert "salt_gpu_polish_lv" in syms and "salt_gpu_polish_sw" in syms
 
 
-@pytest.mark.parametrize("out,args", [("expect_polish_edge_se.sam", []), ("expect_polish_edge_pe.sam", ["-p"])])
+@pytest.mark.parametrize("out,args", EDGE_CASES)
 def test_polish_edge_cases_equal_the_reference(out, args, lam_index):
     """tests/polish_edge.py: reads with a dozen XA hits on both strands and in both contigs, hits that coincide after the offset sort,
     pairs that are / are not 350..650 apart, and hits whose window runs past the end of the genome (the reference clips the window, keeps
     the shorter length for the rest of the record and leaves the previous window's bases behind the clip).  Expected output: the REAL
     reference's (tests/golden/make_polish_fixture.py)."""
-    p = subprocess.run([POLISH] + args + [lam_index, os.path.join(LAMBDA, "polish_edge_in.sam")], capture_output=True)
+    p = subprocess.run([POLISH] + list(args) + [lam_index, os.path.join(LAMBDA, "polish_edge_in.sam")], capture_output=True)
     assert p.returncode == 0, p.stderr[-300:]
     g, w = p.stdout.split(b"\n"), open(os.path.join(LAMBDA, out), "rb").read().split(b"\n")
     bad = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]

@@ -10,7 +10,7 @@ import pytest
 from conftest import GOLDEN, LAMBDA, ROOT
 
 sys.path.insert(0, GOLDEN)
-from make_polish_fixture import CASES, polish_input          # noqa: E402
+from make_polish_fixture import CASES, EDGE_CASES, polish_input          # noqa: E402
 
 
 @pytest.mark.parametrize("out,args,src", CASES)
@@ -23,9 +23,9 @@ def test_polish_oracle_equals_the_reference(out, args, src, oracle_lib, tmp_path
     assert p.stdout == open(os.path.join(LAMBDA, out), "rb").read()
 
 
-@pytest.mark.parametrize("out,args", [("expect_polish_edge_se.sam", []), ("expect_polish_edge_pe.sam", ["-p"])])
+@pytest.mark.parametrize("out,args", EDGE_CASES)
 def test_polish_oracle_equals_the_reference_on_edge_cases(out, args, oracle_lib):
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "polish_oracle"], check=True, stdout=subprocess.DEVNULL)
-    p = subprocess.run([os.path.join(ROOT, "oracle", "polish_oracle")] + args + [os.path.join(LAMBDA, "idx"), os.path.join(LAMBDA, "polish_edge_in.sam")], capture_output=True)
+    p = subprocess.run([os.path.join(ROOT, "oracle", "polish_oracle")] + list(args) + [os.path.join(LAMBDA, "idx"), os.path.join(LAMBDA, "polish_edge_in.sam")], capture_output=True)
     assert p.returncode == 0, p.stderr[-300:]
     assert p.stdout == open(os.path.join(LAMBDA, out), "rb").read()
