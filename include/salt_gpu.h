@@ -180,6 +180,12 @@ int  salt_gpu_ws_pe_counts(salt_gpu_ws_t *ws, uint32_t out[8]);
  * Multi-line FASTQ records are not read here (SALT_E_INVAL names the record); callers fall back to their host parser. */
 typedef struct { int32_t print_xa_cigar, print_nm_md; const char *rg_id; } salt_text_opt_t;      /* -c, -d, -g */
 int  salt_gpu_index_set_contigs(salt_gpu_index_t *ix, int32_t n, const int64_t *offsets, const char *const *names);
+/* optional: size the workspace's text buffers ahead of the first call (blocks of up to max_block_bytes with about est_reads reads of
+ * up to max_read_len bases, about est_sam_bytes of SAM); what a later block needs beyond that is grown then.  host_sam (may be NULL):
+ * page-locked memory of the caller's (salt_gpu_host_alloc, e.g. allocated while the index was loading) the SAM text is returned in as
+ * long as it suffices; it stays the caller's to free, after the workspace is destroyed. */
+int  salt_gpu_ws_reserve_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, uint64_t max_block_bytes, uint32_t est_reads, uint32_t max_read_len,
+                              uint64_t est_sam_bytes, void *host_sam, uint64_t host_sam_bytes);
 int  salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, const salt_text_opt_t *topt, const char *fastq, uint64_t n_bytes,
                             const char **sam, uint64_t *sam_bytes, uint32_t *n_reads);
 int  salt_gpu_host_alloc(uint64_t bytes, void **ptr);      /* page-locked host memory for the text buffers */

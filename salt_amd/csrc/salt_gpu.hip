@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <cstddef>
 #include <string>
 #include <thread>
@@ -52,6 +53,8 @@ struct salt_gpu_ws {
     uint8_t *d_raw = nullptr; uint64_t raw_cap = 0; uint32_t *d_tile = nullptr; uint64_t tile_cap = 0; uint32_t *d_lines = nullptr; uint64_t lines_cap = 0;
     FqRec *d_rec = nullptr; uint32_t *d_tctl = nullptr, *d_samoff = nullptr; void *d_scan = nullptr; size_t scan_bytes = 0;
     char *d_sam = nullptr, *h_sam = nullptr; uint64_t sam_cap = 0; char *d_rg = nullptr; std::string rg;
+    bool h_sam_owned = true;                                                 // false: the caller's page-locked buffer (salt_gpu_ws_reserve_text)
+    uint32_t text_calls = 0;                                                 // SALT_TEXT_TRACE: stage clocks of the first text call
     uint32_t heavy_blocks = 2048;
     int all_heavy = 0;
     hipStream_t stream = nullptr;
@@ -306,7 +309,7 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
     hipSetDevice(ws->ix->device);
     hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_heads); if (ws->h_heads) hipHostFree(ws->h_heads); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gap);
     hipFree(ws->d_raw); hipFree(ws->d_tile); hipFree(ws->d_lines); hipFree(ws->d_rec); hipFree(ws->d_tctl); hipFree(ws->d_samoff); hipFree(ws->d_scan); hipFree(ws->d_sam); hipFree(ws->d_rg);
-    if (ws->h_sam) hipHostFree(ws->h_sam);
+    if (ws->h_sam && ws->h_sam_owned) hipHostFree(ws->h_sam);
     hipFree(ws->d_pe_scr); hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres); hipFree(ws->d_pctl); hipFree(ws->d_sw_scr); hipFree(ws->d_pcq);
     if (ws->stream) hipStreamDestroy(ws->stream);
     for (auto &e : ws->ev) if (e) hipEventDestroy(e);
@@ -478,6 +481,7 @@ extern "C" int salt_gpu_index_set_contigs(salt_gpu_index_t *ix, int32_t n, const
     HIPCHK(hipMemcpy(ix->d_c_name_off, noff.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ix->d_c_names, blob.data(), blob.size(), hipMemcpyHostToDevice));
     ix->n_contigs = n;
+    HIPCHK(text_warm());                                     // the text kernels' code object is loaded now, not inside the first block's call
     return SALT_OK;
 }
 
@@ -492,6 +496,53 @@ extern "C" void salt_gpu_host_free(void *ptr) { if (ptr) hipHostFree(ptr); }
 #define REGROW(ptr, cap, need, type) do { if ((need) > (cap)) { HIPCHK(hipStreamSynchronize(st)); hipFree(ptr); (ptr) = nullptr; (cap) = 0; \
     const uint64_t want_ = (need) + (need) / 4; HIPCHK(hipMalloc((void **)&(ptr), want_ * sizeof(type))); (cap) = want_; } } while (0)
 
+// Sizes every buffer a text call of up to max_block_bytes / est_reads reads of max_read_len bases will ask for, so that the first call
+// on the workspace finds them (a later, larger block still regrows them).  One-time work a driver does next to attaching the index.
+extern "C" int salt_gpu_ws_reserve_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint64_t max_block_bytes, uint32_t est_reads, uint32_t max_read_len,
+                                        uint64_t est_sam_bytes, void *host_sam, uint64_t host_sam_bytes)
+{
+    if (!ws || !o || max_block_bytes == 0 || est_reads == 0) return fail(SALT_E_INVAL, "bad reserve arguments");
+    if (est_reads > ws->max_reads) est_reads = ws->max_reads;
+    uint32_t spr = 0;
+    int rc = check_opt(ws->ix, o, max_read_len, &spr);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ws->ix->device));
+    hipStream_t st = ws->stream;
+    REGROW(ws->d_raw, ws->raw_cap, max_block_bytes + 64, uint8_t);
+    if (!ws->d_tctl) HIPCHK(hipMalloc((void **)&ws->d_tctl, 16));
+    REGROW(ws->d_tile, ws->tile_cap, ws->raw_cap / FQ_TILE + 4, uint32_t);
+    {
+        const size_t need = text_scan_bytes(std::max<uint64_t>(ws->tile_cap, (uint64_t)ws->max_reads + 2));
+        if (need > ws->scan_bytes) { hipFree(ws->d_scan); ws->d_scan = nullptr; ws->scan_bytes = 0; HIPCHK(hipMalloc(&ws->d_scan, need)); ws->scan_bytes = need; }
+    }
+    REGROW(ws->d_lines, ws->lines_cap, 4ull * est_reads + 8, uint32_t);
+    if (!ws->d_rec) HIPCHK(hipMalloc((void **)&ws->d_rec, (uint64_t)ws->max_reads * sizeof(FqRec)));
+    if (!ws->d_samoff) HIPCHK(hipMalloc((void **)&ws->d_samoff, ((uint64_t)ws->max_reads + 2) * 4));
+    const uint64_t items = (uint64_t)est_reads * 2u * spr;
+    if (items > ws->sai_cap) {
+        hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); ws->d_sai_c = ws->d_sai_r = nullptr; ws->sai_cap = 0;
+        HIPCHK(hipMalloc((void **)&ws->d_sai_c, items * sizeof(uint4)));
+        HIPCHK(hipMalloc((void **)&ws->d_sai_r, items * sizeof(uint4)));
+        ws->sai_cap = items;
+    }
+    const PackGeom pg = PackGeom::make(max_read_len);
+    if ((uint64_t)ws->max_reads * pg.pm_stride > ws->pm_cap || (uint64_t)ws->max_reads * pg.tb_stride > ws->tb_cap) {
+        hipFree(ws->d_pm); hipFree(ws->d_tb); ws->d_pm = ws->d_tb = nullptr; ws->pm_cap = ws->tb_cap = 0;
+        HIPCHK(hipMalloc((void **)&ws->d_pm, (uint64_t)ws->max_reads * pg.pm_stride * 4));
+        HIPCHK(hipMalloc((void **)&ws->d_tb, (uint64_t)ws->max_reads * pg.tb_stride * 4));
+        ws->pm_cap = (uint64_t)ws->max_reads * pg.pm_stride; ws->tb_cap = (uint64_t)ws->max_reads * pg.tb_stride;
+    }
+    if (host_sam && host_sam_bytes > est_sam_bytes + 64) est_sam_bytes = host_sam_bytes - 64;
+    if (est_sam_bytes + 64 > ws->sam_cap) {
+        hipFree(ws->d_sam); ws->d_sam = nullptr; if (ws->h_sam && ws->h_sam_owned) hipHostFree(ws->h_sam); ws->h_sam = nullptr; ws->sam_cap = 0;
+        HIPCHK(hipMalloc((void **)&ws->d_sam, est_sam_bytes + 64));
+        if (host_sam && host_sam_bytes >= est_sam_bytes + 64) { ws->h_sam = static_cast<char *>(host_sam); ws->h_sam_owned = false; }
+        else { HIPCHK(hipHostMalloc((void **)&ws->h_sam, est_sam_bytes + 64, hipHostMallocDefault)); ws->h_sam_owned = true; }
+        ws->sam_cap = est_sam_bytes + 64;
+    }
+    return SALT_OK;
+}
+
 extern "C" int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_text_opt_t *to, const char *fastq, uint64_t n_bytes,
                                       const char **sam, uint64_t *sam_bytes, uint32_t *n_reads)
 {
@@ -504,6 +555,10 @@ extern "C" int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
     if (!ix->d_c_off) return fail(SALT_E_INVAL, "SAM text needs the contig table: call salt_gpu_index_set_contigs first");
     HIPCHK(hipSetDevice(ix->device));
     hipStream_t st = ws->stream;
+    const bool trace = ws->text_calls++ == 0 && getenv("SALT_TEXT_TRACE");
+    double tm[8]; int n_tm = 0;
+    auto mark = [&]() { if (trace && n_tm < 8) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); tm[n_tm++] = (double)ts.tv_sec + ts.tv_nsec * 1e-9; } };
+    mark();
     // ---- the raw block and its lines ----
     REGROW(ws->d_raw, ws->raw_cap, n_bytes + 64, uint8_t);
     const uint64_t n_tiles = (n_bytes + FQ_TILE - 1) / FQ_TILE;
@@ -514,6 +569,7 @@ extern "C" int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
         const size_t need = text_scan_bytes(std::max<uint64_t>(ws->tile_cap, (uint64_t)ws->max_reads + 2));
         if (need > ws->scan_bytes) { HIPCHK(hipStreamSynchronize(st)); hipFree(ws->d_scan); ws->d_scan = nullptr; ws->scan_bytes = 0; HIPCHK(hipMalloc(&ws->d_scan, need)); ws->scan_bytes = need; }
     }
+    mark();
     HIPCHK(hipMemcpyAsync(ws->d_raw, fastq, n_bytes, hipMemcpyHostToDevice, st));
     // newline count first: the line table is sized by it
     uint32_t n_nl = 0;
@@ -524,6 +580,7 @@ extern "C" int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
     const uint32_t n_rec = n_nl / 4;
     if (n_rec > ws->max_reads) return fail(SALT_E_CAPACITY, "more reads in the block (" + std::to_string(n_rec) + ") than the workspace holds");
     if (n_rec == 0) return SALT_OK;
+    mark();
     REGROW(ws->d_lines, ws->lines_cap, (uint64_t)n_nl + 8, uint32_t);
     HIPCHK(launch_fq_lines(ws->d_raw, n_bytes, ws->d_tile, ws->d_lines, st));
     // ---- records, offsets, codes ----
@@ -546,8 +603,10 @@ extern "C" int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
     }
     HIPCHK(launch_fq_codes(ws->d_raw, ws->d_rec, ws->d_offs, n_rec, ws->d_seqs, st));
     // ---- align ----
+    mark();
     int rc = align_resident_impl(ws, o, n_rec, ctl[1], ws->d_seqs, ws->d_offs, ws->d_results, st, 0);
     if (rc) return rc;
+    mark();
     // ---- SAM text ----
     const std::string rg = to->rg_id ? to->rg_id : "";
     if (rg != ws->rg || (!rg.empty() && !ws->d_rg)) {
@@ -567,16 +626,23 @@ extern "C" int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
     uint32_t total = 0;
     HIPCHK(hipMemcpyAsync(&total, ws->d_samoff + n_rec, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    mark();
     if ((uint64_t)total + 64 > ws->sam_cap) {
-        hipFree(ws->d_sam); ws->d_sam = nullptr; if (ws->h_sam) { hipHostFree(ws->h_sam); ws->h_sam = nullptr; } ws->sam_cap = 0;
+        hipFree(ws->d_sam); ws->d_sam = nullptr; if (ws->h_sam && ws->h_sam_owned) hipHostFree(ws->h_sam); ws->h_sam = nullptr; ws->sam_cap = 0; ws->h_sam_owned = true;
         const uint64_t want = (uint64_t)total + total / 4 + 64;
         HIPCHK(hipMalloc((void **)&ws->d_sam, want));
         HIPCHK(hipHostMalloc((void **)&ws->h_sam, want, hipHostMallocDefault));
         ws->sam_cap = want;
     }
+    mark();
     HIPCHK(launch_sam_write(d, n_rec, ws->d_samoff, ws->d_sam, st));
     HIPCHK(hipMemcpyAsync(ws->h_sam, ws->d_sam, total, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    mark();
+    if (trace && n_tm == 8)
+        fprintf(stderr, "[salt_gpu] first text call (ms): raw buffers %.1f, copy in + count %.1f, lines/parse/codes %.1f, align launch (+ its buffers) %.1f, "
+                        "kernels + SAM lengths %.1f, SAM buffers %.1f, write + copy out %.1f\n", (tm[1] - tm[0]) * 1e3, (tm[2] - tm[1]) * 1e3, (tm[3] - tm[2]) * 1e3,
+                (tm[4] - tm[3]) * 1e3, (tm[5] - tm[4]) * 1e3, (tm[6] - tm[5]) * 1e3, (tm[7] - tm[6]) * 1e3);
     *sam = ws->h_sam; *sam_bytes = total; *n_reads = n_rec;
     return SALT_OK;
 }

@@ -115,6 +115,7 @@ struct SamDev {                                                               //
     const uint32_t *text, *ref;                                                // 2-bit genome, mixRef
     int32_t xa_cigar, nm_md; const char *rg; int32_t rg_len;
 };
+hipError_t text_warm();                                     // forces the load of the text kernels' code object
 size_t text_scan_bytes(uint64_t max_items);
 hipError_t launch_fq_count(const uint8_t *raw, uint64_t n, uint32_t *tile_cnt, void *tmp, size_t tmp_bytes, hipStream_t st);
 hipError_t launch_fq_lines(const uint8_t *raw, uint64_t n, const uint32_t *tile_off, uint32_t *line_start, hipStream_t st);

@@ -254,6 +254,12 @@ __global__ void __launch_bounds__(256) k_sam_write(SamDev d, uint32_t n, const u
 }
 
 // ---- launchers (all on stream st; scan temporaries are the caller's) ----
+hipError_t text_warm()
+{
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_fq_lines));
+}
+
 size_t text_scan_bytes(uint64_t max_items)
 {
     size_t b = 0;

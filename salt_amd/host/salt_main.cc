@@ -325,17 +325,19 @@ int usage()
 // back (salt_gpu_align_se_text: parse, align and format are kernels), and the host only moves bytes:
 //   every worker claims the next chunk of the file (pread into page-locked memory), cuts it at record boundaries -- a record starts
 //   at a line that begins with '@' and whose next-but-one line begins with '+' (a quality line may begin with '@', but then the
-//   line two further on is a sequence) --, calls the device, and writes its SAM block at the offset the blocks before it add up to
-//   (pwrite, in parallel, when stdout is a regular file; in turn otherwise).  Output order = input order, as the reference's puts
-//   loop gives it (alnse.c:1433-1439).
+//   line two further on is a sequence) --, calls the device, and writes its SAM block when the blocks before it have been written.
+//   One writer at a time also for regular files: buffered writes to one file serialize on the inode anyway (one thread alone writes
+//   10.6 GB/s into the page cache of the GPU box, eight threads with pwrite at their own offsets 9.5 GB/s between them), and the
+//   blocks behind the one being written are read and aligned meanwhile.  Output order = input order, as the reference's puts loop
+//   gives it (alnse.c:1433-1439).
 // ---------------------------------------------------------------------------------------------
 struct TextRun {
     int fd = -1; uint64_t file_size = 0, chunk = 0;
     std::atomic<uint64_t> next_chunk{ 0 };
-    // output sequencing: block k may learn its offset once block k - 1 has published its end, and (stream mode) write once k - 1 has written
+    // output sequencing: block k is written once block k - 1 has been
     std::mutex mu; std::condition_variable cv;
-    uint64_t sized = 0, written = 0; uint64_t out_off = 0; long reads_done = 0;
-    bool out_seekable = false; int out_fd = 1;
+    uint64_t written = 0; long reads_done = 0;
+    int ready = 0; bool go = false;                         // workers that finished their set-up; the clock starts when all have
     std::atomic<bool> failed{ false };
 };
 
@@ -363,7 +365,72 @@ static uint64_t next_record_start(const char *buf, uint64_t n, uint64_t from, bo
     return n;
 }
 
-static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector<salt_gpu_index_t *> &gix, int n_gpus, int n_workers_per_gpu,
+// What the text path needs to know before the index is there: chunk size, workers, and -- from the first 64 KB of the file -- how many
+// reads a chunk is expected to hold and how much SAM they turn into.  Workspaces are sized by that expectation (+ 30 %), not by the
+// worst case of 32-byte records; a chunk that holds more reads (SALT_E_CAPACITY) has its worker re-create the workspace for the worst
+// case and call again.
+struct TextPlan {
+    uint64_t chunk = 0, in_cap = 0, sam_cap = 0;
+    int n_workers = 0, wpg = 0;
+    uint32_t worst_reads = 0, max_reads = 0, head_read_len = 0;
+    // page-locked buffers, allocated by a thread of their own while the index is loaded and attached
+    std::vector<char *> in_buf, sam_buf;
+    std::thread alloc; bool alloc_ok = true; double alloc_s = 0;
+    ~TextPlan();
+};
+
+static void text_plan(TextPlan &P, const char *fn_reads, int n_gpus, int n_threads)
+{
+    { const char *e = getenv("SALT_CHUNK_MB"); int mb = e ? atoi(e) : 32; if (mb < 1) mb = 1; if (mb > 1024) mb = 1024; P.chunk = (uint64_t)mb << 20; }
+    if (const char *e = getenv("SALT_CHUNK_BYTES")) { long v = atol(e); if (v >= 256) P.chunk = (uint64_t)v; }      // tests: many chunks on a small file
+    // workers per GPU: each preads a chunk, calls the device and writes its block in turn.  The write stream is the narrow part (one
+    // writer at a time); three to four workers keep it busy, more only lengthen the start-up (measured 2: 25.8, 3: 28.7, 4: 27.9,
+    // 6: 24.2, 8: 23.8 Mreads/s on 16 M reads)
+    P.wpg = n_threads / n_gpus >= 4 ? 4 : 2;
+    if (const char *e = getenv("SALT_TEXT_WORKERS")) { int v = atoi(e); if (v >= 1 && v <= 32) P.wpg = v; }
+    P.n_workers = n_gpus * P.wpg;
+    P.worst_reads = (uint32_t)((P.chunk + TEXT_SLACK) / 32);
+    P.max_reads = P.worst_reads;
+    double sam_per_fq_byte = 1.5;                            // SAM bytes a FASTQ byte turns into, for the first sizing of the SAM buffers
+    char head[65536];
+    ssize_t got = -1;
+    { const int fd = open(fn_reads, O_RDONLY); if (fd >= 0) { got = pread(fd, head, sizeof head, 0); close(fd); } }
+    uint64_t lines = 0, last_rec_end = 0, line_start = 0, name_bytes = 0;
+    for (ssize_t i = 0; i < got; ++i)
+        if (head[i] == '\n') {
+            const uint32_t len = (uint32_t)((uint64_t)i - line_start);
+            if ((lines & 3) == 0) name_bytes += len;
+            if ((lines & 3) == 1 && len > P.head_read_len) P.head_read_len = len;
+            line_start = (uint64_t)i + 1;
+            if ((++lines & 3) == 0) last_rec_end = (uint64_t)i + 1;
+        }
+    if (lines >= 4 && last_rec_end) {
+        const double n_rec = (double)(lines / 4), rec_bytes = (double)last_rec_end / n_rec;
+        const double est = (double)(P.chunk + TEXT_SLACK) / rec_bytes * 1.3 + 1024.0;
+        if (est < (double)P.worst_reads) P.max_reads = (uint32_t)est;
+        // a record: name, the fixed fields (~45 bytes), SEQ, QUAL, tags (NM MD XV XA: ~40 + alternative hits)
+        sam_per_fq_byte = (name_bytes / n_rec + 2.0 * P.head_read_len + 160.0) / rec_bytes;
+    }
+    if (P.head_read_len > SALT_MAX_READ_LEN) P.head_read_len = 0;      // the call itself reports it
+    P.in_cap = P.chunk + 2 * TEXT_SLACK + 64;
+    P.sam_cap = (uint64_t)((double)(P.chunk + TEXT_SLACK) * sam_per_fq_byte) + 4096;
+    P.in_buf.assign((size_t)P.n_workers, nullptr); P.sam_buf.assign((size_t)P.n_workers, nullptr);
+    P.alloc = std::thread([&P]() {
+        const double t = now();
+        for (int w = 0; w < P.n_workers && P.alloc_ok; ++w)
+            if (salt_gpu_host_alloc(P.in_cap, (void **)&P.in_buf[(size_t)w]) || salt_gpu_host_alloc(P.sam_cap, (void **)&P.sam_buf[(size_t)w])) P.alloc_ok = false;
+        P.alloc_s = now() - t;
+    });
+}
+
+TextPlan::~TextPlan()
+{
+    if (alloc.joinable()) alloc.join();
+    for (char *b : in_buf) if (b) salt_gpu_host_free(b);
+    for (char *b : sam_buf) if (b) salt_gpu_host_free(b);
+}
+
+static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector<salt_gpu_index_t *> &gix, int n_gpus, TextPlan &P,
                        const salt_aln_opt_t &ao, const salt_sam_opt_t &so, double t0)
 {
     TextRun R;
@@ -372,12 +439,8 @@ static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector
     struct stat sb;
     if (fstat(R.fd, &sb) != 0) { fprintf(stderr, "[salt] cannot stat %s\n", fn_reads); return 1; }
     R.file_size = (uint64_t)sb.st_size;
-    { const char *e = getenv("SALT_CHUNK_MB"); int mb = e ? atoi(e) : 32; if (mb < 1) mb = 1; if (mb > 1024) mb = 1024; R.chunk = (uint64_t)mb << 20; }
-    if (const char *e = getenv("SALT_CHUNK_BYTES")) { long v = atol(e); if (v >= 256) R.chunk = (uint64_t)v; }      // tests: many chunks on a small file
+    R.chunk = P.chunk;
     fflush(stdout);
-    struct stat ob;
-    R.out_seekable = fstat(1, &ob) == 0 && S_ISREG(ob.st_mode) && !(fcntl(1, F_GETFL) & O_APPEND);      // pwrite ignores its offset on O_APPEND files
-    if (R.out_seekable) { off_t cur = lseek(1, 0, SEEK_CUR); if (cur < 0) R.out_seekable = false; else R.out_off = (uint64_t)cur; }
     // contig table for RNAME / POS on the device
     {
         const int n = salt_index_n_seqs(ix);
@@ -386,20 +449,26 @@ static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector
         for (int g = 0; g < n_gpus; ++g)
             if (salt_gpu_index_set_contigs(gix[(size_t)g], n, off.data(), nm.data())) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
     }
-    const int n_workers = n_gpus * n_workers_per_gpu;
-    const uint32_t max_reads = (uint32_t)((R.chunk + TEXT_SLACK) / 32);
+    if (P.alloc.joinable()) P.alloc.join();
+    if (!P.alloc_ok) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
+    const int n_workers = P.n_workers, n_workers_per_gpu = P.wpg;
+    const uint32_t worst_reads = P.worst_reads, max_reads = P.max_reads, head_read_len = P.head_read_len;
     const salt_text_opt_t to = { so.print_xa_cigar, so.print_nm_md, so.rg_id };
     const uint64_t n_chunks = (R.file_size + R.chunk - 1) / R.chunk;
     std::vector<std::thread> workers;
-    std::atomic<double> t_read{ 0 }, t_gpu{ 0 }, t_write{ 0 };
+    std::atomic<double> t_read{ 0 }, t_gpu{ 0 }, t_write{ 0 }, t_last{ t0 };     // t_last: when the last SAM byte so far was written
     auto set_failed = [&]() { { std::lock_guard<std::mutex> lk(R.mu); R.failed = true; } R.cv.notify_all(); };
     for (int wk = 0; wk < n_workers; ++wk)
         workers.emplace_back([&, wk]() {
-            salt_gpu_ws_t *ws = nullptr; char *buf = nullptr;
-            const uint64_t cap = R.chunk + 2 * TEXT_SLACK + 64;
-            if (salt_gpu_ws_create(gix[(size_t)(wk / n_workers_per_gpu)], max_reads, (uint64_t)max_reads * 160, &ws) || salt_gpu_host_alloc(cap, (void **)&buf)) {
+            salt_gpu_ws_t *ws = nullptr; char *buf = P.in_buf[(size_t)wk];
+            const bool trace = getenv("SALT_TEXT_TRACE") != nullptr;      // per-worker timeline on stderr
+            const double tw_start = now(); int n_calls = 0; double t_first = 0, t_rest = 0;
+            uint32_t ws_reads = max_reads;
+            if (salt_gpu_ws_create(gix[(size_t)(wk / n_workers_per_gpu)], ws_reads, (uint64_t)ws_reads * 160, &ws) ||
+                (head_read_len && salt_gpu_ws_reserve_text(ws, &ao, R.chunk + TEXT_SLACK, (uint32_t)(ws_reads / 1.3), head_read_len, P.sam_cap - 64, P.sam_buf[(size_t)wk], P.sam_cap))) {
                 fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); set_failed(); return;
             }
+            const double t_setup = now() - tw_start;
             for (;;) {
                 const uint64_t k = R.next_chunk.fetch_add(1);
                 if (k >= n_chunks || R.failed) break;
@@ -425,49 +494,48 @@ static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector
                 const uint64_t beg2 = std::min(beg, end);
                 const char *sam = nullptr; uint64_t sam_bytes = 0; uint32_t n_reads = 0;
                 double tg0 = now();
-                if (end > beg2 && salt_gpu_align_se_text(ws, &ao, &to, buf + beg2, end - beg2, &sam, &sam_bytes, &n_reads)) {
-                    fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); set_failed(); break;
+                int grc = end > beg2 ? salt_gpu_align_se_text(ws, &ao, &to, buf + beg2, end - beg2, &sam, &sam_bytes, &n_reads) : 0;
+                if (grc == SALT_E_CAPACITY && ws_reads < worst_reads) {                         // shorter records than the file's head promised
+                    if (trace) fprintf(stderr, "[salt] worker %d: chunk %llu holds more than %u reads, workspace re-created for %u\n", wk, (unsigned long long)k, ws_reads, worst_reads);
+                    salt_gpu_ws_destroy(ws); ws = nullptr; ws_reads = worst_reads;
+                    grc = salt_gpu_ws_create(gix[(size_t)(wk / n_workers_per_gpu)], ws_reads, (uint64_t)ws_reads * 160, &ws);
+                    if (!grc) grc = salt_gpu_align_se_text(ws, &ao, &to, buf + beg2, end - beg2, &sam, &sam_bytes, &n_reads);
                 }
+                if (grc) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); set_failed(); break; }
                 t_gpu = t_gpu + (now() - tg0);
-                // my offset = the end of block k - 1
-                uint64_t my_off = 0;
+                if (n_calls++ == 0) t_first = now() - tg0; else t_rest += now() - tg0;
+                // block k is written when block k - 1 has been
                 {
                     std::unique_lock<std::mutex> lk(R.mu);
-                    R.cv.wait(lk, [&] { return R.failed || R.sized == k; });
+                    R.cv.wait(lk, [&] { return R.failed || R.written == k; });
                     if (R.failed) break;
-                    my_off = R.out_off; R.out_off += sam_bytes; R.sized = k + 1;
-                    if (R.out_seekable) { R.reads_done += n_reads; fprintf(stderr, "%ld reads have been aligned!\n", R.reads_done); }
-                    R.cv.notify_all();
-                    if (!R.out_seekable) {                                                       // a pipe: blocks are written in turn
-                        R.cv.wait(lk, [&] { return R.failed || R.written == k; });
-                        if (R.failed) break;
-                    }
                 }
                 double tw0 = now();
                 bool ok = true;
                 for (uint64_t w = 0; w < sam_bytes && ok; ) {
-                    ssize_t r = R.out_seekable ? pwrite(1, sam + w, sam_bytes - w, (off_t)(my_off + w)) : write(1, sam + w, sam_bytes - w);
+                    ssize_t r = write(1, sam + w, sam_bytes - w);
                     if (r <= 0) ok = false; else w += (uint64_t)r;
                 }
                 t_write = t_write + (now() - tw0);
+                { const double tn = now(); double cur = t_last.load(); while (tn > cur && !t_last.compare_exchange_weak(cur, tn)) {} }
                 if (!ok) { fprintf(stderr, "[salt] write error on the SAM stream\n"); set_failed(); break; }
-                if (!R.out_seekable) {
+                {
                     std::lock_guard<std::mutex> lk(R.mu);
                     R.written = k + 1; R.reads_done += n_reads;
                     fprintf(stderr, "%ld reads have been aligned!\n", R.reads_done);
-                    R.cv.notify_all();
                 }
+                R.cv.notify_all();
             }
-            salt_gpu_host_free(buf);
+            if (trace) fprintf(stderr, "[salt] worker %d: started %.3f s after the clock, setup %.3f s, first device call %.3f s, %d later calls %.4f s each, done at %.3f s\n", wk,
+                               tw_start - t0, t_setup, t_first, n_calls - 1, n_calls > 1 ? t_rest / (n_calls - 1) : 0.0, now() - t0);
             salt_gpu_ws_destroy(ws);
         });
     for (auto &w : workers) w.join();
-    if (R.out_seekable && !R.failed) lseek(1, (off_t)R.out_off, SEEK_SET);
     close(R.fd);
-    const double dt = now() - t0;
+    const double dt = t_last.load() - t0;                   // first chunk claimed .. last SAM byte written (releasing the workspaces is not alignment time)
     fprintf(stderr, "[alnse_core]: total %lf sec escaped\n", dt);
-    fprintf(stderr, "[salt] text path: %d worker(s), chunk %llu MiB, %s output; seconds summed over workers: read %.3f device call %.3f write %.3f\n", n_workers,
-            (unsigned long long)(R.chunk >> 20), R.out_seekable ? "seekable (parallel pwrite)" : "stream (in turn)", t_read.load(), t_gpu.load(), t_write.load());
+    fprintf(stderr, "[salt] text path: %d worker(s), chunk %llu MiB, blocks written in turn; seconds summed over workers: read %.3f device call %.3f write %.3f "
+                    "(page-locked buffers: %.3f s, while the index was loading)\n", n_workers, (unsigned long long)(R.chunk >> 20), t_read.load(), t_gpu.load(), t_write.load(), P.alloc_s);
     fprintf(stderr, "[salt] %ld reads, %.3f Mreads/s end to end (FASTQ -> SAM, %d GPU(s))\n", R.reads_done, dt > 0 ? R.reads_done / dt / 1e6 : 0.0, n_gpus);
     return R.failed ? 1 : 0;
 }
@@ -513,6 +581,18 @@ int main(int argc, char **argv)
     if (n_gpus < 1) n_gpus = 1;
     const char *prefix = argv[optind], *fn_reads = argv[optind + 1], *fn_mates = pe ? argv[optind + 2] : nullptr;
 
+    // Single end + a plain (not gzipped) strict 4-line FASTQ in a regular file: the text path -- parse, align and format on the device
+    // (run_se_text).  Everything else (paired end, gzip, pipes, multi-line records) goes through the host pipeline below.
+    // SALT_HOST_PIPELINE=1 forces the latter.  Decided before the index is loaded: the text path's page-locked buffers are allocated
+    // by a thread of their own meanwhile.
+    TextPlan plan; bool text_path = false;
+    if (!pe && !(getenv("SALT_HOST_PIPELINE") && atoi(getenv("SALT_HOST_PIPELINE")))) {
+        struct stat sb; unsigned char magic[2] = { 0, 0 };
+        bool plain = stat(fn_reads, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0;
+        if (plain) { FILE *f = fopen(fn_reads, "rb"); plain = f && fread(magic, 1, 2, f) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b); if (f) fclose(f); }
+        text_path = plain && sniff_four_line(fn_reads);
+        if (text_path) text_plan(plan, fn_reads, n_gpus, n_threads);
+    }
     double t0 = now();
     fprintf(stderr, "[alnse_core]:  Reload index...\n");
     salt_index_t *ix = salt_index_load(prefix, 0);
@@ -538,23 +618,13 @@ int main(int argc, char **argv)
         printf("@PG\tID:snpaln\tPN:snpaln\tCL:\"%s\"\tDS:%d-%d-%d\tVN:0.1beta\n", cmd.c_str(), tmv->tm_year + 1900, tmv->tm_mon + 1, tmv->tm_mday);
         return true;
     };
-    // Single end + a plain (not gzipped) strict 4-line FASTQ in a regular file: the text path -- parse, align and format on the device
-    // (run_se_text).  Everything else (paired end, gzip, pipes, multi-line records) goes through the host pipeline below.
-    // SALT_HOST_PIPELINE=1 forces the latter.
-    if (!pe && !(getenv("SALT_HOST_PIPELINE") && atoi(getenv("SALT_HOST_PIPELINE")))) {
-        struct stat sb; unsigned char magic[2] = { 0, 0 };
-        bool plain = stat(fn_reads, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0;
-        if (plain) { FILE *f = fopen(fn_reads, "rb"); plain = f && fread(magic, 1, 2, f) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b); if (f) fclose(f); }
-        if (plain && sniff_four_line(fn_reads)) {
-            fprintf(stderr, "%lf sec escaped.\n", now() - t0);
-            if (!print_header()) return 1;
-            int wpg = n_threads / n_gpus >= 16 ? 8 : n_threads / n_gpus >= 8 ? 4 : n_threads / n_gpus >= 4 ? 3 : 2;      // text-path workers per GPU: each preads, calls the device, pwrites
-            if (const char *e = getenv("SALT_TEXT_WORKERS")) { int v = atoi(e); if (v >= 1 && v <= 32) wpg = v; }
-            const int rc = run_se_text(fn_reads, ix, gix, n_gpus, wpg, ao, so, now());
-            for (int i = n_gpus - 1; i >= 0; --i) salt_gpu_index_detach(gix[(size_t)i]);
-            salt_index_free(ix);
-            return rc;
-        }
+    if (text_path) {
+        fprintf(stderr, "%lf sec escaped.\n", now() - t0);
+        if (!print_header()) return 1;
+        const int rc = run_se_text(fn_reads, ix, gix, n_gpus, plan, ao, so, now());
+        for (int i = n_gpus - 1; i >= 0; --i) salt_gpu_index_detach(gix[(size_t)i]);
+        salt_index_free(ix);
+        return rc;
     }
     if (pe && po.max_tlen == 0) {
         // N3: -b 0 = infer the insert-size window from the first batch (N_SEQS / 2 pairs), the mates aligned as single-end reads

@@ -42,6 +42,8 @@ int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint64_t max_ba
     (void)max_reads; (void)max_bases;
     struct salt_gpu_ws *ws = calloc(1, sizeof *ws); ws->ix = ix; *out = ws; return SALT_OK;
 }
+int salt_gpu_ws_reserve_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint64_t b, uint32_t r, uint32_t l, uint64_t sb, void *hs, uint64_t hb)
+{ (void)ws; (void)o; (void)b; (void)r; (void)l; (void)sb; (void)hs; (void)hb; return SALT_OK; }
 void salt_gpu_ws_destroy(salt_gpu_ws_t *ws) { if (ws) { free(ws->sam); free(ws); } }
 int salt_gpu_host_alloc(uint64_t bytes, void **ptr) { *ptr = malloc(bytes); return *ptr ? SALT_OK : SALT_E_NOMEM; }
 void salt_gpu_host_free(void *ptr) { free(ptr); }

@@ -1,7 +1,7 @@
 """Host side of `salt --gpus N` without a GPU: the real `salt` binary and libsalt_host.so run against
 tests/stub/salt_gpu_stub.c, a stand-in for libsalt_gpu.so whose "devices" are labels and whose per-batch work is the CPU oracle.
 What is tested is the driver: option handling, chunks of the FASTQ file dealt to the workers of two devices, SAM blocks put out
-in input order (the reference's puts loop, Align_src/alnse.c:1433-1439) -- to a pipe and, by parallel pwrite, to a regular file."""
+in input order (the reference's puts loop, Align_src/alnse.c:1433-1439) -- to a pipe and to a regular file."""
 import os
 import shutil
 import subprocess
@@ -43,7 +43,7 @@ def test_salt_gpus_n_deals_chunks_and_keeps_the_input_order(case, gpus, stub_tre
     f = tmp_path / "out.sam"
     with open(f, "wb") as fo:
         out = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env)
-    assert out.returncode == 0 and b"parallel pwrite" in out.stderr, out.stderr[-300:]
+    assert out.returncode == 0 and b"blocks written in turn" in out.stderr, out.stderr[-300:]
     assert strip(open(f, "rb").read()) == want
 
 

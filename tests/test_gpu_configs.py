@@ -118,7 +118,7 @@ def test_config4_grch38_scale_pairs_equal_the_oracle(grch38):
 
 def test_config3_cli_fastq_to_sam_equals_the_oracle_cli(grch38, tmp_path):
     """The drop-in command on the GRCh38-scale index, end to end: `salt -d -c idx reads.fq > out.sam` (text path: FASTQ parsed and SAM
-    formatted by kernels, parallel pread / pwrite, chunks of 8 MiB so that several workers and chunk boundaries take part) against
+    formatted by kernels, workers that pread / call the device / write in turn, chunks of 8 MiB so that several workers and chunk boundaries take part) against
     the oracle CLI's SAM for the same 300 000 reads, byte for byte (the @PG line carries the command line and is dropped)."""
     import subprocess
     from salt_amd import workload

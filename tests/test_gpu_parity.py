@@ -685,7 +685,7 @@ def lambda_cli_index(tmp_path_factory):
 @pytest.mark.parametrize("case", ["se_default", "se_r1_m500", "se_refonly", "se_r5_s4_m16", "se_plain_t4"])
 def test_cli_text_path_and_host_pipeline_give_the_reference_sam(case, lambda_cli_index, tmp_path):
     """The two SE pipelines of `salt` against the reference's SAM: the text path (FASTQ parsed and SAM formatted by kernels; here with
-    chunks of a few KB so that hundreds of chunk boundaries fall inside records, to a pipe and to a regular file = parallel pwrite) and
+    chunks of a few KB so that hundreds of chunk boundaries fall inside records, to a pipe and to a regular file) and
     the host pipeline (SALT_HOST_PIPELINE=1: the parser that also reads gzip / multi-line records)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     salt = os.path.join(root, "salt_amd", "bin", "salt")
@@ -702,7 +702,7 @@ def test_cli_text_path_and_host_pipeline_give_the_reference_sam(case, lambda_cli
     f = tmp_path / "out.sam"
     with open(f, "wb") as fo:
         out = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, SALT_CHUNK_BYTES="5000"))
-    assert out.returncode == 0 and b"parallel pwrite" in out.stderr, out.stderr[-400:]
+    assert out.returncode == 0 and b"blocks written in turn" in out.stderr, out.stderr[-400:]
     assert strip(open(f, "rb").read()) == want
 
 
@@ -723,3 +723,27 @@ def test_cli_text_path_reads_crlf_and_a_last_record_without_newline(lambda_cli_i
     got = strip(a.stdout).split(b"\n")
     n_hdr = sum(1 for l in want if l.startswith(b"@"))
     assert got[:n_hdr + 200] == want[:n_hdr + 200]
+
+
+def test_cli_text_path_regrows_its_workspace_when_records_get_shorter(lambda_cli_index, tmp_path):
+    """Workspaces of the text path are sized from the file's first records; a file whose head has 500-byte records and whose body has
+    230-byte ones puts more reads into a chunk than that promised: the worker re-creates its workspace and the SAM is unchanged."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt = os.path.join(root, "salt_amd", "bin", "salt")
+    src = open(os.path.join(LAMBDA, "reads_se.fq"), "rb").read().splitlines()
+    recs = [src[i:i + 4] for i in range(0, len(src) - 3, 4)]
+    out = []
+    for rep in range(16):
+        for j, r in enumerate(recs):
+            name = b"@r%d_%d" % (rep, j) + (b"_" + b"x" * 280 if rep == 0 and j < 200 else b"")
+            out += [name, r[1], b"+", r[3]]
+    fq = tmp_path / "mixed.fq"
+    fq.write_bytes(b"\n".join(out) + b"\n")
+    assert fq.stat().st_size > 6 << 20
+    cmd = [salt, "-d", "-c", "-t", "4", lambda_cli_index, str(fq)]
+    strip = lambda o: b"".join(l for l in o.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    a = subprocess.run(cmd, capture_output=True, env=dict(os.environ, SALT_CHUNK_MB="4", SALT_TEXT_TRACE="1"))
+    b = subprocess.run(cmd, capture_output=True, env=dict(os.environ, SALT_HOST_PIPELINE="1"))
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-300:], b.stderr[-300:])
+    assert b"workspace re-created" in a.stderr, a.stderr[-600:]
+    assert strip(a.stdout) == strip(b.stdout)

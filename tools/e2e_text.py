@@ -36,7 +36,7 @@ for s in settings:
     t0 = time.time()
     with open("/dev/null" if to_null else sam, "wb") as fo:
         r = subprocess.run([salt, "-d", "-c", "-t", env.pop("T", "64"), w["prefix"], fq], stdout=fo, stderr=subprocess.PIPE, env=env)
-    tail = [l for l in r.stderr.decode().splitlines() if l.startswith("[salt]") or l.startswith("[alnse_core]: total")]
+    tail = [l for l in r.stderr.decode().splitlines() if l.startswith("[salt") or l.startswith("[alnse_core]: total")]
     print("== %s  (rc %d, process %.1f s)" % (s or "defaults", r.returncode, time.time() - t0))
     for l in tail:
         print("   ", l)
