@@ -112,6 +112,8 @@ enum { SALT_CTR_LKT, SALT_CTR_OCC_C, SALT_CTR_OCC_R, SALT_CTR_SA_C, SALT_CTR_SA_
         * 4-byte suffix-array / R-position loads, 16-byte verify lane-loads, result bytes stored */
        SALT_CTR_D_WLKT, SALT_CTR_D_COCC_SEED, SALT_CTR_D_ROCC_SEED, SALT_CTR_D_SA_SEED, SALT_CTR_D_TEXT_SEED,
        SALT_CTR_D_SA_LIGHT, SALT_CTR_D_VERIFY_LIGHT, SALT_CTR_D_OUT_LIGHT, SALT_CTR_D_SA_HEAVY, SALT_CTR_D_VERIFY_HEAVY, SALT_CTR_D_OUT_HEAVY,
+       /* context table: 16-byte records read in place of 4-byte suffix-array loads, and the located rows it ruled out (windows never read) */
+       SALT_CTR_D_CTX_ROWS, SALT_CTR_D_CTX_REJECTED,
        SALT_CTR_N };
 
 typedef struct salt_gpu_index salt_gpu_index_t;

@@ -24,7 +24,7 @@ CTR_NAMES = ["lkt", "occ_c", "occ_r", "sa_c", "sa_r", "verify", "verify_words", 
              "t_load", "t_gather", "t_locate", "t_sort", "t_dedup", "t_verify", "t_scan", "t_gap", "t_tail", "heavy_reads", "x0", "x1", "x2", "x3",
              "lt_seeds", "lt_locate", "lt_sort", "lt_verify", "lt_out", "lt_samples", "max_heavy", "max_gapfin",
              "d_wlkt", "d_cocc_seed", "d_rocc_seed", "d_sa_seed", "d_text_seed", "d_sa_light", "d_verify_light", "d_out_light",
-             "d_sa_heavy", "d_verify_heavy", "d_out_heavy"]
+             "d_sa_heavy", "d_verify_heavy", "d_out_heavy", "d_ctx_rows", "d_ctx_rejected"]
 
 
 class SaltError(RuntimeError):

@@ -581,13 +581,30 @@ __device__ __forceinline__ uint32_t dedup_loci(uint32_t *loci, uint32_t n, bool 
 // ---- candidates of one strand: gather seeds, order them, locate, sort, dedup ----------------------
 // Leaves the candidate positions in w.loci[0..return).  gap_mode selects the range filter of
 // alnse_check_withgap (alnse.c:894) instead of alnse_check_nogap's (alnse.c:762).
-struct CandStats { uint32_t n_cand, n_sa_c, n_sa_r, n_loci; uint32_t in_lds; };     // in_lds: the loci went to w.loci (PE lists that fit)
+struct CandStats { uint32_t n_cand, n_sa_c, n_sa_r, n_loci; uint32_t in_lds; uint32_t n_ctx_rej; };     // in_lds: the loci went to w.loci (PE lists that fit)
 struct CandArgs {                      // everything by value: a by-reference IndexView would live in scratch memory
     const uint32_t *c_sa, *r_pos; const uint4 *sai_c, *sai_r;
     uint32_t ref_len, spr, max_locate, r, L; int strand; bool gap_mode; unsigned long long *phase;
     uint32_t *loci; uint32_t loci_cap; int pe;
     bool finish;                   // false: stop after locate (unsorted, duplicates and out-of-range loci still in)
+    const uint4 *c_ctx; uint32_t ctx_k;    // non-null: rows come from the context table and a row whose window has more than 3 mismatches for
+                                           // certain (ctx_reject, salt_device.h) is counted against the caps but not stored.  Gap-free pass only.
 };
+
+// The read's side of a context comparison for a seed that starts at read offset `off` (pm: the strand's one-hot words in LDS).
+// Lane t < CTX_N faces genome base s + ctx_k + t, i.e. read base off + ctx_k + t; lane CTX_N + u faces s - 1 - u, read base off - 1 - u.
+__device__ __forceinline__ CtxRead ctx_read(const uint32_t *pm, uint32_t L, uint32_t off, uint32_t ctx_k)
+{
+    const uint32_t t = lane_id();
+    const int p = t < CTX_N ? (int)(off + ctx_k + t) : (int)off - 1 - (int)(t - CTX_N);
+    const bool v = t < 2u * CTX_N && p >= 0 && p < (int)L;
+    const uint32_t nib = v ? (pm[(uint32_t)p >> 3] >> (4u * ((uint32_t)p & 7u))) & 15u : 0u;
+    CtxRead rd;
+    rd.lo = __ballot(v && (nib & 0xAu) != 0);                // one-hot 1 << code: code bit 0 set for 2 and 8, bit 1 for 4 and 8
+    rd.hi = __ballot(v && (nib & 0xCu) != 0);
+    rd.use = __ballot(v && (nib == 1u || nib == 2u || nib == 4u || nib == 8u));     // N (15) matches everything: not counted
+    return rd;
+}
 // Not inlined (three call sites, ~1 400 instructions).  Its arguments are the same for all 64 lanes: passed by value they would be
 // written to and read back from scratch memory once per lane and call (~6 KB per call, measured as 430 MB of writes per launch), so the
 // caller leaves ONE copy in the wave's LDS.
@@ -648,22 +665,35 @@ __device__ __attribute__((noinline)) CandStats build_candidates(WaveLds &w)
     pc.stamp(SALT_CTR_T_GATHER);
     // locate: SE under the global max_locate cap (alnse_locate_alt, alnse.c:633-731); PE with the per-interval cap
     // and the 0x40000 global cap of alnse_locate (alnse.c:501-629; here bounded by the scratch capacity)
-    uint32_t n = 0;
+    uint32_t n = 0, ns = 0;                                   // rows that count against the cap; rows stored (ns < n only with the context table)
     bool full = false;
+    const gp_u32x4 c_ctx = as_global(a.c_ctx);
+    const bool use_ctx = !PE && a.c_ctx != nullptr && !gap_mode;
     for (uint32_t i = 0; i < n_list[0] && !full; ++i) {
         const uint32_t sp = w.u.sai.sp[0][i], off = w.u.sai.off[0][i] & 0x7FFFFFFFu;
         const bool located = (w.u.sai.off[0][i] >> 31) != 0;                  // k_seed resolved this one-row interval to its position
         uint32_t ep = w.u.sai.ep[0][i];
         if (PE && ep - sp > ap.max_locate) ep = sp + ap.max_locate;             // j - sp <= max_locate (alnse.c:523)
+        const bool ctx_here = use_ctx && !located;
+        CtxRead rd = { 0, 0, 0 };
+        if (ctx_here) rd = ctx_read(w.pm[strand], L, off, a.ctx_k);
         for (uint64_t j0 = sp; j0 <= ep && !full; j0 += 64) {
             pc.add(SALT_CTR_X0, 1);
             uint64_t j = j0 + lane;
-            bool in = j <= ep, keep = false;
+            bool in = j <= ep, keep = false, rej = false;
             uint32_t pos = 0;
-            if (in) { pos = (located ? (uint32_t)j : ix.c_sa[j]) - off; keep = !(pos + L > ix.ref_len); }        // u32 wrap as in alnse.c:672-673
+            if (in) {
+                uint32_t sa;
+                if (ctx_here) { const u32x4_t rc = c_ctx[j]; sa = rc.x; rej = ctx_reject(make_uint4(rc.x, rc.y, rc.z, rc.w), rd, 3u); }
+                else sa = located ? (uint32_t)j : ix.c_sa[j];
+                pos = sa - off; keep = !(pos + L > ix.ref_len);                 // u32 wrap as in alnse.c:672-673
+            }
             uint64_t m = __ballot(keep);
             uint32_t rank = (uint32_t)__popcll(m & lt);
-            if (keep && n + rank < cap_total) loci[n + rank] = pos;
+            const bool st = keep && !rej && n + rank < cap_total;              // inside the cap and not ruled out by its context
+            const uint64_t ms = __ballot(st);
+            if (st) loci[ns + (uint32_t)__popcll(ms & lt)] = pos;
+            ns += (uint32_t)__popcll(ms);
             uint32_t tot = (uint32_t)__popcll(m);
             if (n + tot >= cap_total) {
                 // lookups the sequential loop would have made before stopping
@@ -692,26 +722,28 @@ __device__ __attribute__((noinline)) CandStats build_candidates(WaveLds &w)
             if (in) { pos = ix.r_pos[j] - off; keep = !(pos > ix.ref_len || pos + L > ix.ref_len); }   // alnse.c:715-717
             uint64_t m = __ballot(keep);
             uint32_t rank = (uint32_t)__popcll(m & lt);
-            if (keep && n + rank < cap_total) loci[n + rank] = pos;
+            if (keep && n + rank < cap_total) loci[ns + rank] = pos;
             uint32_t tot = (uint32_t)__popcll(m);
             if (n + tot >= cap_total) {
                 uint64_t last = m; uint32_t need = cap_total - n;
                 for (uint32_t q = 1; q < need; ++q) last &= last - 1;
                 n_sa_r += (uint32_t)__ffsll((long long)last);
-                n = cap_total; full = true;
-            } else { n += tot; n_sa_r += (uint32_t)__popcll(__ballot(in)); }
+                ns += need; n = cap_total; full = true;
+            } else { n += tot; ns += tot; n_sa_r += (uint32_t)__popcll(__ballot(in)); }
         }
     }
+    const uint32_t n_ctx_rej = n - ns;
     n_loci_out += n;
+    n = ns;                                                   // what the passes below see
     WSYNC();
     pc.stamp(SALT_CTR_T_LOCATE);
-    if (!a.finish) return CandStats{ n, n_sa_c, n_sa_r, n_loci_out, pe_in_lds ? 1u : 0u };
+    if (!a.finish) return CandStats{ n, n_sa_c, n_sa_r, n_loci_out, pe_in_lds ? 1u : 0u, n_ctx_rej };
     sort_loci(loci, n);
     WSYNC();
     pc.stamp(SALT_CTR_T_SORT);
     const uint32_t n_out = dedup_loci(loci, n, gap_mode, L, ix.ref_len);
     pc.stamp(SALT_CTR_T_DEDUP);
-    return CandStats{ n_out, n_sa_c, n_sa_r, n_loci_out, pe_in_lds ? 1u : 0u };
+    return CandStats{ n_out, n_sa_c, n_sa_r, n_loci_out, pe_in_lds ? 1u : 0u, n_ctx_rej };
 }
 
 template <bool PE>
@@ -1228,7 +1260,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     const uint32_t *rec = pm + (uint64_t)r * ap.pg.pm_stride;               // k_pack's record of this read
     const uint32_t L = rec[2 * ap.pg.nw8];
     salt_result_t *out = results + r;
-    uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_lv = 0, c_loci = 0;
+    uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_lv = 0, c_loci = 0, c_ctx_rej = 0;
     PhaseClock pc(phase);
     const uint64_t rt0 = phase ? __builtin_amdgcn_s_memrealtime() : 0;
     uint32_t *loci = PE ? pe_loci : w.loci;                   // candidate loci: LDS; for PE mates the global scratch when a list outgrows it
@@ -1271,10 +1303,10 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         // Located rows first, unsorted: only loci that can pass (<= 3 mismatches, inside the reference) matter to the
         // sequential rule, so the sort (alnse.c:726-729), the duplicate filter (alnse.c:758-762) and the rule run on
         // those few; the result is the one the full sorted list gives.
-        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, false }, w);
+        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, false, ix.c_ctx, ix.ctx_k }, w);
         if (PE) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
         pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
-        const uint32_t n_loc = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
+        const uint32_t n_loc = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci; c_ctx_rej += cs.n_ctx_rej;
         uint32_t call_best_n = INF, call_best_pos = 0;
         auto verify_all = [&](uint32_t n) {                   // cand_e[i] = min(mismatches, INF) of loci[i], loads of 128 candidates in flight
             if (L <= 120) verify_quads<8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
@@ -1293,7 +1325,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             }
         }
         const uint32_t n_cand = n_loc;
-        c_verify += n_loc; n_cand_nogap += n_loc; n_loc_s[strand] = n_loc;
+        c_verify += n_loc; n_cand_nogap += n_loc + cs.n_ctx_rej; n_loc_s[strand] = n_loc;
         for (uint32_t b = lane; b < n_cand; b += 64) c_vwords += ((loci[b] & 7u) + L + 7) >> 3;
         if (found[strand]) { q_pos = call_best_pos; q_ndiff = call_best_n; q_gap = 0; q_strand = (uint32_t)strand; }
         WSYNC();
@@ -1307,7 +1339,8 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         const bool lanes_fit = gap_k0 <= LLV_K && L + 4 <= 8u * (LLV_TW - 1);
         if (lanes_fit && g.cap && n_cand_nogap > 0) {
             // k_gap / k_gapfin / k_cigar take it from here: both strands' located rows go to the pool as they are (unsorted,
-            // duplicates included -- rule_unsorted needs neither).  Strand 1's rows are still in `loci`; strand 0's are located again.
+            // duplicates included -- rule_unsorted needs neither).  Strand 1's rows are still in `loci` (unless the context table
+            // thinned them: the gapped pass needs every row); strand 0's are located again.
             uint32_t slot = 0;
             if (lane == 0) slot = atomicAdd(&g.gctl[2], 1u);
             slot = (uint32_t)__shfl((int)slot, 0);
@@ -1317,9 +1350,9 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                 for (int k = 0; k < 2 && ok; ++k) {
                     const int strand = 1 - k;
                     uint32_t n = n_loc_s[1];
-                    if (strand == 0) {
+                    if (strand == 0 || (!PE && ix.c_ctx != nullptr)) {
                         WSYNC();
-                        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, 0, true, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, false }, w);
+                        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, false, nullptr, 0 }, w);
                         if (PE) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
                         c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
                         n = cs.n_cand;
@@ -1354,6 +1387,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                             atomicAdd(ctr + SALT_CTR_D_SA_HEAVY, c_sa_c + c_sa_r);
                             atomicAdd(ctr + SALT_CTR_D_VERIFY_HEAVY, c_verify * (L <= 120 ? 4u : L <= 248 ? 8u : (((L + 7) >> 3) + 4u) / 4u));
                             atomicAdd(ctr + SALT_CTR_D_OUT_HEAVY, 5u * (ns[0] + ns[1]) + 16u);      // the located rows + distances handed to k_gap
+                            if (ix.c_ctx) { atomicAdd(ctr + SALT_CTR_D_CTX_ROWS, c_verify + c_ctx_rej); atomicAdd(ctr + SALT_CTR_D_CTX_REJECTED, c_ctx_rej); }
                         }
                     }
                     return;
@@ -1363,7 +1397,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         }
         for (int strand = 0; strand < 2; ++strand) {
             pc.stamp(SALT_CTR_T_GAP);
-            const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, true }, w);
+            const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, true, nullptr, 0 }, w);
             if (PE) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
             pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
             const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
@@ -1486,6 +1520,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             atomicAdd(ctr + SALT_CTR_D_SA_HEAVY, c_sa_c + c_sa_r);
             atomicAdd(ctr + SALT_CTR_D_VERIFY_HEAVY, c_verify * (L <= 120 ? 4u : L <= 248 ? 8u : (((L + 7) >> 3) + 4u) / 4u));
             atomicAdd(ctr + SALT_CTR_D_OUT_HEAVY, 128u);
+            if (ix.c_ctx) { atomicAdd(ctr + SALT_CTR_D_CTX_ROWS, c_verify + c_ctx_rej); atomicAdd(ctr + SALT_CTR_D_CTX_REJECTED, c_ctx_rej); }
         }
     }
 }

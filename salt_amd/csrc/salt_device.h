@@ -21,6 +21,13 @@
 //          (lookup.h:39-53, with that table's A-padded tail quirk) followed by W-12 steps of
 //          bwt_match_exact_alt (bwt.c:281-309); R: the first W iterations of Rbwt_exact_match_backward
 //          from (0, textLength) (rbwt.c:619-648).  Tabulated once at attach time; (1,0) = dead.
+//   c_ctx  (optional, 16 B per C suffix-array row) .x = the row's suffix-array value again, .y/.z/.w = the 2-bit genome around that
+//          suffix: CTX_N bases behind the first ctx_k (= seed length) bases of the suffix and CTX_N bases in front of it, as two bit
+//          planes, plus per side the number of positions whose allele mask is not exactly the genome base (SNP sites, N runs).
+//          A locate that reads its rows from here can bound the mismatches of the candidate window from below WITHOUT touching
+//          the window: rows come 4 to a 64-byte line and in order, windows are one random DRAM row each.  A candidate whose
+//          bound exceeds 3 would fail alnse_check_nogap's ed_mismatch (alnse.c:734-782) and is dropped before it; nothing else
+//          changes (see ctx_reject below).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -42,18 +49,47 @@ struct ImageHeader {
     uint32_t ref_len, r_lkt_len;
     uint64_t off_c_occ, off_c_sa, off_lkt, off_r_occ, off_r_pos, off_wlkt, off_ref, off_text;
     uint64_t n_c_blocks, n_r_blocks;
-    uint64_t reserved[7];
+    uint64_t off_ctx;                                               // 0: no context table; else behind the W-mer table (not part of the compact image)
+    uint32_t ctx_k, pad0;
+    uint64_t reserved[5];
 };
-static const uint64_t IMAGE_MAGIC = 0x53414c5447465839ull;          // "SALTGFX9"
+static const uint64_t IMAGE_MAGIC = 0x53414c5447465841ull;          // "SALTGFXA"
 
 // What kernels receive (by value): resolved pointers + scalars.
 struct IndexView {
     const COcc *c_occ; const uint32_t *c_sa; const uint32_t *lkt;
     const ROcc *r_occ; const uint32_t *r_pos; const uint4 *wlkt; const uint32_t *ref; const uint32_t *text;
+    const uint4 *c_ctx; uint32_t ctx_k;                            // nullptr: absent
     uint32_t c_primary, c_L2[5], c_seq_len;
     uint32_t r_text_len, r_inv_sa0, r_cum[6];
     uint32_t ref_len, lkt_len, r_lkt_len;
 };
+
+// ---- c_ctx records -------------------------------------------------------------------------------------------------
+// Bit t of a plane, t < CTX_N: genome base s + ctx_k + t (side A, behind the seed); bit CTX_N + u: genome base s - 1 - u (side B, in
+// front of the suffix).  96 bits behind .x: low plane (46), high plane (46), special-site count of A (2), of B (2); a count of 3
+// means "3 or more, or the side runs off the genome": that side bounds nothing.
+static const uint32_t CTX_N = 23;
+static const uint64_t CTX_MASK_A = (1ull << CTX_N) - 1ull, CTX_MASK_B = CTX_MASK_A << CTX_N;
+__device__ __forceinline__ uint4 ctx_pack(uint32_t sa, uint64_t lo, uint64_t hi, uint32_t ns_a, uint32_t ns_b)
+{
+    return make_uint4(sa, (uint32_t)lo, (uint32_t)(lo >> 32) | ((uint32_t)hi << 14), (uint32_t)(hi >> 18) | (ns_a << 28) | (ns_b << 30));
+}
+// The read's side of the comparison, the same for every row of one seed interval: planes of the read bases facing the record's
+// positions, and `use` = the positions that face a base of the read which is not N.
+struct CtxRead { uint64_t lo, hi, use; };
+// true: the window of this row has more than `bound` mismatches for certain (so ed_mismatch(..., bound) would return -1).
+// Mismatches between the 2-bit genome and the read are counted over the usable positions; every special site among them may be a
+// match after all (the mask holds more than the genome base), so each side's count is lowered by its special-site count.
+__device__ __forceinline__ bool ctx_reject(const uint4 rec, const CtxRead rd, uint32_t bound)
+{
+    const uint64_t lo = (uint64_t)rec.y | ((uint64_t)(rec.z & 0x3FFFu) << 32), hi = (uint64_t)(rec.z >> 14) | ((uint64_t)(rec.w & 0x0FFFFFFFu) << 18);
+    const uint64_t m = ((lo ^ rd.lo) | (hi ^ rd.hi)) & rd.use;
+    const uint32_t ns_a = (rec.w >> 28) & 3u, ns_b = rec.w >> 30;
+    const uint32_t ca = (uint32_t)__popcll(m & CTX_MASK_A), cb = (uint32_t)__popcll(m & CTX_MASK_B);
+    const uint32_t la = (ns_a == 3u || ca < ns_a) ? 0u : ca - ns_a, lb = (ns_b == 3u || cb < ns_b) ? 0u : cb - ns_b;
+    return la + lb > bound;
+}
 
 __device__ __forceinline__ uint32_t sel4(uint4 v, uint32_t c)
 {

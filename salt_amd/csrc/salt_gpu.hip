@@ -79,6 +79,7 @@ static void make_view(salt_gpu_index *ix)
     v.wlkt = reinterpret_cast<const uint4 *>(b + h.off_wlkt);
     v.ref = reinterpret_cast<const uint32_t *>(b + h.off_ref);
     v.text = reinterpret_cast<const uint32_t *>(b + h.off_text);
+    v.c_ctx = h.off_ctx ? reinterpret_cast<const uint4 *>(b + h.off_ctx) : nullptr; v.ctx_k = h.ctx_k;
     v.c_primary = h.c_primary; memcpy(v.c_L2, h.c_L2, sizeof v.c_L2); v.c_seq_len = h.c_seq_len;
     v.r_text_len = h.r_text_len; v.r_inv_sa0 = h.r_inv_sa0; memcpy(v.r_cum, h.r_cum, sizeof v.r_cum);
     v.ref_len = h.ref_len; v.lkt_len = h.lkt_len; v.r_lkt_len = h.r_lkt_len;
@@ -109,12 +110,20 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     hd.lkt_len = h->lkt_len; hd.lkt_n = h->lkt_n;
     hd.r_text_len = h->r_text_len; hd.r_inv_sa0 = h->r_inv_sa0; memcpy(hd.r_cum, h->r_cum, sizeof hd.r_cum);
     hd.ref_len = h->ref_len;
+    // The context table (c_ctx, salt_device.h): 16 B per suffix-array row (46 GiB at GRCh38 scale), taken whenever the seed length is
+    // known; SALT_GPU_NO_CTX=1 leaves it out (A/B runs, small devices).
+    const uint64_t ctx_bytes = (((uint64_t)h->c_seq_len + 1) * 16 + 255) / 256 * 256;
+    bool want_ctx = h->l_seed > 0 && !(getenv("SALT_GPU_NO_CTX") && atoi(getenv("SALT_GPU_NO_CTX")));
     {   // width of the device k-mer table: 32 B x 4^W (14: 8 GiB, 15: 32 GiB, 16: 128 GiB).  Every extra base saves each seed
         // one C and one R backward-search step (k_seed: -9 % per base) and makes more C intervals one row wide, which the entry then
         // resolves by itself, so the widest table that leaves room for the rest is taken: W = 16 on a 288 GB MI355X.
         uint32_t w = 14;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) w = free_b >= (200ull << 30) ? 16 : free_b >= (72ull << 30) ? 15 : 14;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            if (want_ctx && (uint64_t)free_b < ctx_bytes + (24ull << 30)) want_ctx = false;          // a device this small keeps the table narrow and the windows random
+            const uint64_t avail = (uint64_t)free_b - (want_ctx ? ctx_bytes : 0);
+            w = avail >= (200ull << 30) ? 16 : avail >= (72ull << 30) ? 15 : 14;
+        }
         if (const char *e = getenv("SALT_GPU_LKT_LEN")) w = (uint32_t)atoi(e);
         if (h->l_seed > 0 && w > (uint32_t)h->l_seed) w = (uint32_t)h->l_seed;
         if (h->l_seed <= 0) w = h->lkt_len;
@@ -135,6 +144,7 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     hd.off_text = off;  off = align_up(off + ((uint64_t)h->c_seq_len / 16 + 4) * 4, 256);
     // last: everything before it is the COMPACT image, from which the W-mer table can be rebuilt on any device
     hd.off_wlkt = off; off = align_up(off + (1ull << (2 * hd.r_lkt_len)) * 32, 256);
+    if (want_ctx) { hd.off_ctx = off; hd.ctx_k = (uint32_t)h->l_seed; off += ctx_bytes; }
     hd.bytes = off;
     ix->bytes = off;
 
@@ -185,6 +195,7 @@ extern "C" int salt_gpu_index_attach(const salt_host_index_t *h, int device, sal
     launch_build_r_pos(ix->view, d_r_sa, reinterpret_cast<uint32_t *>(ix->image + hd.off_r_pos), nullptr);
     launch_build_text(ix->view, reinterpret_cast<uint32_t *>(ix->image + hd.off_text), nullptr);       // after c_sa (same stream)
     launch_build_wlkt(ix->view, hd.r_lkt_len, reinterpret_cast<uint4 *>(ix->image + hd.off_wlkt), nullptr);
+    if (hd.off_ctx) launch_build_c_ctx(ix->view, hd.ctx_k, reinterpret_cast<uint4 *>(ix->image + hd.off_ctx), nullptr);      // after c_sa and text
     CHK2(hipGetLastError());
     CHK2(hipDeviceSynchronize());
     hipFree(d_sa_s); hipFree(d_r_sa);
@@ -230,10 +241,11 @@ extern "C" int salt_gpu_index_image_compact(const salt_gpu_index_t *ix, void **d
     return SALT_OK;
 }
 
-// the W-mer table of an image whose compact part is in place (device of ix current)
+// the W-mer table and the context table of an image whose compact part is in place (device of ix current)
 static int rebuild_wlkt(salt_gpu_index *ix)
 {
     launch_build_wlkt(ix->view, ix->hdr.r_lkt_len, reinterpret_cast<uint4 *>(ix->image + ix->hdr.off_wlkt), nullptr);
+    if (ix->hdr.off_ctx) launch_build_c_ctx(ix->view, ix->hdr.ctx_k, reinterpret_cast<uint4 *>(ix->image + ix->hdr.off_ctx), nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     return SALT_OK;

@@ -130,6 +130,7 @@ static const uint32_t FQ_TILE = 1024;                                          /
 void launch_pack_c_occ(const uint32_t *bwt, uint64_t bwt_words, uint32_t seq_len, uint64_t n_blocks, COcc *out, uint32_t *err, hipStream_t st);
 void launch_pack_r_occ(const uint32_t *code, uint64_t code_words, const uint32_t *minor, uint64_t minor_words, const uint32_t *major, uint64_t major_words,
                        uint32_t text_len, uint64_t n_blocks, ROcc *out, uint32_t *err, hipStream_t st);
+void launch_build_c_ctx(const IndexView &ix, uint32_t ctx_k, uint4 *out, hipStream_t st);
 void launch_build_c_sa(const IndexView &ix, const uint32_t *sa_sampled, uint32_t sa_intv, uint32_t *out, hipStream_t st);
 void launch_build_r_pos(const IndexView &ix, const uint32_t *r_sa, uint32_t *out, hipStream_t st);
 void launch_build_text(const IndexView &ix, uint32_t *out, hipStream_t st);
