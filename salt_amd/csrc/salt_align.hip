@@ -2570,7 +2570,7 @@ uint32_t heavy_blocks_per_cu()
 
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, unsigned long long *ctr,
-                  uint32_t n_blocks, void *lvtab, const GapBufs &g, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st)
+                  uint32_t n_blocks, uint32_t gap_blocks, void *lvtab, const GapBufs &g, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st)
 {
     if (!ap.n_reads) { if (ev3) for (int i = 0; i < 3; ++i) hipEventRecord(ev3[i], st); return; }
     uint32_t blocks = n_blocks < ap.n_reads ? n_blocks : ap.n_reads;
@@ -2581,7 +2581,7 @@ void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm
     if (!g.cap) { if (ev3) { hipEventRecord(ev3[1], st); hipEventRecord(ev3[2], st); } return; }
     // the deferred gapped passes: distances by (read, strand, 32 candidates), one finishing wave per read, one traceback per wave
     // grids: k_gap has many ~70 us items and wants every wave; the other two have few, short items and start faster on fewer blocks
-    hipLaunchKernelGGL(k_gap, dim3(n_blocks), dim3(64), 0, st, ix, ap, pm, g);
+    hipLaunchKernelGGL(k_gap, dim3(gap_blocks), dim3(64), 0, st, ix, ap, pm, g);
     if (ev3) hipEventRecord(ev3[1], st);
     hipLaunchKernelGGL(k_gapfin, dim3((n_blocks + 3) / 4), dim3(64), 0, st, ix, ap, pm, results, g, ctr);
     if (ev3) hipEventRecord(ev3[2], st);

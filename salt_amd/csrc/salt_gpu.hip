@@ -55,7 +55,7 @@ struct salt_gpu_ws {
     char *d_sam = nullptr, *h_sam = nullptr; uint64_t sam_cap = 0; char *d_rg = nullptr; std::string rg;
     bool h_sam_owned = true;                                                 // false: the caller's page-locked buffer (salt_gpu_ws_reserve_text)
     uint32_t text_calls = 0;                                                 // SALT_TEXT_TRACE: stage clocks of the first text call
-    uint32_t heavy_blocks = 2048;
+    uint32_t heavy_blocks = 2048, gap_blocks = 2048;
     int all_heavy = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
@@ -300,9 +300,14 @@ extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint
         // Half of that by default: the persistent kernels are latency bound, so alone they lose 3 % with 6 waves per CU instead of
         // 12, while the kernels of the other batches in flight (other workspaces / streams) find room: +8 % on the 4-stream step
         // (measured: 3 -> 670, 4 -> 693, 6 -> 705, 8 -> 686, 12 -> 654 Mreads/s)
-        if (per_cu > 8) per_cu = 8;
+        if (per_cu > 6) per_cu = 6;
         if (const char *e2 = getenv("SALT_GPU_HEAVY_PER_CU")) { int v = atoi(e2); if (v > 0 && (uint32_t)v <= heavy_blocks_per_cu()) per_cu = (uint32_t)v; }
         ws->heavy_blocks = (uint32_t)prop.multiProcessorCount * per_cu;    // persistent one-wave blocks
+        // k_gap's items (64 candidates' Landau-Vishkin distances, ~70 us each) are independent and need no table of their own: its grid is
+        // what its 9.3 KB of LDS admit per CU (16), not k_heavy's (13 079 items per 10^6 GRCh38-scale reads: 0.54 ms on 2 048 waves, 0.31 on 4 096)
+        uint32_t gap_per_cu = 16;
+        if (const char *e2 = getenv("SALT_GPU_GAP_PER_CU")) { int v = atoi(e2); if (v > 0 && v <= 16) gap_per_cu = (uint32_t)v; }
+        ws->gap_blocks = (uint32_t)prop.multiProcessorCount * gap_per_cu;
         CHKW(hipMalloc(&ws->d_lvtab, (uint64_t)ws->heavy_blocks * lv_table_bytes()));
         const char *e = getenv("SALT_GPU_ALL_HEAVY");
         ws->all_heavy = e && atoi(e) != 0;
@@ -400,7 +405,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
                      static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, st);
     if (timed) HIPCHK(hipEventRecord(ev[3], st));
     launch_heavy(ws->ix->view, ap, ws->d_pm, ws->d_sai_c, ws->d_sai_r,
-                 static_cast<salt_result_t *>(d_results), ws->d_queue, ctr, ws->heavy_blocks, ws->d_lvtab,
+                 static_cast<salt_result_t *>(d_results), ws->d_queue, ctr, ws->heavy_blocks, ws->gap_blocks, ws->d_lvtab,
                  gap_bufs_layout(ws->d_gap, ws->gcap, ws->d_qctl, nullptr), pe ? ws->d_pe_scr : nullptr, timed ? ev + 4 : nullptr, st);
     if (timed) { HIPCHK(hipEventRecord(ev[7], st)); ++ws->n_timed; }
     HIPCHK(hipGetLastError());

@@ -66,7 +66,7 @@ struct GapBufs {
 GapBufs gap_bufs_layout(uint8_t *base, uint32_t cap, uint32_t *gctl, size_t *bytes);   // base = nullptr: size only
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, unsigned long long *ctr,
-                  uint32_t n_blocks, void *lvtab, const GapBufs &g, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st);
+                  uint32_t n_blocks, uint32_t gap_blocks, void *lvtab, const GapBufs &g, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st);
 size_t lv_table_bytes();                // per-block LV traceback table (global memory)
 
 // ---- paired end (salt_pe.hip) ----
