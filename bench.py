@@ -43,8 +43,8 @@ def log(*a):
 def device_bytes(ctr, n_reads, L, spr):
     """Device-layout algorithmic bytes of ONE launch per kernel, from the kernels' own access counters (salt_gpu_ws_counters,
     DESIGN 5): what the device structures must move -- one 64-byte sector per W-mer gather, the 32-byte C / 64-byte R Occ blocks
-    actually fetched, 4 bytes per suffix-array / R-position load, 8 per text word pair, 16 per verify lane-load (64 per
-    candidate window), the packed read records, seed intervals and result rows each kernel reads and writes."""
+    actually fetched, 4 bytes per suffix-array / R-position load (16 when the row comes from the context table), 8 per text word pair,
+    16 per verify lane-load (64 per candidate window), the packed read records, seed intervals and result rows each kernel reads and writes."""
     items = n_reads * 2 * spr
     nw8, nw16, nw32 = (L + 7) // 8, (L + 15) // 16, (L + 31) // 32
     pm = ((2 * nw8 + 1 + 3) & ~3) * 4
@@ -54,7 +54,7 @@ def device_bytes(ctr, n_reads, L, spr):
     b["k_seed"] = (n_reads * tb + ctr["d_wlkt"] * SECTOR + ctr["d_cocc_seed"] * 32 + ctr["d_rocc_seed"] * 64 + ctr["d_sa_seed"] * 4
                    + ctr["d_text_seed"] * 8 + items * 32)
     b["k_light"] = (n_reads * pm + items * 32 + ctr["d_sa_light"] * 4 + ctr["d_verify_light"] * 16 + ctr["d_out_light"])
-    b["k_heavy"] = (ctr["heavy_reads"] * (pm + 2 * spr * 32) + ctr["d_sa_heavy"] * 4 + ctr["d_verify_heavy"] * 16 + ctr["d_out_heavy"])
+    b["k_heavy"] = (ctr["heavy_reads"] * (pm + 2 * spr * 32) + ctr["d_sa_heavy"] * 4 + ctr.get("d_ctx_rows", 0) * 12 + ctr["d_verify_heavy"] * 16 + ctr["d_out_heavy"])
     return b
 
 
@@ -284,7 +284,7 @@ def main():
                                     "4/16/32/64-byte record, i.e. exact for these gather shapes (no x2 streaming correction applies)")
         rq = pk.get(dom, {}).get("TCC_EA0_RDREQ_sum")
         if rq:
-            # what actually limits these kernels: the RATE of random 64-byte requests, not their bytes (a second adjacent sector per window is free)
+            # how far the kernel is from the memory system's limit for its access shape: random 64-byte requests per second (a second adjacent sector per window is free)
             roof["random_requests"] = {"per_launch": int(rq), "G_per_s": round(rq / (serial_kms[dom] / 1e3) / 1e9, 1), "ceiling_G_per_s": RANDOM_REQ_GPS,
                                        "frac_of_ceiling": round(rq / (serial_kms[dom] / 1e3) / 1e9 / RANDOM_REQ_GPS, 3),
                                        "whole_step_G_per_s_wall": round(sum(v.get("TCC_EA0_RDREQ_sum", 0) for v in pk.values()) / (dt / args.steps) / 1e9, 1),
@@ -295,8 +295,12 @@ def main():
         ir = prof.get("issue", {}).get(dom)
         if ir:
             roof["issue_bound"] = ir
-        roof["limiter"] = ("random 64-byte memory requests: the step issues ~95 M of them per 10^6 reads (W-mer gathers, Occ blocks, suffix-array rows, candidate windows) "
-                           "and the chip serves 38-48 G/s at this footprint; bytes (frac of the 8 TB/s peak) and vector issue slots (issue_bound.valu_issue_frac) are far from their limits")
+        roof["limiter"] = ("memory latency x resident waves, not a bandwidth: k_seed and k_light2 fill every wave slot (8 per SIMD) with dependent chains of random loads "
+                           "(a W-mer gather, then up to k - W Occ steps per seed; 3 round trips per read pair), k_heavy's reads make ~20 dependent round trips each on 6 one-wave "
+                           "blocks per CU.  With 4 or more streams the step is pinned at the sum of the slot-filling kernels plus the part of k_heavy that does not hide behind them "
+                           "(2 streams: the serialized sum; 4, 6, 8: the same plateau).  random_requests.frac_of_ceiling and frac (bytes) say how far the memory system is from ITS "
+                           "limits: about half of the random-request rate and a fifth of the streaming peak.  Halving k_heavy's requests (the context table, DESIGN 3) "
+                           "took 14 % off its time: that is what a latency bound looks like")
         roof["counters"] = {k: int(v) for k, v in ctr.items() if k.startswith("d_")}
         out["roofline"] = roof
 

@@ -581,7 +581,7 @@ __device__ __forceinline__ uint32_t dedup_loci(uint32_t *loci, uint32_t n, bool 
 // ---- candidates of one strand: gather seeds, order them, locate, sort, dedup ----------------------
 // Leaves the candidate positions in w.loci[0..return).  gap_mode selects the range filter of
 // alnse_check_withgap (alnse.c:894) instead of alnse_check_nogap's (alnse.c:762).
-struct CandStats { uint32_t n_cand, n_sa_c, n_sa_r, n_loci; uint32_t in_lds; uint32_t n_ctx_rej; };     // in_lds: the loci went to w.loci (PE lists that fit)
+struct CandStats { uint32_t n_cand, n_sa_c, n_sa_r, n_loci; uint32_t in_lds; uint32_t n_ctx_rej, n_ctx_rows; };     // in_lds: the loci went to w.loci (PE lists that fit)
 struct CandArgs {                      // everything by value: a by-reference IndexView would live in scratch memory
     const uint32_t *c_sa, *r_pos; const uint4 *sai_c, *sai_r;
     uint32_t ref_len, spr, max_locate, r, L; int strand; bool gap_mode; unsigned long long *phase;
@@ -665,7 +665,7 @@ __device__ __attribute__((noinline)) CandStats build_candidates(WaveLds &w)
     pc.stamp(SALT_CTR_T_GATHER);
     // locate: SE under the global max_locate cap (alnse_locate_alt, alnse.c:633-731); PE with the per-interval cap
     // and the 0x40000 global cap of alnse_locate (alnse.c:501-629; here bounded by the scratch capacity)
-    uint32_t n = 0, ns = 0;                                   // rows that count against the cap; rows stored (ns < n only with the context table)
+    uint32_t n = 0, ns = 0, n_ctx_rows = 0;                   // rows that count against the cap; rows stored (ns < n only with the context table)
     bool full = false;
     const gp_u32x4 c_ctx = as_global(a.c_ctx);
     const bool use_ctx = !PE && a.c_ctx != nullptr && !gap_mode;
@@ -701,9 +701,9 @@ __device__ __attribute__((noinline)) CandStats build_candidates(WaveLds &w)
                 uint32_t need = cap_total - n;           // >= 1
                 for (uint32_t q = 1; q < need; ++q) last &= last - 1;
                 uint32_t stop_lane = (uint32_t)__ffsll((long long)last) - 1;
-                n_sa_c += stop_lane + 1;
+                n_sa_c += stop_lane + 1; if (ctx_here) n_ctx_rows += stop_lane + 1;
                 n = cap_total; full = true;
-            } else { n += tot; n_sa_c += (uint32_t)__popcll(__ballot(in)); }
+            } else { n += tot; const uint32_t looked = (uint32_t)__popcll(__ballot(in)); n_sa_c += looked; if (ctx_here) n_ctx_rows += looked; }
         }
     }
     pc.stamp(SALT_CTR_X2);
@@ -737,13 +737,13 @@ __device__ __attribute__((noinline)) CandStats build_candidates(WaveLds &w)
     n = ns;                                                   // what the passes below see
     WSYNC();
     pc.stamp(SALT_CTR_T_LOCATE);
-    if (!a.finish) return CandStats{ n, n_sa_c, n_sa_r, n_loci_out, pe_in_lds ? 1u : 0u, n_ctx_rej };
+    if (!a.finish) return CandStats{ n, n_sa_c, n_sa_r, n_loci_out, pe_in_lds ? 1u : 0u, n_ctx_rej, n_ctx_rows };
     sort_loci(loci, n);
     WSYNC();
     pc.stamp(SALT_CTR_T_SORT);
     const uint32_t n_out = dedup_loci(loci, n, gap_mode, L, ix.ref_len);
     pc.stamp(SALT_CTR_T_DEDUP);
-    return CandStats{ n_out, n_sa_c, n_sa_r, n_loci_out, pe_in_lds ? 1u : 0u, n_ctx_rej };
+    return CandStats{ n_out, n_sa_c, n_sa_r, n_loci_out, pe_in_lds ? 1u : 0u, n_ctx_rej, n_ctx_rows };
 }
 
 template <bool PE>
@@ -1260,7 +1260,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     const uint32_t *rec = pm + (uint64_t)r * ap.pg.pm_stride;               // k_pack's record of this read
     const uint32_t L = rec[2 * ap.pg.nw8];
     salt_result_t *out = results + r;
-    uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_lv = 0, c_loci = 0, c_ctx_rej = 0;
+    uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_lv = 0, c_loci = 0, c_ctx_rej = 0, c_ctx_rows = 0;
     PhaseClock pc(phase);
     const uint64_t rt0 = phase ? __builtin_amdgcn_s_memrealtime() : 0;
     uint32_t *loci = PE ? pe_loci : w.loci;                   // candidate loci: LDS; for PE mates the global scratch when a list outgrows it
@@ -1306,7 +1306,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, false, ix.c_ctx, ix.ctx_k }, w);
         if (PE) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
         pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
-        const uint32_t n_loc = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci; c_ctx_rej += cs.n_ctx_rej;
+        const uint32_t n_loc = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci; c_ctx_rej += cs.n_ctx_rej; c_ctx_rows += cs.n_ctx_rows;
         uint32_t call_best_n = INF, call_best_pos = 0;
         auto verify_all = [&](uint32_t n) {                   // cand_e[i] = min(mismatches, INF) of loci[i], loads of 128 candidates in flight
             if (L <= 120) verify_quads<8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
@@ -1387,7 +1387,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                             atomicAdd(ctr + SALT_CTR_D_SA_HEAVY, c_sa_c + c_sa_r);
                             atomicAdd(ctr + SALT_CTR_D_VERIFY_HEAVY, c_verify * (L <= 120 ? 4u : L <= 248 ? 8u : (((L + 7) >> 3) + 4u) / 4u));
                             atomicAdd(ctr + SALT_CTR_D_OUT_HEAVY, 5u * (ns[0] + ns[1]) + 16u);      // the located rows + distances handed to k_gap
-                            if (ix.c_ctx) { atomicAdd(ctr + SALT_CTR_D_CTX_ROWS, c_verify + c_ctx_rej); atomicAdd(ctr + SALT_CTR_D_CTX_REJECTED, c_ctx_rej); }
+                            if (ix.c_ctx) { atomicAdd(ctr + SALT_CTR_D_CTX_ROWS, c_ctx_rows); atomicAdd(ctr + SALT_CTR_D_CTX_REJECTED, c_ctx_rej); }
                         }
                     }
                     return;
@@ -1520,7 +1520,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             atomicAdd(ctr + SALT_CTR_D_SA_HEAVY, c_sa_c + c_sa_r);
             atomicAdd(ctr + SALT_CTR_D_VERIFY_HEAVY, c_verify * (L <= 120 ? 4u : L <= 248 ? 8u : (((L + 7) >> 3) + 4u) / 4u));
             atomicAdd(ctr + SALT_CTR_D_OUT_HEAVY, 128u);
-            if (ix.c_ctx) { atomicAdd(ctr + SALT_CTR_D_CTX_ROWS, c_verify + c_ctx_rej); atomicAdd(ctr + SALT_CTR_D_CTX_REJECTED, c_ctx_rej); }
+            if (ix.c_ctx) { atomicAdd(ctr + SALT_CTR_D_CTX_ROWS, c_ctx_rows); atomicAdd(ctr + SALT_CTR_D_CTX_REJECTED, c_ctx_rej); }
         }
     }
 }
