@@ -747,3 +747,52 @@ def test_cli_text_path_regrows_its_workspace_when_records_get_shorter(lambda_cli
     assert a.returncode == 0 and b.returncode == 0, (a.stderr[-300:], b.stderr[-300:])
     assert b"workspace re-created" in a.stderr, a.stderr[-600:]
     assert strip(a.stdout) == strip(b.stdout)
+
+
+def test_gpu_context_table_rules_rows_out_without_changing_a_result(tmp_path):
+    """The context table (c_ctx, salt_device.h) lets k_heavy drop located rows whose window has more than 3 mismatches for certain.
+    A tandem-repeat genome (every seed hits hundreds of diverged copies) with one SNP per ~60 bases (contexts full of special sites),
+    reads with N, reads at both ends of the genome: every field equals the oracle's, equals the run without the table, and the table
+    did rule rows out."""
+    import sys
+    import salt_amd
+    from salt_amd import workload
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    import oracle_py
+    genome = workload.make_tandem(divergence=0.08)
+    pos, mask = workload.make_snps(genome, 20000, seed=6)
+    fa, snp, prefix = str(tmp_path / "g.fa"), str(tmp_path / "s.txt"), str(tmp_path / "idx")
+    workload.write_fasta(fa, "tandem", genome)
+    workload.write_snps(snp, "tandem", genome, pos, mask)
+    subprocess.run([os.path.join(root, "salt_amd", "bin", "salt-idx"), "-k", "21", fa, snp, prefix], check=True, stderr=subprocess.DEVNULL)
+    seqs, offs, _, _ = workload.make_reads(genome, pos, mask, 3000, 100, seed=21)
+    seqs = seqs.copy()
+    rng = np.random.default_rng(4)
+    for r in rng.choice(3000, 300, replace=False):              # N inside the contexts of some reads
+        seqs[int(offs[r]) + rng.integers(0, 100, 3)] = 4
+    ends = np.concatenate([genome[:100], genome[-100:], genome[1:101], genome[-101:-1]]).astype(np.uint8)
+    seqs = np.concatenate([seqs, ends]); offs = np.concatenate([offs, offs[-1] + 100 * np.arange(1, 5, dtype=np.uint32)]).astype(np.uint32)
+    n = len(offs) - 1
+    idx = salt_amd.Index.reload(prefix)
+    opt, _ = salt_amd.AlnOpt.from_argv([], idx.l_seed)
+    opt.collect_counters = 1
+    got = {}
+    for no_ctx in ("0", "1"):
+        os.environ["SALT_GPU_NO_CTX"] = no_ctx
+        try:
+            aln = salt_amd.GpuAligner(idx, device=0, max_reads=n, max_bases=int(offs[-1]) + 64)
+            aln.counters()
+            got[no_ctx] = (aln.alnse_core1(opt, seqs, offs).copy(), aln.counters())
+            aln.close()
+        finally:
+            del os.environ["SALT_GPU_NO_CTX"]
+    assert got["0"][1]["d_ctx_rejected"] > 10000 and got["0"][1]["d_ctx_rows"] > got["0"][1]["d_ctx_rejected"], got["0"][1]
+    assert got["1"][1]["d_ctx_rows"] == 0
+    assert got["0"][0].tobytes() == got["1"][0].tobytes()
+    ora = oracle_py.Oracle(prefix)
+    want = ora.align(ora.opt(l_overlap=opt.l_overlap, max_seed=opt.max_seed, max_locate=opt.max_locate, seed_only_ref=opt.seed_only_ref), seqs, offs, n_threads=8)
+    ora.close()
+    idx.destroy()
+    bad = oracle_py.compare(got["0"][0], want)
+    assert len(bad) == 0, bad[:5]
