@@ -215,6 +215,43 @@ def make_reads_hash(genome, site, n_reads, L, seed=1, batch=0):
     return reads.reshape(-1), offs, start, rev
 
 
+def make_pairs_hash(genome, site, n_pairs, L, seed=2, batch=0, insert_mean=400, insert_sd=50):
+    """One batch of read pairs as tensors on genome.device, mates interleaved (2p, 2p + 1) the way salt_gpu_align_pe takes them:
+    (codes uint8 [2 * n_pairs * L], offs int32 [2 * n_pairs + 1], start1 int64, start2 int64, flipped bool).  A fragment of
+    insert_mean + insert_sd * z bases (z: sum of four uniforms, variance 1) starts uniformly over the concatenated genome; one mate is
+    its first L bases as they lie, the other the reverse complement of its last L; `flipped` pairs swap the roles (the fragment came
+    from the reverse strand).  Every SNP site takes a random listed allele, 0.5 %/base substitutions; no indels, no N.
+    start1 / start2: the leftmost genome position of mate 2p / 2p + 1."""
+    import torch
+    dev, n = genome.device, genome.numel()
+    st = lambda k: 16 * batch + k
+    pid = torch.arange(n_pairs, dtype=torch.int64, device=dev)
+    z = sum((hbits(seed, st(1 + j), pid) % 100000).to(torch.float64) / 100000.0 for j in range(4))      # mean 2, variance 1/3
+    isz = (insert_mean + insert_sd * (z - 2.0) * (3.0 ** 0.5)).round().to(torch.int64).clamp(min=L + 10, max=insert_mean + 6 * insert_sd)
+    f0 = hbits(seed, st(0), pid) % (n - (insert_mean + 6 * insert_sd) - 8)
+    ar = torch.arange(L, dtype=torch.int64, device=dev)
+
+    def window(start, stream):
+        idx = start[:, None] + ar[None, :]
+        cell = pid[:, None] * L + ar[None, :]
+        frag = genome[idx]
+        m = site[idx]
+        pick = _pick_table(dev)[m.to(torch.int64), hbits(seed, st(stream), cell) % 12]
+        frag = torch.where(m != 0, pick, frag)
+        err = (hbits(seed, st(stream + 1), cell) % 1000) < 5
+        return torch.where(err, ((frag.to(torch.int64) + 1 + hbits(seed, st(stream + 2), cell) % 3) & 3).to(torch.uint8), frag)
+
+    left, right = window(f0, 5), window(f0 + isz - L, 8)
+    rc = lambda x: 3 - torch.flip(x, dims=[1])
+    flipped = (hbits(seed, st(11), pid) % 2) == 1
+    m1 = torch.where(flipped[:, None], rc(right), left)
+    m2 = torch.where(flipped[:, None], left, rc(right))
+    reads = torch.stack([m1, m2], dim=1).reshape(-1)
+    offs = (torch.arange(2 * n_pairs + 1, dtype=torch.int64, device=dev) * L).to(torch.int32)
+    s_left, s_right = f0, f0 + isz - L
+    return reads, offs, torch.where(flipped, s_right, s_left), torch.where(flipped, s_left, s_right), flipped
+
+
 def as_builder_input(genome, pos, mask, contigs=1, name="synth1"):
     """(contigs, SNP groups) as salt_amd.idx_build_mem takes them: base letters per contig, and per contig its SNPs with 0-based
     positions inside the contig, allele masks and reference codes (what write_fasta + write_snps would put into files)."""
