@@ -448,7 +448,9 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
 // ---------------------------------------------------------------------------------------------
 // k_align: LDS of one wave
 // ---------------------------------------------------------------------------------------------
-struct SaiLists { uint32_t sp[2][SLOTS], ep[2][SLOTS], off[2][SLOTS]; };     // [0]=C, [1]=R
+template <int NS> struct SaiListsT { uint32_t sp[2][NS], ep[2][NS], off[2][NS]; };     // [0]=C, [1]=R
+struct SaiLists { uint32_t *sp[2], *ep[2], *off[2]; };                                // the same lists by reference (the sort replica below)
+template <int NS> __device__ __forceinline__ SaiLists sai_ref(SaiListsT<NS> &a) { return SaiLists{ { a.sp[0], a.sp[1] }, { a.ep[0], a.ep[1] }, { a.off[0], a.off[1] } }; }
 struct LvTables { short L[LVK][64]; char A[LVK][64]; };
 // lane-parallel LV (one candidate per lane): nibble-packed text window per lane + two DP rows per lane
 static constexpr int LLV_K = 12;                 // handles k <= 12 (reads up to 129 bp at k = L/10)
@@ -457,9 +459,15 @@ static constexpr int LLV_W = 2 * LLV_K + 3;      // diagonals -k-1 .. k+1
 static constexpr int LLV_N = 64;                 // candidates per round: one per lane
 struct LaneLv { uint32_t T[LLV_N * LLV_TW]; uint8_t rows[2][LLV_W][LLV_N]; };
 struct LvBytes { uint8_t T[MAXL + 4 + 64]; uint8_t P[MAXL + 64]; };
-struct WaveLds {                                 // ~10.7 KB: 14-15 one-wave blocks per CU
+// NS: seed slots per list the block can hold; LLV: with the lane-LV scratch (9 KB) for gapped passes finished inside the block.
+// k_heavy's usual shape is <32, false> = 7.5 KB: its LDS is what decides how much of a CU it leaves to the kernels of the other
+// batches in flight (18.6 KB per block with 512 slots and the lane-LV scratch: 303-345 Mreads/s on the 4-stream step; 7.5 KB: 383-388)
+template <int NS, bool LLV>
+struct WaveLdsT {
+    static constexpr bool HAS_LLV = LLV;
+    static constexpr int N_SLOTS = NS;
     uint32_t pm[2][MAXL / 8];                               // one-hot nibble words of the read, both strands (k_pack)
-    union { SaiLists sai; LaneLv llv; LvBytes lvb; } u;     // seeds | lane-LV scratch | wave-LV byte strings
+    union U { SaiListsT<NS> sai; typename std::conditional<LLV, LaneLv, uint32_t>::type llv; LvBytes lvb; } u;     // seeds | lane-LV scratch | wave-LV byte strings
     uint8_t  cand_e[MAXLOC];
     uint32_t loci[MAXLOC];
     uint32_t hit_pos[2][NHIT];
@@ -468,6 +476,9 @@ struct WaveLds {                                 // ~10.7 KB: 14-15 one-wave blo
     int      n_cig;
     alignas(8) uint8_t cargs[128];                          // build_candidates' arguments (CandArgs): see there
 };
+typedef WaveLdsT<SLOTS, true> WaveLds;                      // any read the ABI admits, everything finished inside the block
+typedef WaveLdsT<32, false> WaveLdsSmall;                   // <= 32 seed slots per strand; a gapped read without a k_gap slot goes to the overflow queue
+typedef WaveLdsT<1, false> WaveLdsCigar;                    // k_cigar: the read, the byte strings of one traceback, the CIGAR
 
 // ---- klib introsort replica on the (sp,ep,off) triple arrays (ksort.h:159-228) ------------------
 struct Sai { uint32_t sp, ep, off; };
@@ -608,8 +619,8 @@ __device__ __forceinline__ CtxRead ctx_read(const uint32_t *pm, uint32_t L, uint
 // Not inlined (three call sites, ~1 400 instructions).  Its arguments are the same for all 64 lanes: passed by value they would be
 // written to and read back from scratch memory once per lane and call (~6 KB per call, measured as 430 MB of writes per launch), so the
 // caller leaves ONE copy in the wave's LDS.
-template <bool PE>
-__device__ __attribute__((noinline)) CandStats build_candidates(WaveLds &w)
+template <bool PE, class W>
+__device__ __attribute__((noinline)) CandStats build_candidates(W &w)
 {
     const CandArgs a = *reinterpret_cast<const CandArgs *>(w.cargs);
     const uint32_t lane = lane_id();
@@ -656,7 +667,7 @@ __device__ __attribute__((noinline)) CandStats build_candidates(WaveLds &w)
     // The reference orders both lists by interval size (alnse.c:307-308, klib introsort).  The order only decides WHICH
     // rows are located before a cap stops the loops; when every row is located the loci are the same set, and they
     // are sorted right after -- so the (serial) replica of the sort runs only when the cap can bite.
-    if (rows > cap_total && lane < 2) sai_introsort(w.u.sai, (int)lane, (int)n_list[lane]);
+    if (rows > cap_total && lane < 2) { SaiLists sl = sai_ref(w.u.sai); sai_introsort(sl, (int)lane, (int)n_list[lane]); }
     // a PE mate may enumerate 0x40000 loci, which need the global scratch; the usual few hundred stay in LDS like an SE read's (the
     // verify and rule passes then pay one memory round trip per trip instead of two or three)
     const bool pe_in_lds = PE && rows <= (uint32_t)MAXLOC;
@@ -746,14 +757,14 @@ __device__ __attribute__((noinline)) CandStats build_candidates(WaveLds &w)
     return CandStats{ n_out, n_sa_c, n_sa_r, n_loci_out, pe_in_lds ? 1u : 0u, n_ctx_rej, n_ctx_rows };
 }
 
-template <bool PE>
-__device__ __forceinline__ CandStats build_candidates_call(const CandArgs a, WaveLds &w)
+template <bool PE, class W>
+__device__ __forceinline__ CandStats build_candidates_call(const CandArgs a, W &w)
 {
     static_assert(sizeof(CandArgs) <= sizeof(w.cargs), "CandArgs outgrew its LDS slot");
     WSYNC();
     if (lane_id() == 0) *reinterpret_cast<CandArgs *>(w.cargs) = a;
     WSYNC();
-    return build_candidates<PE>(w);
+    return build_candidates<PE, W>(w);
 }
 
 // ---- masked Hamming distance, capped: returns 0..3 or INF (ed_mismatch, editdistance.c:88-163) ----
@@ -1146,7 +1157,8 @@ __device__ __forceinline__ void rule_sparse(const uint32_t *pos, const uint8_t *
 }
 
 // unpack text masks / one-hot pattern for LV (editdistance.c:183-227)
-__device__ void lv_unpack(const uint32_t *ref_generic, WaveLds &w, int strand, uint32_t L, uint32_t pos)
+template <class W>
+__device__ void lv_unpack(const uint32_t *ref_generic, W &w, int strand, uint32_t L, uint32_t pos)
 {
     const gp_u32 ref = as_global(ref_generic);
     const uint32_t tlen = L + 4;
@@ -1161,7 +1173,8 @@ __device__ void lv_unpack(const uint32_t *ref_generic, WaveLds &w, int strand, u
 }
 
 // CIGAR of a gapped hit into w.cig / w.n_cig (computeEditDistanceWithCigar, useM=1) ------------------
-__device__ __attribute__((noinline)) void lv_cigar(const uint32_t *ref, WaveLds &w, LvTables *tabp, int strand, uint32_t L, uint32_t pos, int k)
+template <class W>
+__device__ __attribute__((noinline)) void lv_cigar(const uint32_t *ref, W &w, LvTables *tabp, int strand, uint32_t L, uint32_t pos, int k)
 {
     LvTables &tab = *tabp;                  // per-block table in global memory (L2-resident, rare path)
     lv_unpack(ref, w, strand, L, pos);
@@ -1248,8 +1261,8 @@ __device__ __forceinline__ uint32_t store_gap_list(const uint32_t *loci, uint32_
     return n_out;
 }
 
-template <bool PE>
-__device__ __forceinline__ void align_general(const IndexView ix, const AlignParams ap, WaveLds &w, const uint32_t r,
+template <bool PE, class W>
+__device__ __forceinline__ void align_general(const IndexView ix, const AlignParams ap, W &w, const uint32_t r,
                               const uint32_t *__restrict__ pm,
                               const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r,
                               salt_result_t *__restrict__ results, unsigned long long *__restrict__ ctr,
@@ -1395,6 +1408,14 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                 WSYNC();                                                  // pool exhausted: finish this read here
             }
         }
+        if constexpr (!W::HAS_LLV) {
+            // ... which takes the lane-LV scratch this block does not carry: the read goes to the overflow queue and the pass behind
+            // this kernel (the same code in a block that has it) starts it again.  Nothing of it has been written yet.
+            if (lanes_fit && n_cand_nogap > 0) {
+                if (lane == 0) g.ovq[atomicAdd(&g.gctl[9], 1u)] = r;
+                return;
+            }
+        }
         for (int strand = 0; strand < 2; ++strand) {
             pc.stamp(SALT_CTR_T_GAP);
             const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, true, nullptr, 0 }, w);
@@ -1404,8 +1425,8 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             bool any = false;
             // all candidates' distances at the call's initial bound, 64 at a time (one per lane); the
             // sequential rule below then only compares numbers
-            const bool lanes_ok = lanes_fit;
-            if (lanes_ok) {
+            const bool lanes_ok = lanes_fit && W::HAS_LLV;
+            if constexpr (W::HAS_LLV) if (lanes_ok) {
                 const int k0 = gap_k0;
                 for (uint32_t b = 0; b < n_cand; b += LLV_N) {
                     WSYNC();
@@ -1531,27 +1552,28 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
 //   qctl[2] gapped reads (slots)       qctl[3] k_gap head        qctl[4] k_gapfin head
 //   qctl[5] k_gap items                qctl[6] CIGAR items       qctl[7] k_cigar head      qctl[8] pool entries used
 // ---------------------------------------------------------------------------------------------
-template <bool PE>
+template <bool PE, class W>
 __device__ __forceinline__ void heavy_body(const IndexView &ix, const AlignParams &ap, const uint32_t *__restrict__ pm,
                                            const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r,
                                            salt_result_t *__restrict__ results, const uint32_t *__restrict__ queue,
                                            unsigned long long *__restrict__ ctr, LvTables *__restrict__ lvtab, const GapBufs g,
-                                           uint8_t *__restrict__ pe_scr)
+                                           uint8_t *__restrict__ pe_scr, const int overflow_pass)
 {
-    __shared__ WaveLds w;
+    __shared__ W w;
     __shared__ uint32_t s_item;
     __shared__ unsigned long long s_phase[SALT_CTR_N];
     unsigned long long *phase = ctr ? s_phase : nullptr;
     if (ctr) { for (int i = threadIdx.x; i < SALT_CTR_N; i += 64) s_phase[i] = 0; }
     WSYNC();
-    const uint32_t n_items = ap.all_heavy ? ap.n_reads : g.gctl[0];
+    // the usual pass takes the reads k_light queued (or all of them); the overflow pass the ones a block without the lane-LV scratch left
+    const uint32_t n_items = overflow_pass ? g.gctl[9] : ap.all_heavy ? ap.n_reads : g.gctl[0];
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(&g.gctl[1], 1u);
+        if (threadIdx.x == 0) s_item = atomicAdd(&g.gctl[overflow_pass ? 10 : 1], 1u);
         WSYNC();
         const uint32_t it = s_item;
         WSYNC();
         if (it >= n_items) break;
-        const uint32_t r = ap.all_heavy ? it : queue[it];
+        const uint32_t r = overflow_pass ? g.ovq[it] : ap.all_heavy ? it : queue[it];
         align_general<PE>(ix, ap, w, r, pm, sai_c, sai_r, results, ctr, phase, lvtab + blockIdx.x, g,
                           pe_scr ? reinterpret_cast<uint32_t *>(pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5) : nullptr,
                           pe_scr ? pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5 + (size_t)PE_LOCI_CAP * 4 : nullptr);
@@ -1564,15 +1586,17 @@ __device__ __forceinline__ void heavy_body(const IndexView &ix, const AlignParam
     }
 }
 
-#define HEAVY_KERNEL(NAME, PE)                                                                                          \
+#define HEAVY_KERNEL(NAME, PE, LDS)                                                                                     \
 __global__ void __launch_bounds__(64)                                                                                   \
 NAME(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,                                                     \
      const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,             \
      const uint32_t *__restrict__ queue, unsigned long long *__restrict__ ctr,                                          \
-     LvTables *__restrict__ lvtab, GapBufs g, uint8_t *__restrict__ pe_scr)                                             \
-{ heavy_body<PE>(ix, ap, pm, sai_c, sai_r, results, queue, ctr, lvtab, g, pe_scr); }
-HEAVY_KERNEL(k_heavy, false)
-HEAVY_KERNEL(k_heavy_pe, true)                  // paired-end mates: PE locate rule, loci in global scratch, gap bound 3, no deferral
+     LvTables *__restrict__ lvtab, GapBufs g, uint8_t *__restrict__ pe_scr, int overflow_pass)                          \
+{ heavy_body<PE, LDS>(ix, ap, pm, sai_c, sai_r, results, queue, ctr, lvtab, g, pe_scr, overflow_pass); }
+HEAVY_KERNEL(k_heavy, false, WaveLdsSmall)      // the usual shape: <= 32 seed slots per strand, gapped reads handed to k_gap
+HEAVY_KERNEL(k_heavy_pe, true, WaveLdsSmall)    // paired-end mates: PE locate rule, loci in global scratch, gap bound 3
+HEAVY_KERNEL(k_heavy_big, false, WaveLds)       // any read the ABI admits, everything finished inside the block: batches with more seed
+HEAVY_KERNEL(k_heavy_pe_big, true, WaveLds)     // slots, runs without the k_gap buffers, and the overflow pass behind the usual shape
 
 // k_gap: one item = 32 candidates of one strand of one queued read: their Landau-Vishkin distances at the bound L/10
 // (ed_diff -> computeEditDistance, editdistance.c:174-232, LandauVishkin.c:19-122), one candidate per lane
@@ -1695,7 +1719,7 @@ k_cigar(IndexView ix, PackGeom pg, const uint32_t *__restrict__ pm, salt_result_
         const uint32_t *__restrict__ items, const uint32_t *__restrict__ count, uint32_t *__restrict__ head, uint32_t cap_items,
         LvTables *__restrict__ lvtab)
 {
-    __shared__ WaveLds w;
+    __shared__ WaveLdsCigar w;
     __shared__ uint32_t s_item;
     const uint32_t lane = lane_id();
     const uint32_t n_items = *count < cap_items ? *count : cap_items;
@@ -2570,13 +2594,25 @@ uint32_t heavy_blocks_per_cu()
 
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, unsigned long long *ctr,
-                  uint32_t n_blocks, uint32_t gap_blocks, void *lvtab, const GapBufs &g, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st)
+                  uint32_t n_blocks, uint32_t gap_blocks, void *lvtab, const GapBufs &g_in, uint32_t *ovq, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st)
 {
     if (!ap.n_reads) { if (ev3) for (int i = 0; i < 3; ++i) hipEventRecord(ev3[i], st); return; }
     uint32_t blocks = n_blocks < ap.n_reads ? n_blocks : ap.n_reads;
     LvTables *tab = static_cast<LvTables *>(lvtab);
-    if (ap.pe) hipLaunchKernelGGL(k_heavy_pe, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr);
-    else     hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr);
+    GapBufs g = g_in; g.ovq = ovq;
+    // The usual shape (7.5 KB of LDS per block) when the batch fits it: at most 32 seed slots per strand and k_gap's buffers to hand gapped
+    // reads to; the few reads it cannot finish (no k_gap slot left) wait in the overflow queue for the pass right behind it, which runs
+    // the all-in-one shape (18.6 KB) and leaves at once when the queue is empty.  SALT_GPU_HEAVY_BIG=1: the all-in-one shape for everything.
+    static const bool force_big = getenv("SALT_GPU_HEAVY_BIG") && atoi(getenv("SALT_GPU_HEAVY_BIG"));
+    const bool small = !force_big && g.cap > 0 && ovq != nullptr && ap.spr <= (uint32_t)WaveLdsSmall::N_SLOTS;
+    if (small) {
+        if (ap.pe) hipLaunchKernelGGL(k_heavy_pe, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr, 0);
+        else     hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr, 0);
+    }
+    // (the overflow pass on a small grid: it is empty nearly always, and 1 536 blocks of 18.6 KB each that only look at a counter cost 70 us)
+    const uint32_t big_blocks = small && blocks > 256u ? 256u : blocks;
+    if (ap.pe) hipLaunchKernelGGL(k_heavy_pe_big, dim3(big_blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr, small ? 1 : 0);
+    else     hipLaunchKernelGGL(k_heavy_big, dim3(big_blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr, small ? 1 : 0);
     if (ev3) hipEventRecord(ev3[0], st);
     if (!g.cap) { if (ev3) { hipEventRecord(ev3[1], st); hipEventRecord(ev3[2], st); } return; }
     // the deferred gapped passes: distances by (read, strand, 32 candidates), one finishing wave per read, one traceback per wave
@@ -2592,7 +2628,10 @@ GapBufs gap_bufs_layout(uint8_t *base, uint32_t cap, uint32_t *gctl, size_t *byt
 {
     GapBufs g; size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off = (off + n + 255) & ~(size_t)255; return base ? base + o : nullptr; };
-    g.pool = cap * 2u * (uint32_t)MAXLOC;                                   // an SE read needs at most 2 x 1000 entries; PE mates share the pool
+    // an SE read needs at most 2 x 1000 entries; PE mates share the pool.  Beyond 32 768 slots the pool stops growing with them
+    // (64 M rows = 335 MB): a batch in which EVERY read needs the gapped pass still finds a slot per read, and rows for all of them
+    // unless they are repeat reads throughout (then the rest takes the overflow pass)
+    { const uint64_t want = (uint64_t)cap * 2u * (uint64_t)MAXLOC; g.pool = (uint32_t)(want < (1ull << 26) ? want : (1ull << 26)); }
     g.items_cap = g.pool / LLV_N + 2u * cap;
     g.gq = reinterpret_cast<uint32_t *>(take((size_t)cap * 4));
     g.gn = reinterpret_cast<uint32_t *>(take((size_t)cap * 2 * 4));
@@ -2601,7 +2640,7 @@ GapBufs gap_bufs_layout(uint8_t *base, uint32_t cap, uint32_t *gctl, size_t *byt
     g.ge = take((size_t)g.pool);
     g.gitems = reinterpret_cast<uint32_t *>(take((size_t)g.items_cap * 4));
     g.cq = reinterpret_cast<uint32_t *>(take((size_t)cap * (1 + SALT_MAX_HITS) * 4));
-    g.gctl = gctl; g.cap = cap;
+    g.gctl = gctl; g.cap = cap; g.ovq = nullptr;
     if (bytes) *bytes = off;
     return g;
 }

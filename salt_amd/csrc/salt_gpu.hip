@@ -284,10 +284,11 @@ extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint
     CHKW(hipMalloc((void **)&ws->d_offs, ((uint64_t)max_reads + 1) * 4));
     CHKW(hipMalloc((void **)&ws->d_results, (uint64_t)max_reads * sizeof(salt_result_t)));
     CHKW(hipMemset(ws->d_results, 0, (uint64_t)max_reads * sizeof(salt_result_t)));
-    CHKW(hipMalloc((void **)&ws->d_queue, (uint64_t)max_reads * 4));
+    CHKW(hipMalloc((void **)&ws->d_queue, (uint64_t)max_reads * 8));           // the reads k_light queues + k_heavy's overflow queue
     CHKW(hipMalloc((void **)&ws->d_qctl, 16 * 4));
-    ws->gcap = max_reads < 65536 ? max_reads : 65536;                   // slots for reads whose gapped pass is deferred (8 KB + 2 KB of pool each)
+    ws->gcap = max_reads < (1u << 20) ? max_reads : (1u << 20);         // slots for reads whose gapped pass is deferred (44 B each + their rows in the pool)
     if (const char *e3 = getenv("SALT_GPU_NO_GAP_DEFER")) if (atoi(e3)) ws->gcap = 0;
+    if (const char *e3 = getenv("SALT_GPU_GAP_SLOTS")) { const int v = atoi(e3); if (v > 0 && (uint32_t)v < ws->gcap) ws->gcap = (uint32_t)v; }     // tests: the overflow pass
     if (ws->gcap) {
         size_t gbytes = 0;
         gap_bufs_layout(nullptr, ws->gcap, nullptr, &gbytes);
@@ -300,7 +301,7 @@ extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint
         // Half of that by default: the persistent kernels are latency bound, so alone they lose 3 % with 6 waves per CU instead of
         // 12, while the kernels of the other batches in flight (other workspaces / streams) find room: +8 % on the 4-stream step
         // (measured: 3 -> 670, 4 -> 693, 6 -> 705, 8 -> 686, 12 -> 654 Mreads/s)
-        if (per_cu > 6) per_cu = 6;
+        if (per_cu > 5) per_cu = 5;
         if (const char *e2 = getenv("SALT_GPU_HEAVY_PER_CU")) { int v = atoi(e2); if (v > 0 && (uint32_t)v <= heavy_blocks_per_cu()) per_cu = (uint32_t)v; }
         ws->heavy_blocks = (uint32_t)prop.multiProcessorCount * per_cu;    // persistent one-wave blocks
         // k_gap's items (64 candidates' Landau-Vishkin distances, ~70 us each) are independent and need no table of their own: its grid is
@@ -406,7 +407,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     if (timed) HIPCHK(hipEventRecord(ev[3], st));
     launch_heavy(ws->ix->view, ap, ws->d_pm, ws->d_sai_c, ws->d_sai_r,
                  static_cast<salt_result_t *>(d_results), ws->d_queue, ctr, ws->heavy_blocks, ws->gap_blocks, ws->d_lvtab,
-                 gap_bufs_layout(ws->d_gap, ws->gcap, ws->d_qctl, nullptr), pe ? ws->d_pe_scr : nullptr, timed ? ev + 4 : nullptr, st);
+                 gap_bufs_layout(ws->d_gap, ws->gcap, ws->d_qctl, nullptr), ws->d_queue + ws->max_reads, pe ? ws->d_pe_scr : nullptr, timed ? ev + 4 : nullptr, st);
     if (timed) { HIPCHK(hipEventRecord(ev[7], st)); ++ws->n_timed; }
     HIPCHK(hipGetLastError());
     return SALT_OK;

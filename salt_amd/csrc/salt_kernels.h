@@ -62,11 +62,12 @@ struct GapBufs {
     uint32_t *cq;        // k_cigar items: (read << 3) | which (0 = the alignment, 1 + i = alternative hit i)
     uint32_t *gctl;
     uint32_t cap, pool, items_cap;
+    uint32_t *ovq;       // reads k_heavy's small shape could not finish (launch_heavy); count gctl[9], head gctl[10]
 };
 GapBufs gap_bufs_layout(uint8_t *base, uint32_t cap, uint32_t *gctl, size_t *bytes);   // base = nullptr: size only
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, unsigned long long *ctr,
-                  uint32_t n_blocks, uint32_t gap_blocks, void *lvtab, const GapBufs &g, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st);
+                  uint32_t n_blocks, uint32_t gap_blocks, void *lvtab, const GapBufs &g, uint32_t *ovq, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st);
 size_t lv_table_bytes();                // per-block LV traceback table (global memory)
 
 // ---- paired end (salt_pe.hip) ----

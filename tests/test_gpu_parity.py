@@ -796,3 +796,37 @@ def test_gpu_context_table_rules_rows_out_without_changing_a_result(tmp_path):
     idx.destroy()
     bad = oracle_py.compare(got["0"][0], want)
     assert len(bad) == 0, bad[:5]
+
+
+def test_gpu_more_gapped_reads_than_k_gap_slots_take_the_overflow_pass(monkeypatch):
+    """k_heavy's usual shape hands gapped reads to k_gap through a slot each (as many as the workspace has reads, up to 2^20) and rows in
+    a pool; a read that finds neither goes to the overflow queue and is finished by the all-in-one shape launched behind it.  90 000
+    reads with an indel each in ONE batch with the slots cut to 20 000 (SALT_GPU_GAP_SLOTS): every field against the oracle."""
+    import salt_amd
+    monkeypatch.setenv("SALT_GPU_GAP_SLOTS", "20000")
+    rng = np.random.default_rng(17)
+    genome = []
+    with open(os.path.join(LAMBDA, "genome.fa")) as f:
+        cur = []
+        for line in f:
+            if line.startswith(">"):
+                if cur:
+                    genome.append("".join(cur))
+                cur = []
+            else:
+                cur.append(line.strip())
+        genome.append("".join(cur))
+    code = np.frombuffer(genome[0].encode(), dtype=np.uint8)
+    g = np.full(len(code), 4, dtype=np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        g[(code == c) | (code == c + 32)] = i
+    n, L = 90_000, 100
+    start = rng.integers(0, len(g) - L - 8, n)
+    p = rng.integers(20, 80, n)
+    idx = start[:, None] + np.arange(L)[None, :]
+    idx = np.where(np.arange(L)[None, :] >= p[:, None], idx + 2, idx)          # a 2-base deletion at p
+    seqs = g[idx].reshape(-1)
+    offs = (np.arange(n + 1, dtype=np.uint64) * L).astype(np.uint32)
+    res, want, bad = _oracle_compare(os.path.join(LAMBDA, "idx"), seqs, offs)
+    assert len(bad) == 0, (len(bad), bad[:5])
+    assert int((want["is_gap"] == 1).sum()) > 70_000                            # 50 000 and more of them took the overflow pass
