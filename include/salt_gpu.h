@@ -182,6 +182,12 @@ int  salt_gpu_ws_pe_counts(salt_gpu_ws_t *ws, uint32_t out[8]);
  * Multi-line FASTQ records are not read here (SALT_E_INVAL names the record); callers fall back to their host parser. */
 typedef struct { int32_t print_xa_cigar, print_nm_md; const char *rg_id; } salt_text_opt_t;      /* -c, -d, -g */
 int  salt_gpu_index_set_contigs(salt_gpu_index_t *ix, int32_t n, const int64_t *offsets, const char *const *names);
+/* Paired end (alnpe_core1 + alnpe_sam, sam.c:331-457): fastq1 / fastq2 hold the same number of whole 4-line records, mate 1 and mate 2 of
+ * pair p at the same record index; the SAM block holds both records of every pair in order, each followed by the reference's empty
+ * line (alnpe.c:640-648).  Needs salt_gpu_index_set_pac and the contig table. */
+int  salt_gpu_align_pe_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, const salt_pe_opt_t *pe, const salt_text_opt_t *topt,
+                            const char *fastq1, uint64_t n1_bytes, const char *fastq2, uint64_t n2_bytes,
+                            const char **sam, uint64_t *sam_bytes, uint32_t *n_pairs);
 /* optional: size the workspace's text buffers ahead of the first call (blocks of up to max_block_bytes with about est_reads reads of
  * up to max_read_len bases, about est_sam_bytes of SAM); what a later block needs beyond that is grown then.  host_sam (may be NULL):
  * page-locked memory of the caller's (salt_gpu_host_alloc, e.g. allocated while the index was loading) the SAM text is returned in as

@@ -639,6 +639,7 @@ extern "C" int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
     d.c_off = ix->d_c_off; d.c_name_off = ix->d_c_name_off; d.c_names = ix->d_c_names; d.n_contigs = ix->n_contigs;
     d.text = ix->view.text; d.ref = ix->view.ref; d.xa_cigar = to->print_xa_cigar; d.nm_md = to->print_nm_md;
     d.rg = ws->d_rg; d.rg_len = to->rg_id ? (int32_t)rg.size() : 0;
+    d.pe = 0; d.min_tlen = d.max_tlen = 0;
     if (to->rg_id && rg.empty()) return fail(SALT_E_INVAL, "empty read group id");
     HIPCHK(launch_sam_len(d, n_rec, ws->d_samoff, ws->d_scan, ws->scan_bytes, st));
     uint32_t total = 0;
@@ -662,6 +663,115 @@ extern "C" int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
                         "kernels + SAM lengths %.1f, SAM buffers %.1f, write + copy out %.1f\n", (tm[1] - tm[0]) * 1e3, (tm[2] - tm[1]) * 1e3, (tm[3] - tm[2]) * 1e3,
                 (tm[4] - tm[3]) * 1e3, (tm[5] - tm[4]) * 1e3, (tm[6] - tm[5]) * 1e3, (tm[7] - tm[6]) * 1e3);
     *sam = ws->h_sam; *sam_bytes = total; *n_reads = n_rec;
+    return SALT_OK;
+}
+
+static int pe_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_pe_opt_t *pe, uint32_t n_pairs, uint32_t max_len,
+                            const void *d_seqs, const void *d_offs, void *d_results, hipStream_t st);
+
+// Paired end: two blocks holding the same number of whole 4-line records (mates in file order); the SAM block holds both records of
+// every pair, each followed by the reference's empty line (alnpe.c:640-648).
+extern "C" int salt_gpu_align_pe_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_pe_opt_t *pe, const salt_text_opt_t *to,
+                                      const char *fastq1, uint64_t n1, const char *fastq2, uint64_t n2,
+                                      const char **sam, uint64_t *sam_bytes, uint32_t *n_pairs)
+{
+    if (!ws || !o || !pe || !to || !fastq1 || !fastq2 || !sam || !sam_bytes || !n_pairs) return fail(SALT_E_INVAL, "null argument");
+    *sam = nullptr; *sam_bytes = 0; *n_pairs = 0;
+    if (n1 == 0 && n2 == 0) return SALT_OK;
+    if (n1 == 0 || n2 == 0) return fail(SALT_E_INVAL, "the two FASTQ blocks hold different numbers of reads");
+    if (n1 + n2 >= 0xFFFFFFE0ull) return fail(SALT_E_CAPACITY, "FASTQ blocks of 4 GiB or more");
+    if (fastq1[n1 - 1] != '\n' || fastq2[n2 - 1] != '\n') return fail(SALT_E_INVAL, "FASTQ block must end with a newline");
+    salt_gpu_index *ix = ws->ix;
+    if (!ix->d_c_off) return fail(SALT_E_INVAL, "SAM text needs the contig table: call salt_gpu_index_set_contigs first");
+    if (!ix->d_pac) return fail(SALT_E_INVAL, "paired end needs the 2-bit genome: call salt_gpu_index_set_pac first");
+    HIPCHK(hipSetDevice(ix->device));
+    hipStream_t st = ws->stream;
+    const uint64_t b2 = (n1 + 3) & ~3ull;                      // block 2 behind block 1, on a word boundary
+    REGROW(ws->d_raw, ws->raw_cap, b2 + n2 + 64, uint8_t);
+    const uint64_t t1 = (n1 + FQ_TILE - 1) / FQ_TILE, t2 = (n2 + FQ_TILE - 1) / FQ_TILE;
+    if (!ws->d_tctl) HIPCHK(hipMalloc((void **)&ws->d_tctl, 16));
+    {
+        REGROW(ws->d_tile, ws->tile_cap, ws->raw_cap / FQ_TILE + 16, uint32_t);
+        const size_t need = text_scan_bytes(std::max<uint64_t>(ws->tile_cap, (uint64_t)ws->max_reads + 2));
+        if (need > ws->scan_bytes) { HIPCHK(hipStreamSynchronize(st)); hipFree(ws->d_scan); ws->d_scan = nullptr; ws->scan_bytes = 0; HIPCHK(hipMalloc(&ws->d_scan, need)); ws->scan_bytes = need; }
+    }
+    uint32_t *tile1 = ws->d_tile, *tile2 = ws->d_tile + t1 + 4;
+    HIPCHK(hipMemcpyAsync(ws->d_raw, fastq1, n1, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ws->d_raw + b2, fastq2, n2, hipMemcpyHostToDevice, st));
+    uint32_t nl[2] = { 0, 0 };
+    HIPCHK(launch_fq_count(ws->d_raw, n1, tile1, ws->d_scan, ws->scan_bytes, st));
+    HIPCHK(launch_fq_count(ws->d_raw + b2, n2, tile2, ws->d_scan, ws->scan_bytes, st));
+    HIPCHK(hipMemcpyAsync(&nl[0], tile1 + t1, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&nl[1], tile2 + t2, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (nl[0] % 4 != 0 || nl[1] % 4 != 0) return fail(SALT_E_INVAL, "FASTQ block does not hold whole 4-line records (" + std::to_string(nl[0]) + " / " + std::to_string(nl[1]) + " lines)");
+    if (nl[0] != nl[1]) return fail(SALT_E_INVAL, "the two FASTQ blocks hold different numbers of reads (" + std::to_string(nl[0] / 4) + " / " + std::to_string(nl[1] / 4) + ")");
+    const uint32_t n = nl[0] / 4, n_rec = 2 * n;
+    if (n_rec > ws->max_reads) return fail(SALT_E_CAPACITY, "more reads in the blocks (" + std::to_string(n_rec) + ") than the workspace holds");
+    if (n == 0) return SALT_OK;
+    REGROW(ws->d_lines, ws->lines_cap, (uint64_t)nl[0] + nl[1] + 24, uint32_t);
+    uint32_t *lines1 = ws->d_lines, *lines2 = ws->d_lines + nl[0] + 8;
+    HIPCHK(launch_fq_lines(ws->d_raw, n1, tile1, lines1, st));
+    HIPCHK(launch_fq_lines(ws->d_raw + b2, n2, tile2, lines2, st));
+    if (!ws->d_rec) HIPCHK(hipMalloc((void **)&ws->d_rec, (uint64_t)ws->max_reads * sizeof(FqRec)));
+    {
+        const uint32_t init[4] = { 0u, 0u, 0xFFFFFFFFu, 0u };
+        HIPCHK(hipMemcpyAsync(ws->d_tctl, init, sizeof init, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(ws->d_offs + n_rec, 0, 4, st));
+    }
+    HIPCHK(launch_fq_parse_mate(ws->d_raw, 0u, lines1, n, 0u, ws->d_rec, ws->d_offs, ws->d_tctl, st));
+    HIPCHK(launch_fq_parse_mate(ws->d_raw, (uint32_t)b2, lines2, n, 1u, ws->d_rec, ws->d_offs, ws->d_tctl, st));
+    HIPCHK(launch_text_scan(ws->d_offs, n_rec + 1, ws->d_scan, ws->scan_bytes, st));
+    uint32_t ctl[4] = { 0, 0, 0, 0 }, bases = 0;
+    HIPCHK(hipMemcpyAsync(ctl, ws->d_tctl, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&bases, ws->d_offs + n_rec, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (ctl[0]) {
+        const char *what = ctl[0] & 1 ? "a record does not start with '@'" : ctl[0] & 2 ? "the third line of a record does not start with '+'"
+                         : ctl[0] & 4 ? "sequence and quality lengths differ" : "empty read";
+        return fail(SALT_E_INVAL, std::string("input is not 4-line FASTQ at record ") + std::to_string(ctl[2]) + " of the blocks: " + what);
+    }
+    if ((uint64_t)bases > ws->max_bases) {
+        hipFree(ws->d_seqs); ws->d_seqs = nullptr;
+        HIPCHK(hipMalloc((void **)&ws->d_seqs, (uint64_t)bases + bases / 4 + 64));
+        ws->max_bases = (uint64_t)bases + bases / 4;
+    }
+    HIPCHK(launch_fq_codes(ws->d_raw, ws->d_rec, ws->d_offs, n_rec, ws->d_seqs, st));
+    int rc = pe_resident_impl(ws, o, pe, n, ctl[1], ws->d_seqs, ws->d_offs, ws->d_results, st);
+    if (rc) return rc;
+    const std::string rg = to->rg_id ? to->rg_id : "";
+    if (to->rg_id && rg.empty()) return fail(SALT_E_INVAL, "empty read group id");
+    if (rg != ws->rg || (!rg.empty() && !ws->d_rg)) {
+        HIPCHK(hipStreamSynchronize(st));
+        hipFree(ws->d_rg); ws->d_rg = nullptr;
+        if (!rg.empty()) { HIPCHK(hipMalloc((void **)&ws->d_rg, rg.size() + 1)); HIPCHK(hipMemcpy(ws->d_rg, rg.data(), rg.size(), hipMemcpyHostToDevice)); }
+        ws->rg = rg;
+    }
+    if (!ws->d_samoff) HIPCHK(hipMalloc((void **)&ws->d_samoff, ((uint64_t)ws->max_reads + 2) * 4));
+    SamDev d;
+    d.raw = ws->d_raw; d.rec = ws->d_rec; d.seqs = ws->d_seqs; d.offs = ws->d_offs; d.res = ws->d_results;
+    d.c_off = ix->d_c_off; d.c_name_off = ix->d_c_name_off; d.c_names = ix->d_c_names; d.n_contigs = ix->n_contigs;
+    d.text = ix->view.text; d.ref = ix->view.ref; d.xa_cigar = to->print_xa_cigar; d.nm_md = to->print_nm_md;
+    d.rg = ws->d_rg; d.rg_len = to->rg_id ? (int32_t)rg.size() : 0;
+    d.pe = 1; d.min_tlen = pe->min_tlen; d.max_tlen = pe->max_tlen;
+    HIPCHK(launch_sam_len(d, n_rec, ws->d_samoff, ws->d_scan, ws->scan_bytes, st));
+    uint32_t total = 0, n_over = 0;
+    HIPCHK(hipMemcpyAsync(&total, ws->d_samoff + n_rec, 4, hipMemcpyDeviceToHost, st));
+    if (ws->d_pctl) HIPCHK(hipMemcpyAsync(&n_over, ws->d_pctl + 4, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_over) return fail(SALT_E_CAPACITY, std::to_string(n_over) + " mate rescue(s) need a Smith-Waterman band wider than this build holds (SW_BAND_W): "
+                                             "the rows of this batch would differ from the reference's");
+    if ((uint64_t)total + 64 > ws->sam_cap) {
+        hipFree(ws->d_sam); ws->d_sam = nullptr; if (ws->h_sam && ws->h_sam_owned) hipHostFree(ws->h_sam); ws->h_sam = nullptr; ws->sam_cap = 0; ws->h_sam_owned = true;
+        const uint64_t want = (uint64_t)total + total / 4 + 64;
+        HIPCHK(hipMalloc((void **)&ws->d_sam, want));
+        HIPCHK(hipHostMalloc((void **)&ws->h_sam, want, hipHostMallocDefault));
+        ws->sam_cap = want;
+    }
+    HIPCHK(launch_sam_write(d, n_rec, ws->d_samoff, ws->d_sam, st));
+    HIPCHK(hipMemcpyAsync(ws->h_sam, ws->d_sam, total, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *sam = ws->h_sam; *sam_bytes = total; *n_pairs = n;
     return SALT_OK;
 }
 #undef REGROW

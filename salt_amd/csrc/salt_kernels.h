@@ -115,6 +115,7 @@ struct SamDev {                                                               //
     const int64_t *c_off; const uint32_t *c_name_off; const char *c_names; int32_t n_contigs;      // contigs (bntann1_t: offset, name)
     const uint32_t *text, *ref;                                                // 2-bit genome, mixRef
     int32_t xa_cigar, nm_md; const char *rg; int32_t rg_len;
+    int32_t pe; uint32_t min_tlen, max_tlen;                                   // pe: records 2p, 2p + 1 are the mates of pair p (alnpe_sam)
 };
 hipError_t text_warm();                                     // forces the load of the text kernels' code object
 size_t text_scan_bytes(uint64_t max_items);
@@ -122,6 +123,11 @@ hipError_t launch_fq_count(const uint8_t *raw, uint64_t n, uint32_t *tile_cnt, v
 hipError_t launch_fq_lines(const uint8_t *raw, uint64_t n, const uint32_t *tile_off, uint32_t *line_start, hipStream_t st);
 hipError_t launch_fq_parse(const uint8_t *raw, const uint32_t *line_start, uint32_t n_rec, FqRec *rec, uint32_t *offs, uint32_t *ctl,
                            void *tmp, size_t tmp_bytes, hipStream_t st);
+// one file of a pair: the records of the block at raw + base become rec[2 i + which] (offsets relative to raw), their lengths len[2 i + which];
+// the caller initialises ctl ({ 0, 0, 0xFFFFFFFF, 0 }) and scans len afterwards (launch_text_scan)
+hipError_t launch_fq_parse_mate(const uint8_t *raw, uint32_t base, const uint32_t *line_start, uint32_t n_rec, uint32_t which, FqRec *rec, uint32_t *len,
+                                uint32_t *ctl, hipStream_t st);
+hipError_t launch_text_scan(uint32_t *v, uint32_t n_plus_1, void *tmp, size_t tmp_bytes, hipStream_t st);       // exclusive scan in place
 hipError_t launch_fq_codes(const uint8_t *raw, const FqRec *rec, const uint32_t *offs, uint32_t n_rec, uint8_t *seqs, hipStream_t st);
 hipError_t launch_sam_len(const SamDev &d, uint32_t n, uint32_t *off, void *tmp, size_t tmp_bytes, hipStream_t st);
 hipError_t launch_sam_write(const SamDev &d, uint32_t n, const uint32_t *off, char *out, hipStream_t st);

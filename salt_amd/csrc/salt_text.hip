@@ -69,8 +69,10 @@ __device__ __forceinline__ uint8_t nt4_dev(uint8_t c)
 }
 
 // err bits: 1 header does not start with '@', 2 third line does not start with '+', 4 sequence / quality lengths differ, 8 empty read
+// raw: the block; base: its offset in the buffer the records' offsets refer to; the record goes to rec[stride * i + which]
 __global__ void __launch_bounds__(256) k_fq_parse(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ line_start, uint32_t n_rec,
-                                                   FqRec *__restrict__ rec, uint32_t *__restrict__ len, uint32_t *__restrict__ ctl /* [0] err, [1] max len, [2] first bad record */)
+                                                   FqRec *__restrict__ rec, uint32_t *__restrict__ len, uint32_t *__restrict__ ctl /* [0] err, [1] max len, [2] first bad record */,
+                                                   uint32_t base, uint32_t stride, uint32_t which)
 {
     TSTRIDE(i, n_rec) {
         const uint32_t l0 = line_start[4 * i], l1 = line_start[4 * i + 1], l2 = line_start[4 * i + 2], l3 = line_start[4 * i + 3], l4 = line_start[4 * i + 4];
@@ -87,8 +89,8 @@ __global__ void __launch_bounds__(256) k_fq_parse(const uint8_t *__restrict__ ra
         const uint32_t L = se - l1;
         if (qe - l3 != L) err |= 4;
         if (L == 0) err |= 8;
-        FqRec r; r.name_off = l0 + 1; r.name_len = name_len; r.seq_off = l1; r.len = L; r.qual_off = l3;
-        rec[i] = r; len[i] = L;
+        FqRec r; r.name_off = base + l0 + 1; r.name_len = name_len; r.seq_off = base + l1; r.len = L; r.qual_off = base + l3;
+        rec[stride * i + which] = r; len[stride * i + which] = L;
         if (err) { atomicOr(ctl, err); atomicMin(ctl + 2, (uint32_t)i); }
         atomicMax(ctl + 1, L);
     }
@@ -150,6 +152,8 @@ __device__ __forceinline__ uint32_t aligned_base(const uint8_t *sq, uint32_t L, 
     return c < 4 ? 3u - c : c;
 }
 
+template <bool WRITE> __device__ void sam_tags(Emit<WRITE> &o, const SamDev &d, const salt_result_t *q, const uint8_t *sq, uint32_t L, uint32_t strand, bool md);
+
 template <bool WRITE>
 __device__ uint32_t sam_record(const SamDev &d, uint32_t i, char *dst)
 {
@@ -177,7 +181,16 @@ __device__ uint32_t sam_record(const SamDev &d, uint32_t i, char *dst)
     o.put('\t');
     if (strand) for (uint32_t j = L; j > 0; --j) o.put((char)qual[j - 1]);
     else o.putn(qual, L);
-    {   // XA (sam.c:186-240)
+    sam_tags<WRITE>(o, d, q, sq, L, strand, d.nm_md != 0);
+    return o.n;
+}
+
+// XA and MD / NM / XV of one record, shared by both record kinds (sam_add_xa sam.c:186-240, sam_add_md_nm sam.c:246-328)
+template <bool WRITE>
+__device__ void sam_tags(Emit<WRITE> &o, const SamDev &d, const salt_result_t *q, const uint8_t *sq, uint32_t L, uint32_t strand, bool md)
+{
+    const char *NT = "ACGTN";
+    {
         bool first = true; int h = 0;
         for (int s = 0; s < 2; ++s)
             for (int k = 0; k < q->n_hits[s]; ++k, ++h) {
@@ -195,7 +208,7 @@ __device__ uint32_t sam_record(const SamDev &d, uint32_t i, char *dst)
                 o.putu(hit.n_diff); o.put(';');
             }
     }
-    if (d.nm_md) {                                                    // MD / NM / XV against the 2-bit genome (sam.c:246-328)
+    if (md) {
         int nm = 0, n_match = 0, n_rs = 0;
         uint32_t rp = q->pos; int si = q->seq_start;
         o.puts("\tMD:Z:");
@@ -237,19 +250,74 @@ __device__ uint32_t sam_record(const SamDev &d, uint32_t i, char *dst)
         }
     }
     if (d.rg_len) { o.puts("\tRG:Z:"); o.putn(reinterpret_cast<const uint8_t *>(d.rg), (uint32_t)d.rg_len); }
+}
+
+// one record of a pair (alnpe_sam, sam.c:331-457): record i = mate i & 1 of pair i >> 1; the caller adds the reference's two newlines
+template <bool WRITE>
+__device__ uint32_t sam_record_pe(const SamDev &d, uint32_t i, char *dst)
+{
+    Emit<WRITE> o{ dst, 0 };
+    const uint32_t me = i, ot = i ^ 1u, m0 = i & ~1u;
+    const salt_result_t *q = d.res + me, *qo = d.res + ot, *q0 = d.res + m0, *q1 = q0 + 1;
+    const FqRec r = d.rec[me];
+    const uint8_t *name = d.raw + r.name_off, *qual = d.raw + r.qual_off, *sq = d.seqs + d.offs[me];
+    const uint32_t L = r.len;
+    const char *NT = "ACGTN";
+    const bool map_me = q->pos != 0xFFFFFFFFu, map_ot = qo->pos != 0xFFFFFFFFu;
+    int rid_me = -1, rid_ot = -1; uint32_t pos_me = 0, pos_ot = 0;
+    if (map_me) { rid_me = seq_id_dev(d, q->pos); pos_me = q->pos - (uint32_t)d.c_off[rid_me] + 1; }
+    if (map_ot) { rid_ot = seq_id_dev(d, qo->pos); pos_ot = qo->pos - (uint32_t)d.c_off[rid_ot] + 1; }
+    int tlen = 0;
+    if (map_me && map_ot) {                                           // computed on (mate 0, mate 1) whichever record this is
+        const uint32_t p0 = (i & 1u) ? pos_ot : pos_me, p1 = (i & 1u) ? pos_me : pos_ot;
+        if (rid_me != rid_ot) tlen = 0;
+        else if (p0 < p1) tlen = (int)(p1 + q1->seq_end - q1->seq_start + 1 - p0);
+        else tlen = (int)(p0 + q0->seq_end - q1->seq_start + 1 - p1);                        // sam.c:355-356: q[1].seq_start in both arms
+        if ((uint32_t)tlen > d.max_tlen || (uint32_t)tlen < d.min_tlen) tlen = 0;
+    }
+    uint32_t flag = 0x1;
+    if (!map_me) flag |= 0x4;
+    if (!map_ot) flag |= 0x8;
+    if (q->strand == 1) flag |= 0x10;
+    if (qo->strand == 1) flag |= 0x20;
+    if (tlen != 0) flag |= 0x2;
+    flag |= (i & 1u) ? 0x80 : 0x40;
+    o.putn(name, r.name_len); o.put('\t'); o.putu(flag); o.put('\t');
+    auto contig = [&](int rid) { o.putn(reinterpret_cast<const uint8_t *>(d.c_names) + d.c_name_off[rid], d.c_name_off[rid + 1] - d.c_name_off[rid]); };
+    if (map_me) {
+        contig(rid_me); o.put('\t'); o.putu(pos_me); o.put('\t'); o.putu(q->mapq); o.put('\t');
+        if (q->seq_start != 0) { o.putu(q->seq_start); o.put('S'); }
+        put_cigar_dev(o, q->cigar, q->n_cigar);
+        if (q->seq_end != L - 1) { o.putu((uint64_t)(L - q->seq_end - 1)); o.put('S'); }
+        o.put('\t');
+    } else if (map_ot) { contig(rid_ot); o.put('\t'); o.putu(pos_ot); o.puts("\t255\t*\t"); }
+    else o.puts("*\t0\t255\t*\t");
+    if (map_ot) {
+        if (rid_me == rid_ot || !map_me) o.puts("=\t"); else { contig(rid_ot); o.put('\t'); }
+        o.putu(pos_ot); o.put('\t');
+    } else o.puts("*\t0\t");
+    if (tlen != 0) { if (q->pos >= qo->pos) o.put('-'); o.putu((uint64_t)tlen); o.put('\t'); }
+    else o.puts("0\t");
+    const uint32_t strand = q->strand == 1 ? 1u : 0u;
+    for (uint32_t j = 0; j < L; ++j) { const uint32_t c = aligned_base(sq, L, strand, j); o.put(NT[c > 4 ? 4 : c]); }
+    o.put('\t');
+    if (strand) for (uint32_t j = L; j > 0; --j) o.put((char)qual[j - 1]);
+    else o.putn(qual, L);
+    sam_tags<WRITE>(o, d, q, sq, L, strand, d.nm_md && map_me);
     return o.n;
 }
 
 __global__ void __launch_bounds__(256) k_sam_len(SamDev d, uint32_t n, uint32_t *__restrict__ len)
 {
-    TSTRIDE(i, n) len[i] = sam_record<false>(d, (uint32_t)i, nullptr) + 1u;        // + the newline
+    if (d.pe) { TSTRIDE(i, n) len[i] = sam_record_pe<false>(d, (uint32_t)i, nullptr) + 2u; }       // + the record's newline and the driver's (alnpe.c:640-648)
+    else { TSTRIDE(i, n) len[i] = sam_record<false>(d, (uint32_t)i, nullptr) + 1u; }               // + the newline
 }
 __global__ void __launch_bounds__(256) k_sam_write(SamDev d, uint32_t n, const uint32_t *__restrict__ off, char *__restrict__ out)
 {
     TSTRIDE(i, n) {
         char *dst = out + off[i];
-        const uint32_t w = sam_record<true>(d, (uint32_t)i, dst);
-        dst[w] = '\n';
+        if (d.pe) { const uint32_t w = sam_record_pe<true>(d, (uint32_t)i, dst); dst[w] = '\n'; dst[w + 1] = '\n'; }
+        else { const uint32_t w = sam_record<true>(d, (uint32_t)i, dst); dst[w] = '\n'; }
     }
 }
 
@@ -294,8 +362,18 @@ hipError_t launch_fq_parse(const uint8_t *raw, const uint32_t *line_start, uint3
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(offs + n_rec, 0, 4, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_fq_parse, dim3(tgrid(n_rec)), dim3(256), 0, st, raw, line_start, n_rec, rec, offs, ctl);
+    hipLaunchKernelGGL(k_fq_parse, dim3(tgrid(n_rec)), dim3(256), 0, st, raw, line_start, n_rec, rec, offs, ctl, 0u, 1u, 0u);
     return rocprim::exclusive_scan(tmp, tmp_bytes, offs, offs, 0u, (size_t)n_rec + 1, rocprim::plus<uint32_t>(), st);
+}
+hipError_t launch_fq_parse_mate(const uint8_t *raw, uint32_t base, const uint32_t *line_start, uint32_t n_rec, uint32_t which, FqRec *rec, uint32_t *len,
+                                uint32_t *ctl, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fq_parse, dim3(tgrid(n_rec)), dim3(256), 0, st, raw + base, line_start, n_rec, rec, len, ctl, base, 2u, which);
+    return hipGetLastError();
+}
+hipError_t launch_text_scan(uint32_t *v, uint32_t n_plus_1, void *tmp, size_t tmp_bytes, hipStream_t st)
+{
+    return rocprim::exclusive_scan(tmp, tmp_bytes, v, v, 0u, (size_t)n_plus_1, rocprim::plus<uint32_t>(), st);
 }
 hipError_t launch_fq_codes(const uint8_t *raw, const FqRec *rec, const uint32_t *offs, uint32_t n_rec, uint8_t *seqs, hipStream_t st)
 {

@@ -376,11 +376,13 @@ struct TextPlan {
     // page-locked buffers, allocated by a thread of their own while the index is loaded and attached
     std::vector<char *> in_buf, sam_buf;
     std::thread alloc; bool alloc_ok = true; double alloc_s = 0;
+    bool pe = false; uint64_t pairs_per_chunk = 0;          // paired end: chunks are cut by record count (both files the same), about `chunk` bytes per file
     ~TextPlan();
 };
 
-static void text_plan(TextPlan &P, const char *fn_reads, int n_gpus, int n_threads)
+static void text_plan(TextPlan &P, const char *fn_reads, int n_gpus, int n_threads, bool pe)
 {
+    P.pe = pe;
     { const char *e = getenv("SALT_CHUNK_MB"); int mb = e ? atoi(e) : 32; if (mb < 1) mb = 1; if (mb > 1024) mb = 1024; P.chunk = (uint64_t)mb << 20; }
     if (const char *e = getenv("SALT_CHUNK_BYTES")) { long v = atol(e); if (v >= 256) P.chunk = (uint64_t)v; }      // tests: many chunks on a small file
     // workers per GPU: each preads a chunk, calls the device and writes its block in turn.  The write stream is the narrow part (one
@@ -414,6 +416,14 @@ static void text_plan(TextPlan &P, const char *fn_reads, int n_gpus, int n_threa
     if (P.head_read_len > SALT_MAX_READ_LEN) P.head_read_len = 0;      // the call itself reports it
     P.in_cap = P.chunk + 2 * TEXT_SLACK + 64;
     P.sam_cap = (uint64_t)((double)(P.chunk + TEXT_SLACK) * sam_per_fq_byte) + 4096;
+    if (pe) {                                                // a chunk = pairs_per_chunk records of EACH file; both blocks share the input buffer
+        const double rec_bytes = lines >= 4 && last_rec_end ? (double)last_rec_end / (double)(lines / 4) : 250.0;
+        P.pairs_per_chunk = (uint64_t)((double)P.chunk / rec_bytes) + 1;
+        P.max_reads = (uint32_t)(2 * P.pairs_per_chunk);
+        P.worst_reads = P.max_reads;                         // exact: the record count is what defines a chunk
+        P.in_cap = 2 * (uint64_t)((double)P.chunk * 1.5) + 2 * TEXT_SLACK + 64;
+        P.sam_cap = 2 * (uint64_t)((double)P.chunk * (sam_per_fq_byte + 0.3)) + 4096;
+    }
     P.in_buf.assign((size_t)P.n_workers, nullptr); P.sam_buf.assign((size_t)P.n_workers, nullptr);
     P.alloc = std::thread([&P]() {
         const double t = now();
@@ -540,6 +550,158 @@ static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector
     return R.failed ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Paired end, two plain 4-line FASTQ files: the same path with chunks cut by RECORD COUNT.  One scanner thread per file counts newlines
+// (8 bytes per step) and publishes the byte offset of every pairs_per_chunk-th record; a worker takes chunk k of both files as soon
+// as both offsets are there, calls salt_gpu_align_pe_text and writes its block in turn.
+// ---------------------------------------------------------------------------------------------
+struct PeScan {
+    std::mutex mu; std::condition_variable cv;
+    std::vector<uint64_t> off[2];                           // off[f][k] = start of chunk k in file f; the last entry of a finished file = its size
+    bool done[2] = { false, false }; uint64_t records[2] = { 0, 0 };
+    bool bad = false;
+};
+
+static inline uint64_t count_nl8(uint64_t w)               // newlines among the 8 bytes of w
+{
+    const uint64_t x = w ^ 0x0A0A0A0A0A0A0A0Aull, m = 0x7F7F7F7F7F7F7F7Full;
+    const uint64_t y = ~(((x & m) + m) | x | m);            // bit 7 of every byte that is zero in x
+    return (uint64_t)__builtin_popcountll(y);
+}
+
+static void pe_scan_file(const char *fn, int f, uint64_t pairs_per_chunk, PeScan &S, std::atomic<bool> &failed)
+{
+    const int fd = open(fn, O_RDONLY);
+    const uint64_t lines_per_chunk = 4 * pairs_per_chunk;
+    auto publish = [&](uint64_t o) { { std::lock_guard<std::mutex> lk(S.mu); S.off[f].push_back(o); } S.cv.notify_all(); };
+    if (fd < 0) { { std::lock_guard<std::mutex> lk(S.mu); S.bad = true; S.done[f] = true; } S.cv.notify_all(); return; }
+    publish(0);
+    std::vector<char> buf((size_t)4 << 20);
+    uint64_t pos = 0, lines = 0, next = lines_per_chunk;    // lines seen so far; the line count at which the next chunk starts
+    char last = '\n';
+    for (;;) {
+        if (failed) break;
+        const ssize_t got = pread(fd, buf.data(), buf.size(), (off_t)pos);
+        if (got <= 0) break;
+        last = buf[(size_t)got - 1];
+        size_t i = 0;
+        while (i < (size_t)got) {
+            // whole 4 KiB pieces that cannot reach the next boundary are counted 8 bytes at a time
+            const size_t piece = std::min<size_t>(4096, (size_t)got - i);
+            uint64_t c = 0; size_t j = 0;
+            for (; j + 8 <= piece; j += 8) { uint64_t w; memcpy(&w, buf.data() + i + j, 8); c += count_nl8(w); }
+            for (; j < piece; ++j) c += buf[i + j] == '\n';
+            if (lines + c < next) { lines += c; i += piece; continue; }
+            for (j = 0; j < piece; ++j)                      // the boundary lies in this piece: byte by byte
+                if (buf[i + j] == '\n' && ++lines == next) { publish(pos + i + j + 1); next += lines_per_chunk; }
+            i += piece;
+        }
+        pos += (uint64_t)got;
+    }
+    close(fd);
+    if (last != '\n') ++lines;                              // a last line without its newline
+    {
+        std::lock_guard<std::mutex> lk(S.mu);
+        if (S.off[f].back() != pos) S.off[f].push_back(pos);
+        S.records[f] = lines / 4; S.done[f] = true;
+        if (lines % 4) S.bad = true;
+    }
+    S.cv.notify_all();
+}
+
+static int run_pe_text(const char *fn1, const char *fn2, salt_index_t *ix, const std::vector<salt_gpu_index_t *> &gix, int n_gpus, TextPlan &P,
+                       const salt_aln_opt_t &ao, const salt_sam_opt_t &so, const salt_pe_opt_t &po, double t0)
+{
+    const int fd[2] = { open(fn1, O_RDONLY), open(fn2, O_RDONLY) };
+    if (fd[0] < 0 || fd[1] < 0) { fprintf(stderr, "[query_open]: file %s open fail!\n", fd[0] < 0 ? fn1 : fn2); return 1; }
+    fflush(stdout);
+    {
+        const int n = salt_index_n_seqs(ix);
+        std::vector<int64_t> off((size_t)n); std::vector<const char *> nm((size_t)n);
+        for (int i = 0; i < n; ++i) salt_index_seq(ix, i, &off[(size_t)i], nullptr, &nm[(size_t)i]);
+        for (int g = 0; g < n_gpus; ++g)
+            if (salt_gpu_index_set_contigs(gix[(size_t)g], n, off.data(), nm.data())) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
+    }
+    if (P.alloc.joinable()) P.alloc.join();
+    if (!P.alloc_ok) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
+    const salt_text_opt_t to = { so.print_xa_cigar, so.print_nm_md, so.rg_id };
+    PeScan S;
+    std::atomic<bool> failed{ false };
+    std::mutex wmu; std::condition_variable wcv; uint64_t written = 0; long pairs_done = 0;
+    std::atomic<uint64_t> next_chunk{ 0 };
+    std::atomic<double> t_read{ 0 }, t_gpu{ 0 }, t_write{ 0 }, t_last{ t0 };
+    auto set_failed = [&]() { failed = true; { std::lock_guard<std::mutex> lk(wmu); } wcv.notify_all(); { std::lock_guard<std::mutex> lk(S.mu); } S.cv.notify_all(); };
+    std::thread scan1(pe_scan_file, fn1, 0, P.pairs_per_chunk, std::ref(S), std::ref(failed)), scan2(pe_scan_file, fn2, 1, P.pairs_per_chunk, std::ref(S), std::ref(failed));
+    std::vector<std::thread> workers;
+    for (int wk = 0; wk < P.n_workers; ++wk)
+        workers.emplace_back([&, wk]() {
+            salt_gpu_ws_t *ws = nullptr; char *buf = P.in_buf[(size_t)wk];
+            if (salt_gpu_ws_create(gix[(size_t)(wk / P.wpg)], P.max_reads + 64, (uint64_t)(P.max_reads + 64) * 160, &ws)) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); set_failed(); return; }
+            for (;;) {
+                const uint64_t k = next_chunk.fetch_add(1);
+                uint64_t lo[2], hi[2]; bool end = false;
+                {   // chunk k of both files: its start and end offsets (or the news that there is no chunk k)
+                    std::unique_lock<std::mutex> lk(S.mu);
+                    S.cv.wait(lk, [&] { return failed.load() || ((S.off[0].size() > k + 1 || S.done[0]) && (S.off[1].size() > k + 1 || S.done[1])); });
+                    if (failed) break;
+                    if (S.bad) { end = true; }
+                    else if (S.off[0].size() <= k + 1 || S.off[1].size() <= k + 1) {
+                        // one file has no chunk k: fine if neither has (both finished with the same number of chunks), else the files differ
+                        end = true;
+                        if ((S.off[0].size() > k + 1) != (S.off[1].size() > k + 1)) S.bad = true;
+                    } else for (int f = 0; f < 2; ++f) { lo[f] = S.off[f][k]; hi[f] = S.off[f][k + 1]; }
+                }
+                if (end) break;
+                const uint64_t n1 = hi[0] - lo[0], n2 = hi[1] - lo[1], b2 = (n1 + 64) & ~63ull;
+                if (b2 + n2 + 2 > P.in_cap) { fprintf(stderr, "[salt] a chunk of %llu pairs is larger than its buffer (records much longer than the file's first ones)\n", (unsigned long long)P.pairs_per_chunk); set_failed(); break; }
+                double tr0 = now();
+                bool ok = true;
+                for (int f = 0; f < 2 && ok; ++f) {
+                    char *dst = buf + (f ? b2 : 0); const uint64_t want = f ? n2 : n1; uint64_t got = 0;
+                    while (got < want) { const ssize_t r = pread(fd[f], dst + got, want - got, (off_t)(lo[f] + got)); if (r <= 0) break; got += (uint64_t)r; }
+                    ok = got == want;
+                }
+                if (!ok) { fprintf(stderr, "[salt] short read on the FASTQ files\n"); set_failed(); break; }
+                uint64_t m1 = n1, m2 = n2;
+                if (m1 && buf[m1 - 1] != '\n') buf[m1++] = '\n';                              // a last record without its newline
+                if (m2 && buf[b2 + m2 - 1] != '\n') buf[b2 + m2++] = '\n';
+                t_read = t_read + (now() - tr0);
+                const char *sam = nullptr; uint64_t sam_bytes = 0; uint32_t n_pairs = 0;
+                double tg0 = now();
+                if (salt_gpu_align_pe_text(ws, &ao, &po, &to, buf, m1, buf + b2, m2, &sam, &sam_bytes, &n_pairs)) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); set_failed(); break; }
+                t_gpu = t_gpu + (now() - tg0);
+                {
+                    std::unique_lock<std::mutex> lk(wmu);
+                    wcv.wait(lk, [&] { return failed.load() || written == k; });
+                    if (failed) break;
+                }
+                double tw0 = now();
+                for (uint64_t w = 0; w < sam_bytes && ok; ) { const ssize_t r = write(1, sam + w, sam_bytes - w); if (r <= 0) ok = false; else w += (uint64_t)r; }
+                t_write = t_write + (now() - tw0);
+                { const double tn = now(); double cur = t_last.load(); while (tn > cur && !t_last.compare_exchange_weak(cur, tn)) {} }
+                if (!ok) { fprintf(stderr, "[salt] write error on the SAM stream\n"); set_failed(); break; }
+                { std::lock_guard<std::mutex> lk(wmu); written = k + 1; pairs_done += n_pairs; fprintf(stderr, "%ld reads have been aligned!\n", 2 * pairs_done); }
+                wcv.notify_all();
+            }
+            salt_gpu_ws_destroy(ws);
+        });
+    for (auto &w : workers) w.join();
+    failed = failed.load();
+    { std::lock_guard<std::mutex> lk(S.mu); } S.cv.notify_all();
+    scan1.join(); scan2.join();
+    close(fd[0]); close(fd[1]);
+    if (!failed && (S.bad || S.records[0] != S.records[1])) {
+        fprintf(stderr, "[salt] the two read files hold different numbers of reads (%llu / %llu) or broken records\n", (unsigned long long)S.records[0], (unsigned long long)S.records[1]);
+        return 1;
+    }
+    const double dt = t_last.load() - t0;
+    fprintf(stderr, "[alnpe_core]: total %lf sec escaped\n", dt);
+    fprintf(stderr, "[salt] text path (paired end): %d worker(s), %llu pairs per chunk, blocks written in turn; seconds summed over workers: read %.3f device call %.3f write %.3f "
+                    "(page-locked buffers: %.3f s, while the index was loading)\n", P.n_workers, (unsigned long long)P.pairs_per_chunk, t_read.load(), t_gpu.load(), t_write.load(), P.alloc_s);
+    fprintf(stderr, "[salt] %ld pairs, %.3f M mates/s end to end (FASTQ -> SAM, %d GPU(s))\n", pairs_done, dt > 0 ? 2.0 * pairs_done / dt / 1e6 : 0.0, n_gpus);
+    return failed ? 1 : 0;
+}
+
 } // namespace
 
 int main(int argc, char **argv)
@@ -586,12 +748,15 @@ int main(int argc, char **argv)
     // SALT_HOST_PIPELINE=1 forces the latter.  Decided before the index is loaded: the text path's page-locked buffers are allocated
     // by a thread of their own meanwhile.
     TextPlan plan; bool text_path = false;
-    if (!pe && !(getenv("SALT_HOST_PIPELINE") && atoi(getenv("SALT_HOST_PIPELINE")))) {
-        struct stat sb; unsigned char magic[2] = { 0, 0 };
-        bool plain = stat(fn_reads, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0;
-        if (plain) { FILE *f = fopen(fn_reads, "rb"); plain = f && fread(magic, 1, 2, f) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b); if (f) fclose(f); }
-        text_path = plain && sniff_four_line(fn_reads);
-        if (text_path) text_plan(plan, fn_reads, n_gpus, n_threads);
+    if (!(getenv("SALT_HOST_PIPELINE") && atoi(getenv("SALT_HOST_PIPELINE")))) {
+        auto plain4 = [](const char *fn) {
+            struct stat sb; unsigned char magic[2] = { 0, 0 };
+            bool plain = stat(fn, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0;
+            if (plain) { FILE *f = fopen(fn, "rb"); plain = f && fread(magic, 1, 2, f) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b); if (f) fclose(f); }
+            return plain && sniff_four_line(fn);
+        };
+        text_path = plain4(fn_reads) && (!pe || plain4(fn_mates));
+        if (text_path) text_plan(plan, fn_reads, n_gpus, n_threads, pe != 0);
     }
     double t0 = now();
     fprintf(stderr, "[alnse_core]:  Reload index...\n");
@@ -618,7 +783,7 @@ int main(int argc, char **argv)
         printf("@PG\tID:snpaln\tPN:snpaln\tCL:\"%s\"\tDS:%d-%d-%d\tVN:0.1beta\n", cmd.c_str(), tmv->tm_year + 1900, tmv->tm_mon + 1, tmv->tm_mday);
         return true;
     };
-    if (text_path) {
+    if (text_path && !pe) {
         fprintf(stderr, "%lf sec escaped.\n", now() - t0);
         if (!print_header()) return 1;
         const int rc = run_se_text(fn_reads, ix, gix, n_gpus, plan, ao, so, now());
@@ -654,6 +819,14 @@ int main(int argc, char **argv)
             return 1;
         }
         fprintf(stderr, "[alnpe_core]: insert size window [%u, %u] inferred from %u pairs\n", po.min_tlen, po.max_tlen, used);
+    }
+    if (text_path && pe) {
+        fprintf(stderr, "%lf sec escaped.\n", now() - t0);
+        if (!print_header()) return 1;
+        const int rc = run_pe_text(fn_reads, fn_mates, ix, gix, n_gpus, plan, ao, so, po, now());
+        for (int i = n_gpus - 1; i >= 0; --i) salt_gpu_index_detach(gix[(size_t)i]);
+        salt_index_free(ix);
+        return rc;
     }
     // workers per GPU: each takes a batch through parse -> device -> format, so several batches overlap on the host
     const int WPG = n_threads / n_gpus >= 32 ? 4 : n_threads / n_gpus >= 12 ? 3 : 2;

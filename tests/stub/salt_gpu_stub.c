@@ -52,6 +52,10 @@ int salt_gpu_align_se(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint32_t n, co
 int salt_gpu_align_pe(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_pe_opt_t *pe, uint32_t n, const uint8_t *s, const uint32_t *f, salt_result_t *r)
 { (void)ws; (void)o; (void)pe; (void)n; (void)s; (void)f; (void)r; return fail("salt_gpu_align_pe is not part of the stub"); }
 
+int salt_gpu_align_pe_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_pe_opt_t *pe, const salt_text_opt_t *to, const char *f1, uint64_t n1,
+                           const char *f2, uint64_t n2, const char **sam, uint64_t *sam_bytes, uint32_t *n_pairs)
+{ (void)ws; (void)o; (void)pe; (void)to; (void)f1; (void)n1; (void)f2; (void)n2; (void)sam; (void)sam_bytes; (void)n_pairs; return fail("salt_gpu_align_pe_text is not part of the stub"); }
+
 static uint8_t nt4(int c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
 
 int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_text_opt_t *to, const char *fq, uint64_t n_bytes,

@@ -256,3 +256,27 @@ def test_cli_pe_infers_the_insert_window_like_the_oracle(tmp_path):
         few.append(str(p))
     bad = subprocess.run([salt, "-p", "-b", "0", prefix] + few, capture_output=True)
     assert bad.returncode == 1 and b"cannot infer the insert size" in bad.stderr
+
+
+def test_cli_pe_text_path_and_host_pipeline_give_the_reference_sam(tmp_path):
+    """`salt -p` through the text path (both FASTQ files parsed and the pairs' SAM formatted by kernels; chunks of ~13 pairs here, so
+    hundreds of them, cut by record count by the two scanner threads) and through the host pipeline: the reference's SAM both ways.
+    Files with different numbers of reads end with an error, not with output."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt, salt_idx = os.path.join(root, "salt_amd", "bin", "salt"), os.path.join(root, "salt_amd", "bin", "salt-idx")
+    prefix = str(tmp_path / "idx")
+    subprocess.run([salt_idx, "-k", "19", os.path.join(LAMBDA, "genome.fa"), os.path.join(LAMBDA, "snps.txt"), prefix], check=True, stderr=subprocess.DEVNULL)
+    files = [os.path.join(LAMBDA, "reads_pe_1.fq"), os.path.join(LAMBDA, "reads_pe_2.fq")]
+    strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    for case in ("pe_default", "pe_r5"):
+        want = open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
+        for env in (dict(os.environ, SALT_CHUNK_BYTES="4000"), dict(os.environ, SALT_CHUNK_BYTES="250000"), dict(os.environ, SALT_HOST_PIPELINE="1")):
+            out = subprocess.run([salt] + read_cases()[case] + ["-t", "8", prefix] + files, capture_output=True, env=env)
+            assert out.returncode == 0, out.stderr[-400:]
+            assert strip(out.stdout) == want, (case, env.get("SALT_CHUNK_BYTES"), _diff_report(strip(out.stdout), want))
+            assert (b"text path (paired end)" in out.stderr) == ("SALT_HOST_PIPELINE" not in env)
+    short = tmp_path / "short_2.fq"
+    short.write_bytes(b"".join(open(files[1], "rb").readlines()[:-8]))
+    bad = subprocess.run([salt, "-p", prefix, files[0], str(short)], capture_output=True, env=dict(os.environ, SALT_CHUNK_BYTES="4000"))
+    assert bad.returncode == 1 and b"different numbers of reads" in bad.stderr, bad.stderr[-300:]
