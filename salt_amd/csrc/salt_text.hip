@@ -312,12 +312,26 @@ __global__ void __launch_bounds__(256) k_sam_len(SamDev d, uint32_t n, uint32_t 
     if (d.pe) { TSTRIDE(i, n) len[i] = sam_record_pe<false>(d, (uint32_t)i, nullptr) + 2u; }       // + the record's newline and the driver's (alnpe.c:640-648)
     else { TSTRIDE(i, n) len[i] = sam_record<false>(d, (uint32_t)i, nullptr) + 1u; }               // + the newline
 }
-__global__ void __launch_bounds__(256) k_sam_write(SamDev d, uint32_t n, const uint32_t *__restrict__ off, char *__restrict__ out)
+// One wave per 64 consecutive records.  A thread that formats its record straight into the output writes single bytes at its own
+// address: 64 different cache lines per store instruction.  The records of a wave are contiguous in the output (off[] is a scan), so
+// the threads format into an LDS image of that span and the wave then copies the span out with whole-line stores (PE, per 10^6
+// mates: 13 ms -> see DESIGN 4.3).  A span that does not fit the image (very long reads) is written the direct way.
+static constexpr uint32_t SAM_STAGE = 48u << 10;
+__global__ void __launch_bounds__(64) k_sam_write(SamDev d, uint32_t n, const uint32_t *__restrict__ off, char *__restrict__ out)
 {
-    TSTRIDE(i, n) {
-        char *dst = out + off[i];
-        if (d.pe) { const uint32_t w = sam_record_pe<true>(d, (uint32_t)i, dst); dst[w] = '\n'; dst[w + 1] = '\n'; }
-        else { const uint32_t w = sam_record<true>(d, (uint32_t)i, dst); dst[w] = '\n'; }
+    __shared__ char stage[SAM_STAGE];
+    for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n; base += (uint64_t)gridDim.x * 64) {
+        const uint32_t i = (uint32_t)base + threadIdx.x, last = (uint32_t)(base + 64 < n ? base + 64 : n);
+        const uint32_t o0 = off[base], span = off[last] - o0;
+        const bool staged = span <= SAM_STAGE;
+        if (i < n) {
+            char *dst = staged ? stage + (off[i] - o0) : out + off[i];
+            if (d.pe) { const uint32_t w = sam_record_pe<true>(d, i, dst); dst[w] = '\n'; dst[w + 1] = '\n'; }
+            else { const uint32_t w = sam_record<true>(d, i, dst); dst[w] = '\n'; }
+        }
+        __syncthreads();
+        if (staged) for (uint32_t k = threadIdx.x; k < span; k += 64) out[o0 + k] = stage[k];
+        __syncthreads();
     }
 }
 
@@ -389,7 +403,8 @@ hipError_t launch_sam_len(const SamDev &d, uint32_t n, uint32_t *off, void *tmp,
 }
 hipError_t launch_sam_write(const SamDev &d, uint32_t n, const uint32_t *off, char *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_sam_write, dim3(tgrid(n)), dim3(256), 0, st, d, n, off, out);
+    const uint64_t waves = ((uint64_t)n + 63) / 64;
+    hipLaunchKernelGGL(k_sam_write, dim3((uint32_t)(waves < 8192 ? waves : 8192)), dim3(64), 0, st, d, n, off, out);
     return hipGetLastError();
 }
 
