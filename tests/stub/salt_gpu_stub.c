@@ -52,10 +52,6 @@ int salt_gpu_align_se(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint32_t n, co
 int salt_gpu_align_pe(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_pe_opt_t *pe, uint32_t n, const uint8_t *s, const uint32_t *f, salt_result_t *r)
 { (void)ws; (void)o; (void)pe; (void)n; (void)s; (void)f; (void)r; return fail("salt_gpu_align_pe is not part of the stub"); }
 
-int salt_gpu_align_pe_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_pe_opt_t *pe, const salt_text_opt_t *to, const char *f1, uint64_t n1,
-                           const char *f2, uint64_t n2, const char **sam, uint64_t *sam_bytes, uint32_t *n_pairs)
-{ (void)ws; (void)o; (void)pe; (void)to; (void)f1; (void)n1; (void)f2; (void)n2; (void)sam; (void)sam_bytes; (void)n_pairs; return fail("salt_gpu_align_pe_text is not part of the stub"); }
-
 static uint8_t nt4(int c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
 
 int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_text_opt_t *to, const char *fq, uint64_t n_bytes,
@@ -93,5 +89,55 @@ int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const sal
     const char *log = getenv("SALT_STUB_LOG");
     if (log) { pthread_mutex_lock(&g_mu); FILE *f = fopen(log, "a"); if (f) { fprintf(f, "%d %u\n", ws->ix->device, n); fclose(f); } pthread_mutex_unlock(&g_mu); }
     *sam = ws->sam; *sam_bytes = used; *n_reads = n;
+    return SALT_OK;
+}
+
+/* one 4-line record at *p of fq[0..n): name (trimmed like query.c:139-143), codes, qualities; advances *p; 0 = ok */
+static int stub_record(const char *fq, uint64_t n, uint64_t *p, char *name, size_t name_cap, uint8_t *seq, char *qual, size_t cap, int *L_out)
+{
+    const char *l[5]; l[0] = fq + *p;
+    for (int k = 1; k <= 4; ++k) { const char *nl = memchr(l[k - 1], '\n', (size_t)(fq + n - l[k - 1])); if (!nl) return -1; l[k] = nl + 1; }
+    if (l[0][0] != '@' || l[2][0] != '+') return -2;
+    size_t nl_ = 0;
+    for (const char *c = l[0] + 1; c < l[1] - 1 && *c != ' ' && !(*c >= 9 && *c <= 13) && nl_ < name_cap - 1; ++c) name[nl_++] = *c;
+    if (nl_ > 2 && name[nl_ - 2] == '/' && name[nl_ - 1] >= '0' && name[nl_ - 1] <= '9') nl_ -= 2;
+    name[nl_] = 0;
+    size_t L = (size_t)(l[2] - 1 - l[1]); while (L && l[1][L - 1] == '\r') --L;
+    if (L == 0 || L >= cap) return -3;
+    for (size_t i = 0; i < L; ++i) { seq[i] = nt4((unsigned char)l[1][i]); qual[i] = l[3][i]; }
+    qual[L] = 0;
+    *L_out = (int)L; *p = (uint64_t)(l[4] - fq);
+    return 0;
+}
+
+int salt_gpu_align_pe_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_pe_opt_t *pe, const salt_text_opt_t *to, const char *f1, uint64_t n1,
+                           const char *f2, uint64_t n2, const char **sam, uint64_t *sam_bytes, uint32_t *n_pairs)
+{
+    *sam = NULL; *sam_bytes = 0; *n_pairs = 0;
+    if (getenv("SALT_STUB_NO_PE")) return fail("salt_gpu_align_pe_text is not part of the stub");
+    if (n1 == 0 && n2 == 0) return SALT_OK;
+    if (n1 == 0 || n2 == 0 || f1[n1 - 1] != '\n' || f2[n2 - 1] != '\n') return fail("blocks must hold the same number of whole records");
+    so_opt_t so; so_opt_default(ws->ix->ora, &so);
+    so.l_overlap = o->l_overlap; so.max_seed = o->max_seed; so.max_locate = o->max_locate; so.seed_only_ref = o->seed_only_ref;
+    so.print_xa_cigar = to->print_xa_cigar; so.print_nm_md = to->print_nm_md; so.rg_id = to->rg_id;
+    size_t used = 0; uint32_t n = 0;
+    uint64_t p1 = 0, p2 = 0;
+    while (p1 < n1 && p2 < n2) {
+        char nm0[512], nm1[512], q0[4097], q1[4097]; uint8_t s0[4096], s1[4096]; int l0 = 0, l1 = 0;
+        if (stub_record(f1, n1, &p1, nm0, sizeof nm0, s0, q0, sizeof s0, &l0) || stub_record(f2, n2, &p2, nm1, sizeof nm1, s1, q1, sizeof s1, &l1)) return fail("not whole 4-line FASTQ records");
+        so_result_t res[2];
+        so_align_pe1(ws->ix->ora, &so, pe->min_tlen, pe->max_tlen, s0, l0, s1, l1, res);
+        const size_t need = 16 * (size_t)(l0 + l1) + 16384;
+        if (used + need > ws->cap) { ws->cap = (used + need) * 2; ws->sam = realloc(ws->sam, ws->cap); }
+        const char *nm[2] = { nm0, nm1 }, *ql[2] = { q0, q1 }; const uint8_t *sq[2] = { s0, s1 }; const int ls[2] = { l0, l1 };
+        int w = so_sam_pe(ws->ix->ora, &so, pe->min_tlen, pe->max_tlen, nm, sq, ls, ql, res, ws->sam + used, ws->cap - used);
+        if (w < 0) return fail("SAM record too long");
+        used += (size_t)w;
+        ++n;
+    }
+    if (p1 < n1 || p2 < n2) return fail("the two FASTQ blocks hold different numbers of reads");
+    const char *log = getenv("SALT_STUB_LOG");
+    if (log) { pthread_mutex_lock(&g_mu); FILE *f = fopen(log, "a"); if (f) { fprintf(f, "%d %u\n", ws->ix->device, n); fclose(f); } pthread_mutex_unlock(&g_mu); }
+    *sam = ws->sam; *sam_bytes = used; *n_pairs = n;
     return SALT_OK;
 }

@@ -50,7 +50,37 @@ def test_salt_gpus_n_deals_chunks_and_keeps_the_input_order(case, gpus, stub_tre
 def test_salt_reports_a_device_error_and_exits_nonzero(stub_tree, tmp_path):
     """Paired end goes through the host pipeline, which the stub does not serve: the device error must reach stderr and the exit code."""
     d, prefix = stub_tree
-    env = dict(os.environ, SALT_STUB_PREFIX=prefix, LD_LIBRARY_PATH=str(d / "lib"))
+    env = dict(os.environ, SALT_STUB_PREFIX=prefix, SALT_STUB_NO_PE="1", LD_LIBRARY_PATH=str(d / "lib"))
     out = subprocess.run([str(d / "bin" / "salt"), "-p", prefix, os.path.join(LAMBDA, "reads_pe_1.fq"), os.path.join(LAMBDA, "reads_pe_2.fq")],
                          capture_output=True, env=env, timeout=120)
     assert out.returncode == 1 and b"not part of the stub" in out.stderr
+
+
+@pytest.mark.parametrize("case,gpus", [("pe_default", 2), ("pe_r5", 3)])
+def test_salt_pe_text_path_cuts_both_files_by_record_count(case, gpus, stub_tree, tmp_path):
+    """The paired-end driver: two scanner threads publish the offsets of every n-th record of both files, workers of several
+    "devices" take chunk k of both, blocks come out in input order.  Chunks of a dozen pairs; mates whose records differ in length
+    between the two files (names of different lengths), so that the same chunk has different byte ranges in the two files."""
+    d, prefix = stub_tree
+    want = open(os.path.join(LAMBDA, "expect_%s.sam" % case), "rb").read()
+    strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    f1 = os.path.join(LAMBDA, "reads_pe_1.fq")
+    lines = open(os.path.join(LAMBDA, "reads_pe_2.fq"), "rb").read().split(b"\n")
+    for i in range(0, len(lines) - 3, 4):                 # a comment of growing length behind every second-mate name: same SAM, other offsets
+        lines[i] = lines[i] + b" " + b"c" * (i % 37)
+    f2 = tmp_path / "mates.fq"
+    f2.write_bytes(b"\n".join(lines))
+    log = str(tmp_path / "stub.log")
+    env = dict(os.environ, SALT_STUB_PREFIX=prefix, SALT_STUB_LOG=log, SALT_CHUNK_BYTES="3000", LD_LIBRARY_PATH=str(d / "lib"))
+    out = subprocess.run([str(d / "bin" / "salt")] + read_cases()[case] + ["-t", "16", "--gpus", str(gpus), prefix, f1, str(f2)], capture_output=True, env=env)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert b"text path (paired end)" in out.stderr
+    assert strip(out.stdout) == want
+    rows = [l.split() for l in open(log).read().splitlines()]
+    assert sum(int(r[1]) for r in rows) == 1000 and len(rows) > 20
+    assert {int(r[0]) for r in rows} == set(range(gpus))
+    # one read less in the second file: an error, no shifted pairs
+    f3 = tmp_path / "short.fq"
+    f3.write_bytes(b"\n".join(lines[:-5]) + b"\n")
+    bad = subprocess.run([str(d / "bin" / "salt")] + read_cases()[case] + [prefix, f1, str(f3)], capture_output=True, env=env)
+    assert bad.returncode == 1 and b"different numbers of reads" in bad.stderr, bad.stderr[-300:]
