@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1000000, help="reads given to the CPU baseline / parity check")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--e2e-reads", type=int, default=32000000, help="reads of the end-to-end leg (`salt` binary, FASTQ -> SAM); 0 = skip")
+    ap.add_argument("--e2e-pairs", type=int, default=4000000, help="pairs (2 x 150) of the paired-end end-to-end leg (`salt -p`); 0 = skip")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (experiments; default: the workload's own batch)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("SALT_BENCH_STREAMS", "4")),
                     help="workspaces / HIP streams per GPU the steps are dealt to round-robin (salt runs 2-4 align workers per GPU)")
@@ -333,6 +334,11 @@ def main():
                 out["e2e"] = e2e_leg(args, cfg, w, genome, site, workload, torch, np, log)
             except Exception as ex:                                    # the leg is a report, not a gate
                 out["e2e"] = {"error": str(ex)[:300]}
+        if args.e2e_pairs > 0 and args.e2e_reads > 0:
+            try:
+                out["e2e_pe"] = e2e_pe_leg(args, w, genome, site, workload, torch, np, log)
+            except Exception as ex:
+                out["e2e_pe"] = {"error": str(ex)[:300]}
         print(json.dumps(out), flush=True)
     for a in alns[1:]:
         a.close()
@@ -383,6 +389,44 @@ def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log):
                     "[alnse_core] total (restarted where the reference restarts its own, behind the index reload, alnse.c:1366; workspace set-up included; ends with the "
                     "last SAM byte written; index load + attach excluded, as SURVEY 8d defines it)" % (threads, sam_bytes / 1e9),
             "align_wall_s": align_s, "process_wall_s": round(wall, 2), "fastq_write_s": round(t_write, 2), "pipeline": detail}
+
+
+def e2e_pe_leg(args, w, genome, site, workload, torch, np, log):
+    """`salt -d -c -p -a 250 -b 550` on two FASTQ files of 2 x 150-base pairs of the same genome (BASELINE's paired-end configuration): the
+    binary's own clock as in e2e_leg."""
+    L, n, d = 150, args.e2e_pairs, w["dir"]
+    fq = [os.path.join(d, "e2e_1.fq"), os.path.join(d, "e2e_2.fq")]
+    with open(fq[0], "wb") as f1, open(fq[1], "wb") as f2:
+        done = 0
+        while done < n:
+            k = min(500000, n - done)
+            seqs, _, _, _, _ = workload.make_pairs_hash(genome, site, k, L, seed=78, batch=done // 500000)
+            r = seqs.view(k, 2, L).cpu().numpy()
+            f1.write(workload.fastq_bytes(r[:, 0, :].reshape(-1), k, L, first_id=done))
+            f2.write(workload.fastq_bytes(r[:, 1, :].reshape(-1), k, L, first_id=done))
+            done += k
+    threads = min(os.cpu_count() or 1, 64)
+    sam = os.path.join(d, "e2e_pe.sam")
+    t0 = time.time()
+    with open(sam, "wb") as fo:
+        p = subprocess.run([os.path.join(ROOT, "salt_amd", "bin", "salt"), "-d", "-c", "-p", "-a", "250", "-b", "550", "-t", str(threads), w["prefix"]] + fq,
+                           stdout=fo, stderr=subprocess.PIPE, timeout=900)
+    wall = time.time() - t0
+    err = p.stderr.decode(errors="replace")
+    if p.returncode != 0:
+        raise RuntimeError("salt -p exited %d: %s" % (p.returncode, err[-200:]))
+    align_s, detail = None, None
+    for line in err.splitlines():
+        if line.startswith("[alnpe_core]: total") or line.startswith("[alnse_core]: total"):
+            align_s = float(line.split()[2])
+        if line.startswith("[salt] text path") or line.startswith("[salt] host phases"):
+            detail = line[7:]
+    sam_bytes = os.path.getsize(sam)
+    for f in fq + [sam]:
+        os.unlink(f)
+    return {"value": round(2 * n / align_s / 1e6, 3) if align_s else None, "unit": "M mates/s", "pairs": n, "read_len": L, "threads": threads,
+            "what": "salt -d -c -p -a 250 -b 550 -t %d <idx> r1.fq r2.fq > out.sam (%.2f GB of SAM); the binary's clock as in e2e" % (threads, sam_bytes / 1e9),
+            "align_wall_s": align_s, "process_wall_s": round(wall, 2), "pipeline": detail}
 
 
 if __name__ == "__main__":

@@ -636,7 +636,10 @@ static int run_pe_text(const char *fn1, const char *fn2, salt_index_t *ix, const
     for (int wk = 0; wk < P.n_workers; ++wk)
         workers.emplace_back([&, wk]() {
             salt_gpu_ws_t *ws = nullptr; char *buf = P.in_buf[(size_t)wk];
-            if (salt_gpu_ws_create(gix[(size_t)(wk / P.wpg)], P.max_reads + 64, (uint64_t)(P.max_reads + 64) * 160, &ws)) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); set_failed(); return; }
+            if (salt_gpu_ws_create(gix[(size_t)(wk / P.wpg)], P.max_reads + 64, (uint64_t)(P.max_reads + 64) * 160, &ws) ||
+                (P.head_read_len && salt_gpu_ws_reserve_text(ws, &ao, P.in_cap, P.max_reads, P.head_read_len, P.sam_cap - 64, P.sam_buf[(size_t)wk], P.sam_cap))) {
+                fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); set_failed(); return;
+            }
             for (;;) {
                 const uint64_t k = next_chunk.fetch_add(1);
                 uint64_t lo[2], hi[2]; bool end = false;

@@ -280,3 +280,28 @@ def test_cli_pe_text_path_and_host_pipeline_give_the_reference_sam(tmp_path):
     short.write_bytes(b"".join(open(files[1], "rb").readlines()[:-8]))
     bad = subprocess.run([salt, "-p", prefix, files[0], str(short)], capture_output=True, env=dict(os.environ, SALT_CHUNK_BYTES="4000"))
     assert bad.returncode == 1 and b"different numbers of reads" in bad.stderr, bad.stderr[-300:]
+
+
+def test_cli_pe_text_path_reads_crlf_and_last_records_without_newline(tmp_path):
+    """CRLF line ends in one file, a missing final newline in the other, a quality line that starts with '@': the paired-end text path
+    (chunks cut by the scanner threads every 9 pairs) and the host pipeline print the same SAM."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt, salt_idx = os.path.join(root, "salt_amd", "bin", "salt"), os.path.join(root, "salt_amd", "bin", "salt-idx")
+    prefix = str(tmp_path / "idx")
+    subprocess.run([salt_idx, "-k", "19", os.path.join(LAMBDA, "genome.fa"), os.path.join(LAMBDA, "snps.txt"), prefix], check=True, stderr=subprocess.DEVNULL)
+    l1 = open(os.path.join(LAMBDA, "reads_pe_1.fq"), "rb").read().split(b"\n")[:1200]
+    l2 = open(os.path.join(LAMBDA, "reads_pe_2.fq"), "rb").read().split(b"\n")[:1200]
+    for i in range(3, len(l2), 8):                          # every second quality line of the mates starts with '@'
+        l2[i] = b"@" + l2[i][1:]
+    f1, f2 = tmp_path / "crlf_1.fq", tmp_path / "nonl_2.fq"
+    f1.write_bytes(b"\r\n".join(l1) + b"\r\n")
+    f2.write_bytes(b"\n".join(l2))                          # no newline behind the last quality line
+    cmd = [salt, "-d", "-c", "-p", "-a", "250", "-b", "550", prefix, str(f1), str(f2)]
+    strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    a = subprocess.run(cmd, capture_output=True, env=dict(os.environ, SALT_CHUNK_BYTES="2500"))
+    b = subprocess.run(cmd, capture_output=True, env=dict(os.environ, SALT_HOST_PIPELINE="1"))
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-300:], b.stderr[-300:])
+    assert b"text path (paired end)" in a.stderr
+    assert strip(a.stdout) == strip(b.stdout)
+    assert strip(a.stdout).count(b"\n\n") == 600
