@@ -328,6 +328,16 @@ def main():
             out["parity"] = {"checked_reads": int(ns), "mismatching_reads": int(len(bad)),
                              "mapped_fraction": round(float((gres["pos"] != 0xFFFFFFFF).mean()), 5)}
             ora.close()
+    # the index image and the workspaces go before the end-to-end legs: the `salt` processes attach their own image, and two of them do
+    # not fit one GPU (a salt that finds 70 GiB free attaches a narrower k-mer table and no context table)
+    for a in alns[1:]:
+        a.close()
+    aln.close()
+    if idx is not None:
+        idx.destroy()
+    if rank == 0:
+        del d_ress, batches
+        torch.cuda.empty_cache()
         # ---- end to end: the drop-in binary, FASTQ text -> SAM text, wall clock (SURVEY 8d's metric; never `value`) ----
         if args.e2e_reads > 0:
             try:
@@ -340,11 +350,6 @@ def main():
             except Exception as ex:
                 out["e2e_pe"] = {"error": str(ex)[:300]}
         print(json.dumps(out), flush=True)
-    for a in alns[1:]:
-        a.close()
-    aln.close()
-    if idx is not None:
-        idx.destroy()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -375,7 +380,7 @@ def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log):
     wall = time.time() - t0
     err = p.stderr.decode(errors="replace")
     if p.returncode != 0:
-        raise RuntimeError("salt exited %d: %s" % (p.returncode, err[-200:]))
+        raise RuntimeError("salt exited %d: %s" % (p.returncode, " | ".join(l for l in err.splitlines() if "have been aligned" not in l)[-280:]))
     align_s, detail = None, None
     for line in err.splitlines():
         if line.startswith("[alnse_core]: total"):
@@ -414,7 +419,7 @@ def e2e_pe_leg(args, w, genome, site, workload, torch, np, log):
     wall = time.time() - t0
     err = p.stderr.decode(errors="replace")
     if p.returncode != 0:
-        raise RuntimeError("salt -p exited %d: %s" % (p.returncode, err[-200:]))
+        raise RuntimeError("salt -p exited %d: %s" % (p.returncode, " | ".join(l for l in err.splitlines() if "have been aligned" not in l)[-280:]))
     align_s, detail = None, None
     for line in err.splitlines():
         if line.startswith("[alnpe_core]: total") or line.startswith("[alnse_core]: total"):
