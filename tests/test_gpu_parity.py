@@ -665,7 +665,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     env = dict(os.environ, SALT_BENCH_SAME_GPU="1", SALT_BENCH_BACKEND="gloo", SALT_BENCH_WORKLOAD="mini", SALT_GPU_LKT_LEN="14",
                SALT_BENCH_CACHE=str(tmp_path))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu"],
+                          "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu", "--e2e-reads", "0"],
                          capture_output=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-600:]
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
