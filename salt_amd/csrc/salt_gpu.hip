@@ -390,7 +390,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     { static const bool off = getenv("SALT_GPU_NO_UNIQUE") && atoi(getenv("SALT_GPU_NO_UNIQUE")); sp.resolve_unique = !off; }
     if (n_reads > ws->max_reads) return fail(SALT_E_CAPACITY, "more reads than the workspace holds");
     AlignParams ap; ap.pg = pg; ap.n_reads = n_reads; ap.spr = spr; ap.l_seed = o->l_seed; ap.max_locate = o->max_locate; ap.max_hits = o->max_hits;
-    ap.all_heavy = ws->all_heavy; ap.pe = pe; { const char *e = getenv("SALT_GPU_LIGHT_STOP"); ap.dbg_stop = e ? atoi(e) : 0; } ap.max_amb = pe ? 5u : 200u;
+    ap.all_heavy = ws->all_heavy; ap.pe = pe; { const char *e = getenv("SALT_GPU_LIGHT_STOP"); ap.dbg_stop = e ? atoi(e) : 0; } { static const int hs = getenv("SALT_GPU_HEAVY_STOP") ? atoi(getenv("SALT_GPU_HEAVY_STOP")) : 0; ap.heavy_stop = hs; } ap.max_amb = pe ? 5u : 200u;
     if (pe && !ws->d_pe_scr) HIPCHK(hipMalloc((void **)&ws->d_pe_scr, (uint64_t)ws->heavy_blocks * PE_LOCI_CAP * 5));
     unsigned long long *ctr = o->collect_counters ? ws->d_ctr : nullptr;
     const bool timed = ws->timing && ws->n_timed < MAX_TIMED;

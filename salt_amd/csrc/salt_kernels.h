@@ -39,6 +39,7 @@ struct AlignParams {
     int32_t  max_hits;
     PackGeom pg;
     int32_t  dbg_stop;              // debug/A-B: k_light leaves after phase dbg_stop (1..4); results are then garbage
+    int32_t  heavy_stop;            // diagnostics: k_heavy leaves a read after its locate (1), verify (2) or rule (3) passes; results are then garbage
     int32_t  all_heavy;             // debug/A-B: skip k_light, k_heavy walks reads 0..n_reads-1
     int32_t  pe;                    // 1: mates of a paired-end batch -- alnse_overlap semantics (alnse.c:985-1044, 501-629):
                                     //    per-interval locate cap, gapped bound stays 3, > 5 N skips the mate
