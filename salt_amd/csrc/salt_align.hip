@@ -1763,6 +1763,32 @@ k_cigar(IndexView ix, PackGeom pg, const uint32_t *__restrict__ pm, salt_result_
 // (c) a gap-free hit exists.  Everything else is queued for k_heavy, which replays the reference's
 // general control flow.  Same results either way; the split only changes who computes them.
 // ---------------------------------------------------------------------------------------------
+// The queue of reads for k_heavy.  One counter for all of them was what k_light2 waited for: an atomic on ONE address is served every
+// ~11 ns however many waves ask (75 700 queued reads: 0.83 of its 0.87 ms).  The reads of workgroup-sized groups of four go to one
+// of QSEG segments, each with a counter 256 bytes from the next and room for every read that can map to it; k_queue_pack then
+// lays the segments end to end (the order of the queue does not matter) and leaves the count where k_heavy reads it.
+static constexpr uint32_t QSEG = 64, QSEG_STRIDE = 64;                      // segments; words between their counters
+__host__ __device__ __forceinline__ uint32_t qseg_cap(uint32_t n_reads) { return n_reads / QSEG + 8u; }
+__device__ __forceinline__ void queue_push(uint32_t *__restrict__ qseg, uint32_t *__restrict__ qsub, uint32_t n_reads, uint32_t r)
+{
+    const uint32_t s = (r >> 2) & (QSEG - 1u);
+    qseg[(size_t)s * qseg_cap(n_reads) + atomicAdd(&qsub[s * QSEG_STRIDE], 1u)] = r;
+}
+__global__ void __launch_bounds__(256)
+k_queue_pack(const uint32_t *__restrict__ qseg, const uint32_t *__restrict__ qsub, uint32_t n_reads, uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl)
+{
+    __shared__ uint32_t base_s, cnt_s;
+    if (threadIdx.x == 0) {
+        uint32_t base = 0, total = 0;
+        for (uint32_t s = 0; s < QSEG; ++s) { const uint32_t c = qsub[s * QSEG_STRIDE]; if (s < blockIdx.x) base += c; total += c; }
+        base_s = base; cnt_s = qsub[blockIdx.x * QSEG_STRIDE];
+        if (blockIdx.x == 0) qctl[0] = total;
+    }
+    __syncthreads();
+    const uint32_t *src = qseg + (size_t)blockIdx.x * qseg_cap(n_reads);
+    for (uint32_t i = threadIdx.x; i < cnt_s; i += 256) queue[base_s + i] = src[i];
+}
+
 static constexpr int LT_SLOTS = 16;      // seed slots per list handled here
 static constexpr int LT_LOCI = 128;      // loci per strand handled here
 static constexpr int LT_MAXL = 160;
@@ -1781,7 +1807,7 @@ static constexpr int LT_WAVES = 2;       // independent reads (waves) per workgr
 __global__ void __launch_bounds__(64 * LT_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
         const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
-        uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl, unsigned long long *__restrict__ ctr)
+        uint32_t *__restrict__ queue /* the segments */, uint32_t *__restrict__ qsub, unsigned long long *__restrict__ ctr)
 {
     __shared__ LightLds w_all[LT_WAVES];
     LightLds &w = w_all[threadIdx.x >> 6];
@@ -1968,7 +1994,7 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
         }
     }
     if (heavy) {
-        if (lane == 0) queue[atomicAdd(&qctl[0], 1u)] = r;
+        if (lane == 0) queue_push(queue, qsub, ap.n_reads, r);
         return;                                                             // k_heavy does (and counts) all of it
     }
     stamp(SALT_CTR_LT_OUT);
@@ -2081,7 +2107,7 @@ template <int L2_WAVES>
 __global__ void __launch_bounds__(64 * L2_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
          const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
-         uint32_t *__restrict__ queue, uint32_t *__restrict__ qctl)
+         uint32_t *__restrict__ queue /* the segments */, uint32_t *__restrict__ qsub)
 {
     __shared__ LightLds2 w2[2 * L2_WAVES];
     const uint32_t lane = lane_id(), hl = lane & 31u, hb = lane & 32u, half = lane >> 5;
@@ -2260,7 +2286,7 @@ k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
             }
         }
     }
-    if (heavy && hl == 0) queue[atomicAdd(&qctl[0], 1u)] = r;                // k_heavy does all of it
+    if (heavy && hl == 0) queue_push(queue, qsub, ap.n_reads, r);            // k_heavy does all of it
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2323,18 +2349,21 @@ void launch_seed(const IndexView &ix, const SeedParams &sp, const uint32_t *tb, 
 }
 
 void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint8_t *, const uint32_t *, const uint4 *sai_c,
-                  const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, unsigned long long *ctr, hipStream_t st)
+                  const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, uint32_t *qseg, uint32_t *qsub, unsigned long long *ctr, hipStream_t st)
 {
     if (!ap.n_reads) return;
+    hipMemsetAsync(qsub, 0, (size_t)QSEG * QSEG_STRIDE * 4, st);
     static const bool no_half = getenv("SALT_GPU_NO_LIGHT2") && atoi(getenv("SALT_GPU_NO_LIGHT2"));
     if (!no_half && !ctr && !ap.dbg_stop && ap.spr <= (uint32_t)L2_SLOTS && ap.pg.nw8 <= 15) {          // reads of at most 120 bases: two per wave
         static const int wv = getenv("SALT_GPU_L2_WAVES") ? atoi(getenv("SALT_GPU_L2_WAVES")) : 2;
-        if (wv == 1) hipLaunchKernelGGL(k_light2<1>, dim3((ap.n_reads + 1) / 2), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl);
-        else hipLaunchKernelGGL(k_light2<2>, dim3((ap.n_reads + 3) / 4), dim3(128), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl);
-        return;
-    }
-    hipLaunchKernelGGL(k_light, dim3((ap.n_reads + LT_WAVES - 1) / LT_WAVES), dim3(64 * LT_WAVES), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, qctl, ctr);
+        if (wv == 1) hipLaunchKernelGGL(k_light2<1>, dim3((ap.n_reads + 1) / 2), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, qseg, qsub);
+        else hipLaunchKernelGGL(k_light2<2>, dim3((ap.n_reads + 3) / 4), dim3(128), 0, st, ix, ap, pm, sai_c, sai_r, results, qseg, qsub);
+    } else
+        hipLaunchKernelGGL(k_light, dim3((ap.n_reads + LT_WAVES - 1) / LT_WAVES), dim3(64 * LT_WAVES), 0, st, ix, ap, pm, sai_c, sai_r, results, qseg, qsub, ctr);
+    hipLaunchKernelGGL(k_queue_pack, dim3(QSEG), dim3(256), 0, st, qseg, qsub, ap.n_reads, queue, qctl);
 }
+size_t queue_words(uint32_t max_reads) { return (size_t)max_reads * 2 + (size_t)QSEG * qseg_cap(max_reads); }     // flat queue | overflow queue | segments
+uint32_t queue_sub_words() { return QSEG * QSEG_STRIDE; }
 
 // ---------------------------------------------------------------------------------------------
 // k_diag_rule: unit access to rule_unsorted / rule_sparse (tests only).  One wave per case; out[case] = any, best_pos,

@@ -56,6 +56,7 @@ struct salt_gpu_ws {
     bool h_sam_owned = true;                                                 // false: the caller's page-locked buffer (salt_gpu_ws_reserve_text)
     uint32_t text_calls = 0;                                                 // SALT_TEXT_TRACE: stage clocks of the first text call
     uint32_t heavy_blocks = 2048, gap_blocks = 2048;
+    uint32_t *d_qsub = nullptr;                                               // counters of the queue's segments
     int all_heavy = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
@@ -284,7 +285,8 @@ extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint
     CHKW(hipMalloc((void **)&ws->d_offs, ((uint64_t)max_reads + 1) * 4));
     CHKW(hipMalloc((void **)&ws->d_results, (uint64_t)max_reads * sizeof(salt_result_t)));
     CHKW(hipMemset(ws->d_results, 0, (uint64_t)max_reads * sizeof(salt_result_t)));
-    CHKW(hipMalloc((void **)&ws->d_queue, (uint64_t)max_reads * 8));           // the reads k_light queues + k_heavy's overflow queue
+    CHKW(hipMalloc((void **)&ws->d_queue, queue_words(max_reads) * 4));         // the reads k_light queues (flat, and the segments they arrive in) + k_heavy's overflow queue
+    CHKW(hipMalloc((void **)&ws->d_qsub, (size_t)queue_sub_words() * 4));
     CHKW(hipMalloc((void **)&ws->d_qctl, 16 * 4));
     ws->gcap = max_reads < (1u << 20) ? max_reads : (1u << 20);         // slots for reads whose gapped pass is deferred (44 B each + their rows in the pool)
     if (const char *e3 = getenv("SALT_GPU_NO_GAP_DEFER")) if (atoi(e3)) ws->gcap = 0;
@@ -325,7 +327,7 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
 {
     if (!ws) return;
     hipSetDevice(ws->ix->device);
-    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_heads); if (ws->h_heads) hipHostFree(ws->h_heads); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gap);
+    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_heads); if (ws->h_heads) hipHostFree(ws->h_heads); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qsub); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gap);
     hipFree(ws->d_raw); hipFree(ws->d_tile); hipFree(ws->d_lines); hipFree(ws->d_rec); hipFree(ws->d_tctl); hipFree(ws->d_samoff); hipFree(ws->d_scan); hipFree(ws->d_sam); hipFree(ws->d_rg);
     if (ws->h_sam && ws->h_sam_owned) hipHostFree(ws->h_sam);
     hipFree(ws->d_pe_scr); hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres); hipFree(ws->d_pctl); hipFree(ws->d_sw_scr); hipFree(ws->d_pcq);
@@ -403,7 +405,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     if (timed) HIPCHK(hipEventRecord(ev[2], st));
     if (!ap.all_heavy)
         launch_light(ws->ix->view, ap, ws->d_pm, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
-                     static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ctr, st);
+                     static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ws->d_queue + 2 * (size_t)ws->max_reads, ws->d_qsub, ctr, st);
     if (timed) HIPCHK(hipEventRecord(ev[3], st));
     launch_heavy(ws->ix->view, ap, ws->d_pm, ws->d_sai_c, ws->d_sai_r,
                  static_cast<salt_result_t *>(d_results), ws->d_queue, ctr, ws->heavy_blocks, ws->gap_blocks, ws->d_lvtab,

@@ -51,7 +51,9 @@ void launch_pack(const PackGeom &pg, uint32_t n_reads, const uint8_t *seqs, cons
 void launch_seed(const IndexView &ix, const SeedParams &sp, const uint32_t *tb, const uint8_t *seqs, const uint32_t *offs, uint4 *sai_c,
                  uint4 *sai_r, unsigned long long *ctr, hipStream_t st);
 void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
-                  const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, unsigned long long *ctr, hipStream_t st);
+                  const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, uint32_t *qseg, uint32_t *qsub, unsigned long long *ctr, hipStream_t st);
+size_t queue_words(uint32_t max_reads);                      // d_queue: the flat queue, k_heavy's overflow queue, k_light's segments
+uint32_t queue_sub_words();                                 // the segments' counters
 // Deferred gapped passes (k_heavy -> k_gap -> k_gapfin -> k_cigar), `cap` slots; gctl = the workspace's qctl[8]
 struct GapBufs {
     uint32_t *gq;        // [cap] read index of the slot (0xFFFFFFFF: not used after all)
