@@ -1261,7 +1261,12 @@ static int pe_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const sa
     const uint64_t l_pac = (uint64_t)ws->ix->l_pac;
     uint64_t max_win = (uint64_t)pe->max_tlen + max_len + 2;
     if (max_win > l_pac + 1) max_win = l_pac + 1;
-    const SwGeom geom = sw_geom(max_len, max_win, ws->sw_blocks);
+    SwGeom geom = sw_geom(max_len, max_win, ws->sw_blocks);
+    {   // one group (8 lanes) per rescue in flight; rescues are a few per cent of the mates, so a small batch does not need the full grid --
+        // nor its scratch (8 GiB at 2 x 150: a quarter of a second of hipMalloc at the first call of every workspace)
+        const uint32_t enough = n_pairs / 96u < 256u ? 256u : n_pairs / 96u;
+        if (geom.n_blocks > enough && ws->sw_scr_bytes < (uint64_t)geom.n_blocks * 8 * geom.group_bytes) geom.n_blocks = enough;
+    }
     const uint64_t need = (uint64_t)geom.n_blocks * 8 * geom.group_bytes;
     if (need > ws->sw_scr_bytes) {
         HIPCHK(hipStreamSynchronize(st));
