@@ -402,6 +402,22 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
                         const bool head_n = ((vn2 >> (64 - reln2 - m)) & ((1ull << m) - 1ull)) != 0;
                         if (!head_n && u.x >= m && xr == (u.y & mk)) oc = make_uint4(u.x - m, u.x - m, c.s, 2);
                     }
+                    else if (v.y == v.x + 1u && c.inreg && sp.resolve_unique && m >= 1 && m <= 16) {
+                        // two rows (a tenth of the seeds at W = 16 on 3.1e9 bases: chance repeats of the 16-mer): the entry holds both
+                        // suffixes' positions and the bases in front of them.  The m steps still to do keep exactly the rows whose text
+                        // continues like the read: none -> dead, one -> that row, located; both -> the walk decides (a real repeat)
+                        const uint32_t rel = c.s - (c.wb << 4), rr = rel & 15u;
+                        const uint64_t vr = rel < 16 ? (((uint64_t)c.w0 << 32) | c.w1) : (((uint64_t)c.w1 << 32) | c.w2);
+                        const uint32_t mk = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+                        const uint32_t xr = (uint32_t)(vr >> (64 - 2 * rr - 2 * m)) & mk;
+                        const uint32_t reln2 = c.s - (c.nb << 5);
+                        const uint64_t vn2 = ((uint64_t)c.n0 << 32) | c.n1;
+                        const bool head_n = ((vn2 >> (64 - reln2 - m)) & ((1ull << m) - 1ull)) != 0;
+                        const bool ok0 = !head_n && u.x >= m && xr == (u.y & mk), ok1 = !head_n && u.z >= m && xr == (u.w & mk);
+                        if (ok0 && ok1) { pend_c = true; pk_c = v.x; pl_c = v.y; }
+                        else if (ok0) oc = make_uint4(u.x - m, u.x - m, c.s, 2);
+                        else if (ok1) oc = make_uint4(u.z - m, u.z - m, c.s, 2);
+                    }
                     else if ((v.x == v.y && c.inreg && sp.resolve_unique) || i_top < 0) oc = seed_c_rest(ix, sp, c, v.x, v.y, i_top, n_occ_c, n_lkt);   // no walk left (or only the extension)
                     else { pend_c = true; pk_c = v.x; pl_c = v.y; }
                 }

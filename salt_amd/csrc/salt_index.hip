@@ -217,8 +217,9 @@ k_build_wlkt(IndexView ix, uint32_t len, uint4 *__restrict__ out)
         uint4 e = make_uint4(1u, 0u, 1u, 0u), f = make_uint4(0u, 0u, 0u, 0u);
         if (k <= l) { e.x = k; e.y = l; }
         if (k0 <= l0) { e.z = k0; e.w = l0; }
-        if (k == l) {
-            uint32_t p0 = ix.c_sa[k];
+        // a C interval of one or two rows: the position of each suffix and the 16 bases in front of it (.x/.y row k, .z/.w row k + 1)
+        for (uint32_t q = 0; q < 2 && k <= l && l - k <= 1 && q <= l - k; ++q) {
+            uint32_t p0 = ix.c_sa[k + q];
             if (p0 == 0xFFFFFFFFu) p0 = ix.c_seq_len;          // row 0: the empty suffix (bwt_sa's sa[0] = -1)
             uint32_t prev = 0;
             if (p0 >= 16) {
@@ -226,7 +227,7 @@ k_build_wlkt(IndexView ix, uint32_t len, uint4 *__restrict__ out)
                 const uint64_t vt = ((uint64_t)ix.text[tj] << 32) | ix.text[tj + 1];
                 prev = (uint32_t)(vt >> (32 - 2 * tr));
             } else if (p0 > 0) prev = ix.text[0] >> (32 - 2 * p0);
-            f.x = p0; f.y = prev;
+            if (q == 0) { f.x = p0; f.y = prev; } else { f.z = p0; f.w = prev; }
         }
         out[2 * x] = e; out[2 * x + 1] = f;
     }
