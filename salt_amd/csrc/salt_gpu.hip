@@ -300,10 +300,10 @@ extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint
         hipDeviceProp_t prop;
         CHKW(hipGetDeviceProperties(&prop, ix->device));
         uint32_t per_cu = heavy_blocks_per_cu();                           // what LDS / VGPRs admit (12)
-        // Half of that by default: the persistent kernels are latency bound, so alone they lose 3 % with 6 waves per CU instead of
-        // 12, while the kernels of the other batches in flight (other workspaces / streams) find room: +8 % on the 4-stream step
-        // (measured: 3 -> 670, 4 -> 693, 6 -> 705, 8 -> 686, 12 -> 654 Mreads/s)
-        if (per_cu > 5) per_cu = 5;
+        // Eight by default: the persistent kernels are latency bound (alone: 4 -> 1.98, 5 -> 1.64, 6 -> 1.40, 8 -> 1.17 ms per 10^6
+        // GRCh38-scale reads), and since k_light2 no longer waits for its queue counter the 4-stream step is the same for 4 ... 8
+        // (2.50-2.52 ms; 10 -> 2.61), so the count that is best for the kernel alone is taken (profiles/r02/ab_heavy_per_cu_final.log)
+        if (per_cu > 8) per_cu = 8;
         if (const char *e2 = getenv("SALT_GPU_HEAVY_PER_CU")) { int v = atoi(e2); if (v > 0 && (uint32_t)v <= heavy_blocks_per_cu()) per_cu = (uint32_t)v; }
         ws->heavy_blocks = (uint32_t)prop.multiProcessorCount * per_cu;    // persistent one-wave blocks
         // k_gap's items (64 candidates' Landau-Vishkin distances, ~70 us each) are independent and need no table of their own: its grid is
