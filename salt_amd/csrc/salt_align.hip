@@ -265,11 +265,31 @@ __device__ __forceinline__ bool seed_is_n(const SeedCtx c, uint32_t i)
 // read and the text in front of that suffix differ.  Everything by value: what a lambda captures by reference ends up in scratch.
 __device__ __forceinline__ uint32_t seed_resolve_unique(const uint32_t *__restrict__ c_sa, const uint32_t *__restrict__ text, uint32_t c_seq_len,
                                                         uint32_t s, uint32_t wb, uint32_t nb, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t n0, uint32_t n1,
-                                                        int it, uint32_t row, uint32_t &n_aux)
+                                                        int it, uint32_t row, uint32_t &n_aux, const uint4 *__restrict__ c_ctx = nullptr, uint32_t ctx_len = 0)
 {
         const uint32_t m = (uint32_t)it + 1u;
         const uint32_t reln = s - (nb << 5);
         const uint64_t vn = ((uint64_t)n0 << 32) | n1;
+        if (c_ctx && m <= CTX_N) {
+            // the context table's record of the row holds the suffix's position AND the 23 bases in front of it: one load instead of
+            // the suffix-array load followed by the text load (record layout: salt_device.h; side B is complete iff CTX_N <= p0 <= ctx_len)
+            const uint4 rec = c_ctx[row];
+            const uint32_t p0c = rec.x == 0xFFFFFFFFu ? c_seq_len : rec.x;
+            if (p0c >= CTX_N && p0c <= ctx_len) {
+                n_aux += 1u << 10;
+                if (((vn >> (64 - reln - m)) & ((1ull << m) - 1ull)) != 0) return 0xFFFFFFFFu;
+                const uint64_t lo = ((uint64_t)rec.y | ((uint64_t)(rec.z & 0x3FFFu) << 32)) >> CTX_N, hi = ((uint64_t)(rec.z >> 14) | ((uint64_t)(rec.w & 0x0FFFFFFFu) << 18)) >> CTX_N;
+                uint32_t rlo = 0, rhi = 0;
+                for (uint32_t u = 0; u < m; ++u) {                            // read base s + it - u faces genome base p0 - 1 - u
+                    const uint32_t rel = s + (uint32_t)it - u - (wb << 4);
+                    const uint32_t ws = rel < 16 ? w0 : rel < 32 ? w1 : w2;
+                    const uint32_t code = (ws >> (30 - 2 * (rel & 15u))) & 3u;
+                    rlo |= (code & 1u) << u; rhi |= (code >> 1) << u;
+                }
+                const uint32_t mk = (1u << m) - 1u;
+                return ((((uint32_t)lo ^ rlo) | ((uint32_t)hi ^ rhi)) & mk) == 0 ? p0c - m : 0xFFFFFFFFu;
+            }
+        }
         uint32_t p0 = c_sa[row];
         if (p0 == 0xFFFFFFFFu) p0 = c_seq_len;            // row 0: the empty suffix
         bool ok = ((vn >> (64 - reln - m)) & ((1ull << m) - 1ull)) == 0 && p0 >= m;
@@ -303,13 +323,13 @@ __device__ __forceinline__ uint4 seed_c_rest(const IndexView &ix, const SeedPara
     const uint32_t s = c.s;
     const bool uniq = c.inreg && sp.resolve_unique;
     bool alive = true, located = false;
-    if (uniq && kc == lc && i_top >= 0) { const uint32_t p = seed_resolve_unique(ix.c_sa, ix.text, ix.c_seq_len, s, c.wb, c.nb, c.w0, c.w1, c.w2, c.n0, c.n1, i_top, kc, n_aux); alive = p != 0xFFFFFFFFu; located = alive; if (alive) kc = lc = p; }
+    if (uniq && kc == lc && i_top >= 0) { const uint32_t p = seed_resolve_unique(ix.c_sa, ix.text, ix.c_seq_len, s, c.wb, c.nb, c.w0, c.w1, c.w2, c.n0, c.n1, i_top, kc, n_aux, ix.c_ctx, ix.c_seq_len < ix.ref_len ? ix.c_seq_len : ix.ref_len); alive = p != 0xFFFFFFFFu; located = alive; if (alive) kc = lc = p; }
     for (int i = i_top; i >= 0 && alive && !located; --i) {
         if (seed_is_n(c, s + (uint32_t)i)) { alive = false; break; }
         const uint32_t b = seed_base2(c, s + (uint32_t)i);
         uint32_t ok, ol; n_occ_c += c_occ2(ix, kc - 1, lc, b, ok, ol);
         { const uint32_t l2 = pick4(ix.c_L2, b); kc = l2 + ok + 1; lc = l2 + ol; } alive = kc <= lc;
-        if (uniq && alive && kc == lc && i > 0) { const uint32_t p = seed_resolve_unique(ix.c_sa, ix.text, ix.c_seq_len, s, c.wb, c.nb, c.w0, c.w1, c.w2, c.n0, c.n1, i - 1, kc, n_aux); alive = p != 0xFFFFFFFFu; located = alive; if (alive) kc = lc = p; }
+        if (uniq && alive && kc == lc && i > 0) { const uint32_t p = seed_resolve_unique(ix.c_sa, ix.text, ix.c_seq_len, s, c.wb, c.nb, c.w0, c.w1, c.w2, c.n0, c.n1, i - 1, kc, n_aux, ix.c_ctx, ix.c_seq_len < ix.ref_len ? ix.c_seq_len : ix.ref_len); alive = p != 0xFFFFFFFFu; located = alive; if (alive) kc = lc = p; }
     }
     if (!alive) return make_uint4(1, 0, 0, 0);
     if (located) return make_uint4(kc, kc, s, 2);
