@@ -19,6 +19,9 @@ Prints ONE JSON line (rank 0) with the metric of BASELINE.json plus
   "cpu_baseline": the CPU oracle (bit-exact restatement of the reference) on a bounded sample of the same reads on this box's
                   host cores, also used to check the GPU results ("parity")
   "e2e":          the `salt` binary, FASTQ text in -> SAM text out on reads of the same workload: SURVEY 8d's wall-clock metric.
+  "pe":           BASELINE.json configs[3] (2 x 150-base pairs, -p -a 250 -b 550, on the same index): the kernel stage of
+                  salt_gpu_align_pe_resident on resident batches, per-kernel times, the roofline of its dominant kernel, parity against the
+                  oracle on a sample of a timed step's pairs, and the oracle's own rate on this box.
 """
 import argparse
 import json
@@ -38,6 +41,32 @@ SECTOR = 64                    # bytes a random access moves at least (one L2 / 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_info():
+    """(threads this process may run on, model name) of the box the CPU baseline is timed on."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return n, model
+
+
+def spread(step_ends_ms):
+    """min / median / max of the intervals between consecutive step completions (ms): with several batches in flight a step has no wall
+    time of its own, but the completion times of the steps do -- their spacing is the step rate as it varies inside the timed region."""
+    t = sorted(step_ends_ms)
+    d = [t[0]] + [b - a for a, b in zip(t, t[1:])]
+    d.sort()
+    return {"min": round(d[0], 3), "median": round(d[len(d) // 2], 3), "max": round(d[-1], 3), "what": "intervals between consecutive step completions (HIP events on each step's stream)"}
 
 
 def device_bytes(ctr, n_reads, L, spr):
@@ -69,11 +98,21 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--e2e-reads", type=int, default=32000000, help="reads of the end-to-end leg (`salt` binary, FASTQ -> SAM); 0 = skip")
     ap.add_argument("--e2e-pairs", type=int, default=4000000, help="pairs (2 x 150) of the paired-end end-to-end leg (`salt -p`); 0 = skip")
+    ap.add_argument("--pe-pairs", type=int, default=500000, help="pairs (2 x 150) per step of the paired-end kernel-stage leg; 0 = skip")
+    ap.add_argument("--pe-steps", type=int, default=16)
+    ap.add_argument("--pe-batches", type=int, default=4)
+    ap.add_argument("--pe-check", type=int, default=20000, help="pairs of a timed step compared with the oracle (and timed there)")
+    ap.add_argument("--mode", choices=("both", "se", "pe"), default="both", help="profiling runs: `pe` = the paired-end leg with a token single-end step, `se` = no paired-end leg")
+    ap.add_argument("--no-counters", action="store_true", help="profiling runs: skip the steps that run with the access counters on (they use other kernel variants)")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (experiments; default: the workload's own batch)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("SALT_BENCH_STREAMS", "4")),
                     help="workspaces / HIP streams per GPU the steps are dealt to round-robin (salt runs 2-4 align workers per GPU)")
     args = ap.parse_args()
 
+    if args.mode == "pe":
+        args.steps, args.warmup, args.batches, args.e2e_reads, args.e2e_pairs = 1, 1, 1, 0, 0
+    if args.mode == "se":
+        args.pe_pairs = 0
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -197,17 +236,24 @@ def main():
     torch.cuda.synchronize()
     serial_kms, serial_calls = aln.kernel_ms()
     serial_kms = {k: v / max(serial_calls, 1) for k, v in serial_kms.items()}
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_ev[0].record(streams[0])
     for i in range(args.steps):
         step(i)
+        step_ev[i + 1].record(streams[i % n_streams])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the rows the LAST timed step left behind (its batch, its workspace): what the parity leg compares with the oracle
+    last = args.steps - 1
+    timed_rows = d_ress[last % n_streams].clone() if args.steps > 0 else None
+    timed_batch = last % n_batches
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -240,11 +286,13 @@ def main():
                                       "steps dealt round-robin to %d workspace(s)/HIP stream(s) per GPU" % (world, n_streams),
                        "streams_per_gpu": n_streams},
             "stages_s": stages,
-            "kernel_ms": {k: round(v, 3) for k, v in kms.items()},
-            "kernel_ms_serialized": {k: round(v, 3) for k, v in serial_kms.items()},
+            "step_ms": spread([step_ev[0].elapsed_time(e) for e in step_ev[1:]]) if args.steps > 0 else None,
+            "kernel_ms": {k: round(v, 3) for k, v in kms.items() if v},
+            "kernel_ms_serialized": {k: round(v, 3) for k, v in serial_kms.items() if v},
         }
-        # ---- one more serialized step of batch 0 with the access counters on (k_light instead of k_light2: same accesses) ----
-        copt = salt_amd.AlnOpt(l_seed=cfg["k"], collect_counters=1)
+        # ---- one more serialized step of batch 0 with the access counters on (k_light instead of k_light2: same accesses; its rows are NOT
+        # the ones compared with the oracle -- those are timed_rows, taken above) ----
+        copt = salt_amd.AlnOpt(l_seed=cfg["k"], collect_counters=0 if args.no_counters else 1)
         aln.counters()
         s0, o0 = batches[0]
         aln.align_resident(copt, n_reads, L, s0.data_ptr(), o0.data_ptr(), d_ress[0].data_ptr(), streams[0].cuda_stream)
@@ -258,13 +306,16 @@ def main():
         except KeyError:
             db = None
         dom = max(serial_kms, key=lambda k: serial_kms[k])
-        prof = {}
-        pf = os.path.join(ROOT, "profiles", "r02", "pmc_summary_%s.json" % args.workload)
-        if os.path.exists(pf):
-            try:
-                prof = json.load(open(pf))
-            except Exception:
-                prof = {}
+        prof, prof_dir = {}, None
+        for rd in ("r03", "r02"):                               # the newest committed profile of this workload
+            pf = os.path.join(ROOT, "profiles", rd, "pmc_summary_%s.json" % args.workload)
+            if os.path.exists(pf):
+                try:
+                    prof, prof_dir = json.load(open(pf)), "profiles/" + rd
+                    break
+                except Exception:
+                    prof = {}
+        pkey = lambda k: "k_light2" if k == "k_light" and "k_light2" in prof.get("per_kernel_mean", {}) else k    # the timed steps run k_light2
         roof = {"bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "timing": "HIP events on the launch stream over %d serialized steps of this run, every resident batch once (kernel_ms_serialized)" % n_serial}
         if db and dom in db:
@@ -276,29 +327,29 @@ def main():
                          "whole_step_GBps_wall": round(sum(db.values()) / (dt / args.steps) / 1e9, 1),
                          "bytes_model": "device layout: 64 B per W-mer gather, 32/64 B per C/R Occ block fetched, 4 B per SA / R-position load, 8 B per text "
                                         "word pair, 16 B per verify lane-load, packed read records, 32 B per seed interval pair, result rows; counted by the kernels"})
-        tr = prof.get("hbm_bytes_per_launch", {}).get(dom)
+        tr = prof.get("hbm_bytes_per_launch", {}).get(pkey(dom))
         roof["traffic"] = tr
         pk = prof.get("per_kernel_mean", {})
         if tr:
             roof["traffic_GBps"] = round(tr / (serial_kms[dom] / 1e3) / 1e9, 1)
-            roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE of profiles/r02 (separate --pmc passes), raw: tools/ubench/gather shows FETCH_SIZE = 64.0 B per random "
+            roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE of %s (separate --pmc passes)" % prof_dir + ", raw: tools/ubench/gather shows FETCH_SIZE = 64.0 B per random "
                                     "4/16/32/64-byte record, i.e. exact for these gather shapes (no x2 streaming correction applies)")
-        rq = pk.get(dom, {}).get("TCC_EA0_RDREQ_sum")
+        rq = pk.get(pkey(dom), {}).get("TCC_EA0_RDREQ_sum")
         if rq:
             # how far the kernel is from the memory system's limit for its access shape: random 64-byte requests per second (a second adjacent sector per window is free)
             roof["random_requests"] = {"per_launch": int(rq), "G_per_s": round(rq / (serial_kms[dom] / 1e3) / 1e9, 1), "ceiling_G_per_s": RANDOM_REQ_GPS,
                                        "frac_of_ceiling": round(rq / (serial_kms[dom] / 1e3) / 1e9 / RANDOM_REQ_GPS, 3),
                                        "whole_step_G_per_s_wall": round(sum(v.get("TCC_EA0_RDREQ_sum", 0) for v in pk.values()) / (dt / args.steps) / 1e9, 1),
-                                       "source": "TCC_EA0_RDREQ_sum per launch (profiles/r02/pmc_tcc_*.csv) / this run's HIP-event time; ceiling: tools/ubench/gather"}
+                                       "source": "TCC_EA0_RDREQ_sum per launch (%s/pmc_tcc_*.csv) / this run's HIP-event time; ceiling: tools/ubench/gather" % prof_dir}
         alltr = prof.get("hbm_bytes_per_launch", {})
         if alltr:
             roof["whole_step_traffic_GBps_wall"] = round(sum(alltr.values()) / (dt / args.steps) / 1e9, 1)
-        ir = prof.get("issue", {}).get(dom)
+        ir = prof.get("issue", {}).get(pkey(dom))
         if ir:
             roof["issue_bound"] = ir
         roof["limiter"] = ("memory latency x resident waves, not a bandwidth: k_seed and k_light2 fill every wave slot (8 per SIMD) with dependent chains of random loads "
-                           "(a W-mer gather, then up to k - W Occ steps per seed; 3 round trips per read pair), k_heavy's reads make ~20 dependent round trips each on 6 one-wave "
-                           "blocks per CU.  With 4 or more streams the step is pinned at the sum of the slot-filling kernels plus the part of k_heavy that does not hide behind them "
+                           "(a W-mer gather, then up to k - W Occ steps per seed; 3 round trips per read pair), k_heavy's reads make ~20 dependent round trips each on its one-wave "
+                           "persistent blocks (salt_gpu_ws_create: 8 per CU unless SALT_GPU_HEAVY_PER_CU says otherwise).  With 4 or more streams the step is pinned at the sum of the slot-filling kernels plus the part of k_heavy that does not hide behind them "
                            "(2 streams: the serialized sum; 4, 6, 8: the same plateau).  random_requests.frac_of_ceiling and frac (bytes) say how far the memory system is from ITS "
                            "limits: about half of the random-request rate and a fifth of the streaming peak.  Halving k_heavy's requests (the context table, DESIGN 3) "
                            "took 14 % off its time: that is what a latency bound looks like")
@@ -314,20 +365,37 @@ def main():
             ora = oracle_py.Oracle(w["prefix"])
             stages["oracle_load_files"] = round(time.time() - t1, 2)
             oo = ora.opt()
-            cores = min(os.cpu_count() or 1, 64)
-            hs, ho = s0[:ns * L].cpu().numpy(), o0[:ns + 1].cpu().numpy().view(np.uint32)
+            cores, cpu_model = cpu_info()                                   # every hardware thread this process may use
+            sb, ob = batches[timed_batch]
+            hs, ho = sb[:ns * L].cpu().numpy(), ob[:ns + 1].cpu().numpy().view(np.uint32)
             t1 = time.perf_counter()
             ores = ora.align(oo, hs, ho, n_threads=cores)
             cpu_dt = time.perf_counter() - t1
-            gres = d_ress[0].cpu().numpy().view(salt_amd.RESULT_DTYPE)[:ns]     # batch 0 was the last batch aligned into d_ress[0]
+            gres = timed_rows.cpu().numpy().view(salt_amd.RESULT_DTYPE)[:ns]   # the rows of the last TIMED step (k_light2 and all), not of the counters step
             bad = oracle_py.compare(gres, ores)
-            out["cpu_baseline"] = {"value": round(ns / cpu_dt / 1e6, 5), "unit": "Mreads/s", "cores": cores, "kind": "port",
-                                   "sample": "first %d reads of batch 0 of the same workload, oracle/libsalt_oracle.so (bit-exact CPU restatement "
-                                             "of the reference), %d threads, align time only (%.1f s)" % (ns, cores, cpu_dt),
+            out["cpu_baseline"] = {"value": round(ns / cpu_dt / 1e6, 5), "unit": "Mreads/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
+                                   "sample": "first %d reads of batch %d of the same workload, oracle/libsalt_oracle.so (bit-exact CPU restatement "
+                                             "of the reference), %d threads = every hardware thread of this box, align time only (%.1f s)" % (ns, timed_batch, cores, cpu_dt),
                                    "speedup_1gpu": round(value / world / (ns / cpu_dt / 1e6), 1)}
-            out["parity"] = {"checked_reads": int(ns), "mismatching_reads": int(len(bad)),
+            out["parity"] = {"path": "timed step", "what": "rows left by the last step of the timed region (batch %d, workspace %d) vs the oracle, every field" % (timed_batch, last % n_streams),
+                             "checked_reads": int(ns), "mismatching_reads": int(len(bad)),
                              "mapped_fraction": round(float((gres["pos"] != 0xFFFFFFFF).mean()), 5)}
             ora.close()
+        # ---- paired end (BASELINE configs[3]) on the same index, same workspaces ----
+        if args.pe_pairs > 0:
+            ora = None
+            try:
+                if not args.no_cpu:
+                    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                    import oracle_py
+                    ora = oracle_py.Oracle(w["prefix"])
+                out["pe"] = pe_leg(args, cfg, idx, alns, streams, genome, site, ora, oracle_py if ora else None, dev, torch, np, salt_amd, workload, log)
+            except Exception as ex:                                        # a report, not a gate: the SE line must still come out
+                import traceback
+                log(traceback.format_exc())
+                out["pe"] = {"error": repr(ex)[:400]}
+            if ora:
+                ora.close()
     # the index image and the workspaces go before the end-to-end legs: the `salt` processes attach their own image, and two of them do
     # not fit one GPU (a salt that finds 70 GiB free attaches a narrower k-mer table and no context table)
     for a in alns[1:]:
@@ -336,7 +404,7 @@ def main():
     if idx is not None:
         idx.destroy()
     if rank == 0:
-        del d_ress, batches
+        del d_ress, batches, timed_rows
         torch.cuda.empty_cache()
         # ---- end to end: the drop-in binary, FASTQ text -> SAM text, wall clock (SURVEY 8d's metric; never `value`) ----
         if args.e2e_reads > 0:
@@ -353,6 +421,134 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pe_leg(args, cfg, idx, alns, streams, genome, site, ora, oracle_py, dev, torch, np, salt_amd, workload, log):
+    """BASELINE.json configs[3]: 2 x 150-base pairs, `-p -a 250 -b 550`, insert N(400, 50), 3 % of the fragment-end mates damaged (9 %
+    substitutions + a 2-base deletion: seed-and-verify misses them, the Smith-Waterman rescue runs) and 1 % random, on the index of the
+    single-end leg.  A step = salt_gpu_align_pe_resident over one resident batch: k_pack ... k_cigar on the 2n mates, k_pair, k_sw,
+    k_pe_final (+ k_cigar); results stay in HBM.  Same protocol as the single-end leg: distinct resident batches rotated over the
+    workspaces / streams, serialized steps for per-kernel times, the timed region between synchronisations."""
+    L, n_pairs, n_batches, steps = 150, args.pe_pairs, max(1, args.pe_batches), max(1, args.pe_steps)
+    n_streams = len(alns)
+    opt, _ = salt_amd.AlnOpt.from_argv(["-p", "-a", "250", "-b", "550"], cfg["k"])
+    t0 = time.time()
+    batches = []
+    for b in range(n_batches):
+        seqs, offs, _, _, _ = workload.make_pairs_hash(genome, site, n_pairs, L, seed=3, batch=b, damaged=0.03, orphan=0.01)
+        batches.append((seqs, offs))
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    alns[0].set_pac(idx)
+    for a in alns[1:]:
+        a._pac_set = True
+    d_ress = [torch.zeros(2 * n_pairs * salt_amd.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(n_streams)]
+
+    def step(i, k=None, o=opt):
+        k = i % n_streams if k is None else k
+        s, f = batches[i % n_batches]
+        alns[k].align_pe_resident(o, idx, n_pairs, L, s.data_ptr(), f.data_ptr(), d_ress[k].data_ptr(), streams[k].cuda_stream)
+
+    for i in range(2 * n_streams):                              # warm-up: scratch of every workspace (k_sw's, the mates' loci) allocated outside the clock
+        step(i)
+    torch.cuda.synchronize()
+    for a in alns:
+        a.timing(True)
+    n_serial = max(3, n_batches)
+    for i in range(n_serial):
+        step(i, 0)
+    torch.cuda.synchronize()
+    skm, sc = alns[0].kernel_ms()
+    skm = {k: v / max(sc, 1) for k, v in skm.items()}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record(streams[0])
+    for i in range(steps):
+        step(i)
+        ev[i + 1].record(streams[i % n_streams])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms, nc = {}, 0
+    for a in alns:
+        km, c = a.kernel_ms()
+        nc += c
+        for k, v in km.items():
+            kms[k] = kms.get(k, 0.0) + v
+    kms = {k: v / max(nc, 1) for k, v in kms.items()}
+    for a in alns:
+        a.timing(False)
+    last = steps - 1
+    rows = d_ress[last % n_streams].clone()
+    over = sum(a.pe_counts()[4] for a in alns)
+    pc = alns[last % n_streams].pe_counts()
+    value = 2.0 * n_pairs * steps / dt / 1e6
+    out = {"value": round(value, 3), "unit": "M mates/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "dtype": "u32 / i16",
+           "config": {"workload": "BASELINE configs[3] restated: %d pairs of 2 x %d bases per step on the index of the single-end leg, insert N(400,50), 3 %% damaged + 1 %% random "
+                                  "fragment-end mates, -p -a 250 -b 550, %d distinct resident batches rotated over %d workspaces / HIP streams, inputs and results resident "
+                                  "in HBM" % (n_pairs, L, n_batches, n_streams), "pairs_per_step": n_pairs, "read_len": L},
+           "step_ms": spread([ev[0].elapsed_time(e) for e in ev[1:]]),
+           "kernel_ms": {k: round(v, 3) for k, v in kms.items() if v}, "kernel_ms_serialized": {k: round(v, 3) for k, v in skm.items() if v},
+           "per_million_mates_ms_serialized": {k: round(v * 1e6 / (2 * n_pairs), 3) for k, v in skm.items() if v},
+           "rescue_requests_per_step": int(pc[0]), "rescues_beyond_capacity": int(over), "generate_s": round(t_gen, 2)}
+    # ---- counters of one serialized step -> device-layout bytes of the align kernels; k_sw: its windows, reads and result rows ----
+    copt, _ = salt_amd.AlnOpt.from_argv(["-p", "-a", "250", "-b", "550"], cfg["k"])
+    copt.collect_counters = 0 if args.no_counters else 1
+    alns[0].counters()
+    step(0, 0, copt)
+    torch.cuda.synchronize()
+    ctr = alns[0].counters()
+    qc = alns[0].queue_counts()
+    ctr["heavy_reads"] = qc[0]
+    out["queue_counts"] = dict(zip(("heavy_mates", "gapped_mates", "k_gap_items", "k_cigar_items"), [qc[0], qc[2], qc[5], qc[6]]))
+    spr = (L - cfg["k"]) // cfg["k"] + 1
+    try:
+        db = device_bytes(ctr, 2 * n_pairs, L, spr)
+    except KeyError:
+        db = {}
+    # a rescue reads its window once forward and (to the end point) once backward as 4-bit masks or 2-bit bases, the mate, and writes a 160-byte row
+    db["k_sw"] = int(pc[0]) * (2 * (550 + L) // 2 + L + 160)
+    cand = {k: v for k, v in skm.items() if k in db and v > 0}
+    dom = max(cand, key=lambda k: cand[k]) if cand else None
+    if dom:
+        ach = db[dom] / (skm[dom] / 1e3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom + (" (k_heavy_pe)" if dom == "k_heavy" else ""), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(db[dom]), "avg_launch_ms": round(skm[dom], 3),
+                           "all_kernels": {k: {"bytes_per_launch": int(v), "ms": round(skm.get(k, 0.0), 3),
+                                               "GBps": round(v / (skm[k] / 1e3) / 1e9, 1) if skm.get(k) else None} for k, v in db.items()},
+                           "timing": "HIP events on the launch stream over %d serialized steps (kernel_ms_serialized)" % n_serial,
+                           "counters": {k: int(v) for k, v in ctr.items() if k.startswith("d_")},
+                           "note": "k_sw is integer DP in registers (VALU-bound): its byte fraction is small by construction; profiles/r03 holds its issue rate"}
+        pf = os.path.join(ROOT, "profiles", "r03", "pmc_summary_pe_%s.json" % args.workload)
+        if os.path.exists(pf):
+            try:
+                prof = json.load(open(pf))
+                key = "k_heavy_pe" if dom == "k_heavy" else dom
+                out["roofline"]["traffic"] = prof.get("hbm_bytes_per_launch", {}).get(key)
+                out["roofline"]["issue_bound"] = prof.get("issue", {}).get(key)
+            except Exception:
+                pass
+    # ---- parity + CPU baseline on the first pe_check pairs of the last timed step's batch ----
+    nchk = min(args.pe_check, n_pairs)
+    if nchk > 0 and ora is not None:
+        s, f = batches[last % n_batches]
+        hs, ho = s[:2 * nchk * L].cpu().numpy(), f[:2 * nchk + 1].cpu().numpy().view(np.uint32)
+        cores, cpu_model = cpu_info()
+        oo = ora.opt()
+        t1 = time.perf_counter()
+        want = ora.align_pe(oo, hs, ho, opt.min_tlen, opt.max_tlen, n_threads=cores)
+        cdt = time.perf_counter() - t1
+        got = rows.cpu().numpy().view(salt_amd.RESULT_DTYPE)[:2 * nchk]
+        bad = oracle_py.compare(got, want, pe=True)
+        out["parity"] = {"path": "timed step", "checked_pairs": int(nchk), "mismatching_mates": int(len(bad)),
+                         "mapped_fraction": round(float((got["pos"] != 0xFFFFFFFF).mean()), 5),
+                         "rescued_mates": int(((want["seq_start"] != 0) | (want["seq_end"] != L - 1)).sum())}
+        out["cpu_baseline"] = {"value": round(2 * nchk / cdt / 1e6, 5), "unit": "M mates/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
+                               "sample": "the same %d pairs through the oracle's alnpe_core1 restatement on %d threads (%.1f s)" % (nchk, cores, cdt),
+                               "speedup_1gpu": round(value / (2 * nchk / cdt / 1e6), 1)}
+    del d_ress, batches, rows
+    torch.cuda.empty_cache()
+    return out
 
 
 def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log):

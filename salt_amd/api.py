@@ -361,7 +361,7 @@ def suffix_array(text, bits, gpu_device=None):
     return sa
 
 
-KERNELS = ("k_pack", "k_seed", "k_light", "k_heavy", "k_gap", "k_gapfin", "k_cigar")
+KERNELS = ("k_pack", "k_seed", "k_light", "k_heavy", "k_gap", "k_gapfin", "k_cigar", "k_pair", "k_sw", "k_pe_final")
 
 
 class GpuAligner:
@@ -477,12 +477,16 @@ class GpuAligner:
             done += m
         return res
 
-    def align_pe_resident(self, opt, index, n_pairs, max_read_len, d_seqs, d_offs, d_results, stream=0):
-        lib = gpu_lib()
+    def set_pac(self, index):
+        """Uploads the 2-bit genome the singleton rescue aligns against (once per device index; forks made afterwards share it)."""
         if not getattr(self, "_pac_set", False):
             pac, l_pac = index.pac()
-            _gpu_check(lib.salt_gpu_index_set_pac(self._ix, pac, l_pac))
+            _gpu_check(gpu_lib().salt_gpu_index_set_pac(self._ix, pac, l_pac))
             self._pac_set = True
+
+    def align_pe_resident(self, opt, index, n_pairs, max_read_len, d_seqs, d_offs, d_results, stream=0):
+        lib = gpu_lib()
+        self.set_pac(index)
         co, pe = opt._c(), opt._pe()
         _gpu_check(lib.salt_gpu_align_pe_resident(self._ws, ctypes.byref(co), ctypes.byref(pe), n_pairs, max_read_len, d_seqs, d_offs,
                                                   d_results, stream))
@@ -506,6 +510,7 @@ class GpuAligner:
         other.max_reads = max_reads or self.max_reads
         other.max_bases = max_bases or self.max_bases
         other.device = self.device
+        other._pac_set = getattr(self, "_pac_set", False)      # the 2-bit genome belongs to the device index, not to the workspace
         _gpu_check(gpu_lib().salt_gpu_ws_create(self._ix, other.max_reads, other.max_bases, ctypes.byref(other._ws)))
         return other
 

@@ -1357,7 +1357,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
         const uint32_t n_loc = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci; c_ctx_rej += cs.n_ctx_rej; c_ctx_rows += cs.n_ctx_rows;
         uint32_t call_best_n = INF, call_best_pos = 0;
-        if (ap.heavy_stop == 1) continue;
+        if (SALT_DIAG_VAL(ap.heavy_stop) == 1) continue;
         auto verify_all = [&](uint32_t n) {                   // cand_e[i] = min(mismatches, INF) of loci[i], loads of 128 candidates in flight
             if (L <= 120) verify_quads<8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
             else if (L <= 248) verify_quads<8, 8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
@@ -1366,7 +1366,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         };
         verify_all(n_loc);
         pc.stamp(SALT_CTR_T_VERIFY);
-        if (ap.heavy_stop == 2) continue;
+        if (SALT_DIAG_VAL(ap.heavy_stop) == 2) continue;
         {
             bool any = false; uint32_t bp = 0, bv = 0, nh = 0, a0s = 0;
             rule_unsorted<3, false>(loci, cand_e, n_loc, L, ix.ref_len, bound, any, bp, bv, nh, a0s, w.hit_pos[strand], w.hit_nd[strand]);
@@ -1383,7 +1383,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         pc.stamp(SALT_CTR_T_SCAN);
     }
 
-    if (ap.heavy_stop) return;
+    if (SALT_DIAG_VAL(ap.heavy_stop)) return;
     // ---- gapped pass (alnse.c:1089-1096): sequential per candidate, LV across lanes ----
     if (!too_short && !found[0] && !found[1]) {
         int maxd = PE ? 3 : (int)(L / 10);                    // alnse.c:1090 (SE) / alnse.c:1016-1028 (PE keeps 3)
@@ -2390,7 +2390,7 @@ void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm
     if (!ap.n_reads) return;
     hipMemsetAsync(qsub, 0, (size_t)QSEG * QSEG_STRIDE * 4, st);
     static const bool no_half = getenv("SALT_GPU_NO_LIGHT2") && atoi(getenv("SALT_GPU_NO_LIGHT2"));
-    if (!no_half && !ctr && !ap.dbg_stop && ap.spr <= (uint32_t)L2_SLOTS && ap.pg.nw8 <= 15) {          // reads of at most 120 bases: two per wave
+    if (!no_half && !ctr && !SALT_DIAG_VAL(ap.dbg_stop) && ap.spr <= (uint32_t)L2_SLOTS && ap.pg.nw8 <= 15) {          // reads of at most 120 bases: two per wave
         static const int wv = getenv("SALT_GPU_L2_WAVES") ? atoi(getenv("SALT_GPU_L2_WAVES")) : 2;
         if (wv == 1) hipLaunchKernelGGL(k_light2<1>, dim3((ap.n_reads + 1) / 2), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, qseg, qsub);
         else hipLaunchKernelGGL(k_light2<2>, dim3((ap.n_reads + 3) / 4), dim3(128), 0, st, ix, ap, pm, sai_c, sai_r, results, qseg, qsub);

@@ -60,10 +60,11 @@ struct salt_gpu_ws {
     int all_heavy = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
-    std::vector<hipEvent_t> ev;        // 8 per call: before k_pack, k_seed, k_light, k_heavy, k_gap, k_gapfin, k_cigar, after
+    std::vector<hipEvent_t> ev;        // EV_PER_CALL per call: before k_pack, k_seed, k_light, k_heavy, k_gap, k_gapfin, k_cigar, after; paired end: after k_pair, k_sw, k_pe_final (+ its k_cigar)
+    std::vector<uint8_t> ev_pe;        // the call was a paired-end one (its last three events are recorded)
     uint32_t n_timed = 0;
 };
-static const uint32_t MAX_TIMED = 256;
+static const uint32_t MAX_TIMED = 256, EV_PER_CALL = 12;
 
 static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
@@ -392,11 +393,14 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     { static const bool off = getenv("SALT_GPU_NO_UNIQUE") && atoi(getenv("SALT_GPU_NO_UNIQUE")); sp.resolve_unique = !off; }
     if (n_reads > ws->max_reads) return fail(SALT_E_CAPACITY, "more reads than the workspace holds");
     AlignParams ap; ap.pg = pg; ap.n_reads = n_reads; ap.spr = spr; ap.l_seed = o->l_seed; ap.max_locate = o->max_locate; ap.max_hits = o->max_hits;
-    ap.all_heavy = ws->all_heavy; ap.pe = pe; { const char *e = getenv("SALT_GPU_LIGHT_STOP"); ap.dbg_stop = e ? atoi(e) : 0; } { static const int hs = getenv("SALT_GPU_HEAVY_STOP") ? atoi(getenv("SALT_GPU_HEAVY_STOP")) : 0; ap.heavy_stop = hs; } ap.max_amb = pe ? 5u : 200u;
+    ap.all_heavy = ws->all_heavy; ap.pe = pe; ap.dbg_stop = 0; ap.heavy_stop = 0; ap.max_amb = pe ? 5u : 200u;
+#ifdef SALT_DIAG
+    { const char *e = getenv("SALT_GPU_LIGHT_STOP"); ap.dbg_stop = e ? atoi(e) : 0; } { static const int hs = getenv("SALT_GPU_HEAVY_STOP") ? atoi(getenv("SALT_GPU_HEAVY_STOP")) : 0; ap.heavy_stop = hs; }
+#endif
     if (pe && !ws->d_pe_scr) HIPCHK(hipMalloc((void **)&ws->d_pe_scr, (uint64_t)ws->heavy_blocks * PE_LOCI_CAP * 5));
     unsigned long long *ctr = o->collect_counters ? ws->d_ctr : nullptr;
     const bool timed = ws->timing && ws->n_timed < MAX_TIMED;
-    hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * 8] : nullptr;
+    hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * EV_PER_CALL] : nullptr;
     HIPCHK(hipMemsetAsync(ws->d_qctl, 0, 64, st));
     if (timed) HIPCHK(hipEventRecord(ev[0], st));
     launch_pack(pg, n_reads, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_pm, ws->d_tb, st);
@@ -410,7 +414,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     launch_heavy(ws->ix->view, ap, ws->d_pm, ws->d_sai_c, ws->d_sai_r,
                  static_cast<salt_result_t *>(d_results), ws->d_queue, ctr, ws->heavy_blocks, ws->gap_blocks, ws->d_lvtab,
                  gap_bufs_layout(ws->d_gap, ws->gcap, ws->d_qctl, nullptr), ws->d_queue + ws->max_reads, pe ? ws->d_pe_scr : nullptr, timed ? ev + 4 : nullptr, st);
-    if (timed) { HIPCHK(hipEventRecord(ev[7], st)); ++ws->n_timed; }
+    if (timed) { HIPCHK(hipEventRecord(ev[7], st)); ws->ev_pe[ws->n_timed] = 0; ++ws->n_timed; }
     HIPCHK(hipGetLastError());
     return SALT_OK;
 }
@@ -716,11 +720,8 @@ extern "C" int salt_gpu_align_pe_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
     HIPCHK(launch_fq_lines(ws->d_raw, n1, tile1, lines1, st));
     HIPCHK(launch_fq_lines(ws->d_raw + b2, n2, tile2, lines2, st));
     if (!ws->d_rec) HIPCHK(hipMalloc((void **)&ws->d_rec, (uint64_t)ws->max_reads * sizeof(FqRec)));
-    {
-        const uint32_t init[4] = { 0u, 0u, 0xFFFFFFFFu, 0u };
-        HIPCHK(hipMemcpyAsync(ws->d_tctl, init, sizeof init, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemsetAsync(ws->d_offs + n_rec, 0, 4, st));
-    }
+    HIPCHK(launch_fq_ctl_init(ws->d_tctl, st));
+    HIPCHK(hipMemsetAsync(ws->d_offs + n_rec, 0, 4, st));
     HIPCHK(launch_fq_parse_mate(ws->d_raw, 0u, lines1, n, 0u, ws->d_rec, ws->d_offs, ws->d_tctl, st));
     HIPCHK(launch_fq_parse_mate(ws->d_raw, (uint32_t)b2, lines2, n, 1u, ws->d_rec, ws->d_offs, ws->d_tctl, st));
     HIPCHK(launch_text_scan(ws->d_offs, n_rec + 1, ws->d_scan, ws->scan_bytes, st));
@@ -959,7 +960,8 @@ extern "C" int salt_gpu_ws_timing(salt_gpu_ws_t *ws, int enable)
     if (!ws) return fail(SALT_E_INVAL, "null argument");
     HIPCHK(hipSetDevice(ws->ix->device));
     if (enable && ws->ev.empty()) {
-        ws->ev.resize((size_t)MAX_TIMED * 8);
+        ws->ev.resize((size_t)MAX_TIMED * EV_PER_CALL);
+        ws->ev_pe.assign(MAX_TIMED, 0);
         for (auto &e : ws->ev) HIPCHK(hipEventCreate(&e));
     }
     ws->timing = enable != 0; ws->n_timed = 0;
@@ -973,9 +975,10 @@ extern "C" int salt_gpu_ws_kernel_ms(salt_gpu_ws_t *ws, double ms[SALT_N_KERNELS
     for (int k = 0; k < SALT_N_KERNELS; ++k) ms[k] = 0;
     *n_calls = ws->n_timed;
     for (uint32_t i = 0; i < ws->n_timed; ++i) {
-        hipEvent_t *ev = &ws->ev[(size_t)i * 8];
-        HIPCHK(hipEventSynchronize(ev[7]));
-        for (int k = 0; k < SALT_N_KERNELS; ++k) {
+        hipEvent_t *ev = &ws->ev[(size_t)i * EV_PER_CALL];
+        const int n_k = ws->ev_pe[i] ? SALT_N_KERNELS : 7;
+        HIPCHK(hipEventSynchronize(ev[n_k]));
+        for (int k = 0; k < n_k; ++k) {
             float a = 0;
             HIPCHK(hipEventElapsedTime(&a, ev[k], ev[k + 1]));
             ms[k] += a;
@@ -1252,11 +1255,14 @@ static int pe_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const sa
 {
     int rc = pe_prepare(ws, n_pairs, st);
     if (rc) return rc;
+    const uint32_t ti = ws->n_timed;
     rc = align_resident_impl(ws, o, 2 * n_pairs, max_len, d_seqs, d_offs, d_results, st, 1);
     if (rc) return rc;
+    hipEvent_t *ev = ws->n_timed == ti + 1 ? &ws->ev[(size_t)ti * EV_PER_CALL] : nullptr;      // the call above was timed: three more events
     HIPCHK(hipMemsetAsync(ws->d_pctl, 0, 32, st));
     launch_pair(n_pairs, pe->min_tlen, pe->max_tlen, (uint32_t)ws->ix->l_pac, static_cast<const uint32_t *>(d_offs), static_cast<salt_result_t *>(d_results),
                 ws->d_pairs, ws->d_req, ws->d_pctl, st);
+    if (ev) HIPCHK(hipEventRecord(ev[8], st));
     // rescue windows are as long as the insert-size window plus a mate (alnpe.c:213-252, 395-480), whatever -a / -b say
     const uint64_t l_pac = (uint64_t)ws->ix->l_pac;
     uint64_t max_win = (uint64_t)pe->max_tlen + max_len + 2;
@@ -1277,8 +1283,10 @@ static int pe_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const sa
     }
     launch_sw(ws->ix->view, ws->ix->d_pac, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_req, ws->d_pctl, ws->d_swres,
               ws->d_pctl + 1, ws->d_pctl + 4, ws->d_sw_scr, geom, max_len, st);
+    if (ev) HIPCHK(hipEventRecord(ev[9], st));
     launch_pe_final(ws->ix->view, PackGeom::make(max_len), n_pairs, ws->d_pm, static_cast<salt_result_t *>(d_results), ws->d_pairs, ws->d_swres, ws->d_lvtab,
                     ws->d_pcq, ws->d_pctl + 2, ws->heavy_blocks, st);
+    if (ev) { HIPCHK(hipEventRecord(ev[10], st)); ws->ev_pe[ti] = 1; }
     HIPCHK(hipGetLastError());
     return SALT_OK;
 }

@@ -4,6 +4,14 @@
 #include "../../include/salt_gpu.h"
 #include "salt_device.h"
 
+// Diagnostics that CHANGE results (phase timing by leaving kernels early) exist only in -DSALT_DIAG builds (`make DIAG=1`): the release
+// library has neither the environment switches nor the code paths behind them (tests/test_release_build.py greps for the names).
+#ifdef SALT_DIAG
+#define SALT_DIAG_VAL(x) (x)
+#else
+#define SALT_DIAG_VAL(x) 0
+#endif
+
 namespace salt {
 
 // Per-batch packed copies of the reads (k_pack), fixed stride per read so that no kernel waits for offs[]:
@@ -124,6 +132,7 @@ hipError_t text_warm();                                     // forces the load o
 size_t text_scan_bytes(uint64_t max_items);
 hipError_t launch_fq_count(const uint8_t *raw, uint64_t n, uint32_t *tile_cnt, void *tmp, size_t tmp_bytes, hipStream_t st);
 hipError_t launch_fq_lines(const uint8_t *raw, uint64_t n, const uint32_t *tile_off, uint32_t *line_start, hipStream_t st);
+hipError_t launch_fq_ctl_init(uint32_t *ctl, hipStream_t st);                       // ctl = { 0, 0, 0xFFFFFFFF, 0 }
 hipError_t launch_fq_parse(const uint8_t *raw, const uint32_t *line_start, uint32_t n_rec, FqRec *rec, uint32_t *offs, uint32_t *ctl,
                            void *tmp, size_t tmp_bytes, hipStream_t st);
 // one file of a pair: the records of the block at raw + base become rec[2 i + which] (offsets relative to raw), their lengths len[2 i + which];

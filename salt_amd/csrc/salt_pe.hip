@@ -324,8 +324,9 @@ __global__ void __launch_bounds__(64)
 k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
      const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
      uint32_t *__restrict__ overflow, uint8_t *__restrict__ scratch, uint32_t maxcol_bytes, uint32_t group_bytes, uint32_t seg, uint32_t mc_cols,
-     int dbg_skip_tb)
+     int dbg_skip_tb_arg)
 {
+    const int dbg_skip_tb = SALT_DIAG_VAL(dbg_skip_tb_arg);
     extern __shared__ __attribute__((aligned(16))) uint8_t sw_lds[];
     const uint32_t grp = threadIdx.x >> 3, lane = threadIdx.x & 7u;
     SwLds s;
@@ -553,7 +554,11 @@ void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, con
                PeSwRes *res, uint32_t *head, uint32_t *overflow, uint8_t *scratch, SwGeom g, uint32_t max_len, hipStream_t st)
 {
     const uint32_t seg = (max_len + 7) / 8;
+#ifdef SALT_DIAG
     const int skip_tb = getenv("SALT_GPU_SW_SKIP_TB") ? atoi(getenv("SALT_GPU_SW_SKIP_TB")) : 0;     // diagnostics: 1 = no traceback, 2 = phase clocks
+#else
+    const int skip_tb = 0;
+#endif
 #define SALT_LAUNCH_SW(V) hipLaunchKernelGGL(k_sw<V>, dim3(g.n_blocks), dim3(64), sw_lds_bytes(max_len), st, ix, pac, seqs, offs, req, pctl, res, head, \
                                              overflow, scratch, g.maxcol_bytes, g.group_bytes, seg, (V) ? SW_MC_COLS : 0u, skip_tb)
     switch (sw_seg_variant(max_len)) {

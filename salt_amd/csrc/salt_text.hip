@@ -367,12 +367,18 @@ hipError_t launch_fq_lines(const uint8_t *raw, uint64_t n, const uint32_t *tile_
     hipLaunchKernelGGL(k_fq_lines, dim3(tgrid(n_tiles * 256)), dim3(256), 0, st, raw, n, tile_off, line_start);
     return hipGetLastError();
 }
+// ctl = { 0, 0, 0xFFFFFFFF, 0 } by two memsets (no host buffer that would have to outlive the enqueue)
+hipError_t launch_fq_ctl_init(uint32_t *ctl, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(ctl, 0, 16, st);
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(ctl + 2, 0xFF, 4, st);
+}
 // records -> FqRec + lengths; offs[0..n_rec] = exclusive scan of the lengths (offs[n_rec] = all bases); ctl = { error bits, longest read, first bad record }
 hipError_t launch_fq_parse(const uint8_t *raw, const uint32_t *line_start, uint32_t n_rec, FqRec *rec, uint32_t *offs, uint32_t *ctl,
                            void *tmp, size_t tmp_bytes, hipStream_t st)
 {
-    const uint32_t init[4] = { 0u, 0u, 0xFFFFFFFFu, 0u };
-    hipError_t e = hipMemcpyAsync(ctl, init, sizeof init, hipMemcpyHostToDevice, st);
+    hipError_t e = launch_fq_ctl_init(ctl, st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(offs + n_rec, 0, 4, st);
     if (e != hipSuccess) return e;

@@ -339,6 +339,9 @@ struct TextRun {
     uint64_t written = 0; long reads_done = 0;
     int ready = 0; bool go = false;                         // workers that finished their set-up; the clock starts when all have
     std::atomic<bool> failed{ false };
+    // a chunk the device parser refused (SALT_E_INVAL: a multi-line record, a blank line, an empty read -- things kseq.h reads, query.c:103-239):
+    // the blocks before it are written, then the host parser takes over at fb_off (a record start: everything before it was strict 4-line FASTQ)
+    std::atomic<bool> fallback{ false }; uint64_t fb_off = 0;
 };
 
 static const uint64_t TEXT_SLACK = 1u << 20;             // how far past a chunk's end a worker looks for the next record start (longest record it can cut)
@@ -440,8 +443,9 @@ TextPlan::~TextPlan()
     for (char *b : sam_buf) if (b) salt_gpu_host_free(b);
 }
 
+// returns 0 = done, 1 = failed, 2 = *resume_off is where the host pipeline has to take over (everything before it is written)
 static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector<salt_gpu_index_t *> &gix, int n_gpus, TextPlan &P,
-                       const salt_aln_opt_t &ao, const salt_sam_opt_t &so, double t0)
+                       const salt_aln_opt_t &ao, const salt_sam_opt_t &so, double t0, uint64_t *resume_off)
 {
     TextRun R;
     R.fd = open(fn_reads, O_RDONLY);
@@ -481,7 +485,7 @@ static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector
             const double t_setup = now() - tw_start;
             for (;;) {
                 const uint64_t k = R.next_chunk.fetch_add(1);
-                if (k >= n_chunks || R.failed) break;
+                if (k >= n_chunks || R.failed || R.fallback) break;
                 // bytes [lo - 1, hi + slack) of the file: one byte of context in front (is `lo` a line start?), slack behind (where does the last record end?)
                 const uint64_t lo = k * R.chunk, hi = std::min(R.file_size, lo + R.chunk);
                 const uint64_t rd_lo = lo ? lo - 1 : 0, rd_hi = std::min(R.file_size, hi + TEXT_SLACK);
@@ -511,14 +515,26 @@ static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector
                     grc = salt_gpu_ws_create(gix[(size_t)(wk / n_workers_per_gpu)], ws_reads, (uint64_t)ws_reads * 160, &ws);
                     if (!grc) grc = salt_gpu_align_se_text(ws, &ao, &to, buf + beg2, end - beg2, &sam, &sam_bytes, &n_reads);
                 }
+                if (grc == SALT_E_INVAL) {
+                    // not strict 4-line FASTQ in this chunk: when the blocks before it are out, the host parser continues from its first record
+                    const std::string why = salt_gpu_last_error();
+                    std::unique_lock<std::mutex> lk(R.mu);
+                    R.cv.wait(lk, [&] { return R.failed || R.fallback || R.written == k; });
+                    if (!R.failed && !R.fallback) {
+                        R.fb_off = rd_lo + beg2; R.fallback = true;
+                        fprintf(stderr, "[salt] %s: the host parser takes over at byte %llu of %s\n", why.c_str(), (unsigned long long)R.fb_off, fn_reads);
+                    }
+                    lk.unlock(); R.cv.notify_all();
+                    break;
+                }
                 if (grc) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); set_failed(); break; }
                 t_gpu = t_gpu + (now() - tg0);
                 if (n_calls++ == 0) t_first = now() - tg0; else t_rest += now() - tg0;
                 // block k is written when block k - 1 has been
                 {
                     std::unique_lock<std::mutex> lk(R.mu);
-                    R.cv.wait(lk, [&] { return R.failed || R.written == k; });
-                    if (R.failed) break;
+                    R.cv.wait(lk, [&] { return R.failed || R.fallback || R.written == k; });
+                    if (R.failed || R.written != k) break;
                 }
                 double tw0 = now();
                 bool ok = true;
@@ -542,6 +558,7 @@ static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector
         });
     for (auto &w : workers) w.join();
     close(R.fd);
+    if (!R.failed && R.fallback) { *resume_off = R.fb_off; return 2; }
     const double dt = t_last.load() - t0;                   // first chunk claimed .. last SAM byte written (releasing the workspaces is not alignment time)
     fprintf(stderr, "[alnse_core]: total %lf sec escaped\n", dt);
     fprintf(stderr, "[salt] text path: %d worker(s), chunk %llu MiB, blocks written in turn; seconds summed over workers: read %.3f device call %.3f write %.3f "
@@ -609,8 +626,11 @@ static void pe_scan_file(const char *fn, int f, uint64_t pairs_per_chunk, PeScan
     S.cv.notify_all();
 }
 
+// returns 0 = done, 1 = failed, 2 = the host pipeline has to take over at resume_off[0 / 1] of the two files (everything before is written):
+// a chunk the device parser refused, a file whose line count is not a multiple of four (a trailing blank line is fine for kseq.h), or files
+// with different numbers of chunks -- the host parser reads what the reference reads and reports what it cannot
 static int run_pe_text(const char *fn1, const char *fn2, salt_index_t *ix, const std::vector<salt_gpu_index_t *> &gix, int n_gpus, TextPlan &P,
-                       const salt_aln_opt_t &ao, const salt_sam_opt_t &so, const salt_pe_opt_t &po, double t0)
+                       const salt_aln_opt_t &ao, const salt_sam_opt_t &so, const salt_pe_opt_t &po, double t0, uint64_t resume_off[2])
 {
     const int fd[2] = { open(fn1, O_RDONLY), open(fn2, O_RDONLY) };
     if (fd[0] < 0 || fd[1] < 0) { fprintf(stderr, "[query_open]: file %s open fail!\n", fd[0] < 0 ? fn1 : fn2); return 1; }
@@ -626,11 +646,20 @@ static int run_pe_text(const char *fn1, const char *fn2, salt_index_t *ix, const
     if (!P.alloc_ok) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); return 1; }
     const salt_text_opt_t to = { so.print_xa_cigar, so.print_nm_md, so.rg_id };
     PeScan S;
-    std::atomic<bool> failed{ false };
-    std::mutex wmu; std::condition_variable wcv; uint64_t written = 0; long pairs_done = 0;
+    std::atomic<bool> failed{ false }, fallback{ false };
+    std::mutex wmu; std::condition_variable wcv; uint64_t written = 0, fb_chunk = 0; long pairs_done = 0;
     std::atomic<uint64_t> next_chunk{ 0 };
     std::atomic<double> t_read{ 0 }, t_gpu{ 0 }, t_write{ 0 }, t_last{ t0 };
     auto set_failed = [&]() { failed = true; { std::lock_guard<std::mutex> lk(wmu); } wcv.notify_all(); { std::lock_guard<std::mutex> lk(S.mu); } S.cv.notify_all(); };
+    // chunk k cannot go through the device parser: once the blocks before it are out, everyone stops and the host pipeline continues there
+    auto fall_back = [&](uint64_t k, const std::string &why) {
+        {
+            std::unique_lock<std::mutex> lk(wmu);
+            wcv.wait(lk, [&] { return failed.load() || fallback.load() || written == k; });
+            if (!failed && !fallback) { fb_chunk = k; fallback = true; fprintf(stderr, "[salt] %s: the host parser takes over at pair chunk %llu\n", why.c_str(), (unsigned long long)k); }
+        }
+        wcv.notify_all(); { std::lock_guard<std::mutex> lk(S.mu); } S.cv.notify_all();
+    };
     std::thread scan1(pe_scan_file, fn1, 0, P.pairs_per_chunk, std::ref(S), std::ref(failed)), scan2(pe_scan_file, fn2, 1, P.pairs_per_chunk, std::ref(S), std::ref(failed));
     std::vector<std::thread> workers;
     for (int wk = 0; wk < P.n_workers; ++wk)
@@ -642,19 +671,20 @@ static int run_pe_text(const char *fn1, const char *fn2, salt_index_t *ix, const
             }
             for (;;) {
                 const uint64_t k = next_chunk.fetch_add(1);
-                uint64_t lo[2], hi[2]; bool end = false;
+                uint64_t lo[2], hi[2]; bool end = false, odd = false;
                 {   // chunk k of both files: its start and end offsets (or the news that there is no chunk k)
                     std::unique_lock<std::mutex> lk(S.mu);
-                    S.cv.wait(lk, [&] { return failed.load() || ((S.off[0].size() > k + 1 || S.done[0]) && (S.off[1].size() > k + 1 || S.done[1])); });
-                    if (failed) break;
-                    if (S.bad) { end = true; }
+                    S.cv.wait(lk, [&] { return failed.load() || fallback.load() || ((S.off[0].size() > k + 1 || S.done[0]) && (S.off[1].size() > k + 1 || S.done[1])); });
+                    if (failed || fallback) break;
+                    if (S.bad) odd = true;
                     else if (S.off[0].size() <= k + 1 || S.off[1].size() <= k + 1) {
                         // one file has no chunk k: fine if neither has (both finished with the same number of chunks), else the files differ
-                        end = true;
-                        if ((S.off[0].size() > k + 1) != (S.off[1].size() > k + 1)) S.bad = true;
+                        if ((S.off[0].size() > k + 1) != (S.off[1].size() > k + 1)) { S.bad = true; odd = true; }
+                        else end = true;
                     } else for (int f = 0; f < 2; ++f) { lo[f] = S.off[f][k]; hi[f] = S.off[f][k + 1]; }
                 }
                 if (end) break;
+                if (odd) { fall_back(k, "the read files are not two equally long runs of 4-line records"); break; }
                 const uint64_t n1 = hi[0] - lo[0], n2 = hi[1] - lo[1], b2 = (n1 + 64) & ~63ull;
                 if (b2 + n2 + 2 > P.in_cap) { fprintf(stderr, "[salt] a chunk of %llu pairs is larger than its buffer (records much longer than the file's first ones)\n", (unsigned long long)P.pairs_per_chunk); set_failed(); break; }
                 double tr0 = now();
@@ -671,12 +701,14 @@ static int run_pe_text(const char *fn1, const char *fn2, salt_index_t *ix, const
                 t_read = t_read + (now() - tr0);
                 const char *sam = nullptr; uint64_t sam_bytes = 0; uint32_t n_pairs = 0;
                 double tg0 = now();
-                if (salt_gpu_align_pe_text(ws, &ao, &po, &to, buf, m1, buf + b2, m2, &sam, &sam_bytes, &n_pairs)) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); set_failed(); break; }
+                const int grc = salt_gpu_align_pe_text(ws, &ao, &po, &to, buf, m1, buf + b2, m2, &sam, &sam_bytes, &n_pairs);
+                if (grc == SALT_E_INVAL) { fall_back(k, salt_gpu_last_error()); break; }
+                if (grc) { fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); set_failed(); break; }
                 t_gpu = t_gpu + (now() - tg0);
                 {
                     std::unique_lock<std::mutex> lk(wmu);
-                    wcv.wait(lk, [&] { return failed.load() || written == k; });
-                    if (failed) break;
+                    wcv.wait(lk, [&] { return failed.load() || fallback.load() || written == k; });
+                    if (failed || written != k) break;
                 }
                 double tw0 = now();
                 for (uint64_t w = 0; w < sam_bytes && ok; ) { const ssize_t r = write(1, sam + w, sam_bytes - w); if (r <= 0) ok = false; else w += (uint64_t)r; }
@@ -693,6 +725,10 @@ static int run_pe_text(const char *fn1, const char *fn2, salt_index_t *ix, const
     { std::lock_guard<std::mutex> lk(S.mu); } S.cv.notify_all();
     scan1.join(); scan2.join();
     close(fd[0]); close(fd[1]);
+    if (!failed && fallback) {
+        for (int f = 0; f < 2; ++f) resume_off[f] = S.off[f].size() > fb_chunk ? S.off[f][fb_chunk] : (S.off[f].empty() ? 0 : S.off[f].back());
+        return 2;
+    }
     if (!failed && (S.bad || S.records[0] != S.records[1])) {
         fprintf(stderr, "[salt] the two read files hold different numbers of reads (%llu / %llu) or broken records\n", (unsigned long long)S.records[0], (unsigned long long)S.records[1]);
         return 1;
@@ -786,13 +822,17 @@ int main(int argc, char **argv)
         printf("@PG\tID:snpaln\tPN:snpaln\tCL:\"%s\"\tDS:%d-%d-%d\tVN:0.1beta\n", cmd.c_str(), tmv->tm_year + 1900, tmv->tm_mon + 1, tmv->tm_mday);
         return true;
     };
+    bool header_out = false; uint64_t resume[2] = { 0, 0 };      // set when the text path hands the rest of the input to the host pipeline
     if (text_path && !pe) {
         fprintf(stderr, "%lf sec escaped.\n", now() - t0);
         if (!print_header()) return 1;
-        const int rc = run_se_text(fn_reads, ix, gix, n_gpus, plan, ao, so, now());
-        for (int i = n_gpus - 1; i >= 0; --i) salt_gpu_index_detach(gix[(size_t)i]);
-        salt_index_free(ix);
-        return rc;
+        const int rc = run_se_text(fn_reads, ix, gix, n_gpus, plan, ao, so, now(), &resume[0]);
+        if (rc != 2) {
+            for (int i = n_gpus - 1; i >= 0; --i) salt_gpu_index_detach(gix[(size_t)i]);
+            salt_index_free(ix);
+            return rc;
+        }
+        header_out = true;
     }
     if (pe && po.max_tlen == 0) {
         // N3: -b 0 = infer the insert-size window from the first batch (N_SEQS / 2 pairs), the mates aligned as single-end reads
@@ -826,10 +866,13 @@ int main(int argc, char **argv)
     if (text_path && pe) {
         fprintf(stderr, "%lf sec escaped.\n", now() - t0);
         if (!print_header()) return 1;
-        const int rc = run_pe_text(fn_reads, fn_mates, ix, gix, n_gpus, plan, ao, so, po, now());
-        for (int i = n_gpus - 1; i >= 0; --i) salt_gpu_index_detach(gix[(size_t)i]);
-        salt_index_free(ix);
-        return rc;
+        const int rc = run_pe_text(fn_reads, fn_mates, ix, gix, n_gpus, plan, ao, so, po, now(), resume);
+        if (rc != 2) {
+            for (int i = n_gpus - 1; i >= 0; --i) salt_gpu_index_detach(gix[(size_t)i]);
+            salt_index_free(ix);
+            return rc;
+        }
+        header_out = true;
     }
     // workers per GPU: each takes a batch through parse -> device -> format, so several batches overlap on the host
     const int WPG = n_threads / n_gpus >= 32 ? 4 : n_threads / n_gpus >= 12 ? 3 : 2;
@@ -848,8 +891,10 @@ int main(int argc, char **argv)
         if (!fp2) { fprintf(stderr, "[query_open]: file %s open fail!\n", fn_mates); return 1; }
         gzbuffer(fp2, 1 << 20);
     }
-
-    if (!print_header()) return 1;
+    if (header_out) {                                     // the text path wrote everything up to these offsets (plain files: a seek)
+        fflush(stdout);
+        if (gzseek(fp, (z_off_t)resume[0], SEEK_SET) < 0 || (pe && gzseek(fp2, (z_off_t)resume[1], SEEK_SET) < 0)) { fprintf(stderr, "[salt] cannot seek in the read files\n"); return 1; }
+    } else if (!print_header()) return 1;
 
     // ---- pipeline: reader -> per-GPU workers -> ordered writer ----
     std::mutex mu; std::condition_variable cv;
@@ -864,8 +909,9 @@ int main(int argc, char **argv)
     std::atomic<double> t_parse{ 0 }, t_gpu{ 0 }, t_fmt{ 0 };
     double t_write = 0, t_read = 0;
     std::thread reader([&]() {
-        RawReader rr(fp, !sniff_four_line(fn_reads));
-        std::unique_ptr<RawReader> rr2(pe ? new RawReader(fp2, !sniff_four_line(fn_mates)) : nullptr);
+        // (after a hand-over from the text path the head of the file says nothing about what follows: kseq's general reader)
+        RawReader rr(fp, header_out || !sniff_four_line(fn_reads));
+        std::unique_ptr<RawReader> rr2(pe ? new RawReader(fp2, header_out || !sniff_four_line(fn_mates)) : nullptr);
         const int per_batch = pe ? N_SEQS / 2 : N_SEQS;    // pairs per batch: N_SEQS mates (query_read_multiPairedSeqs, query.c:252-268)
         long seq_no = 0;
         for (;;) {

@@ -215,12 +215,14 @@ def make_reads_hash(genome, site, n_reads, L, seed=1, batch=0):
     return reads.reshape(-1), offs, start, rev
 
 
-def make_pairs_hash(genome, site, n_pairs, L, seed=2, batch=0, insert_mean=400, insert_sd=50):
+def make_pairs_hash(genome, site, n_pairs, L, seed=2, batch=0, insert_mean=400, insert_sd=50, damaged=0.0, orphan=0.0):
     """One batch of read pairs as tensors on genome.device, mates interleaved (2p, 2p + 1) the way salt_gpu_align_pe takes them:
     (codes uint8 [2 * n_pairs * L], offs int32 [2 * n_pairs + 1], start1 int64, start2 int64, flipped bool).  A fragment of
     insert_mean + insert_sd * z bases (z: sum of four uniforms, variance 1) starts uniformly over the concatenated genome; one mate is
     its first L bases as they lie, the other the reverse complement of its last L; `flipped` pairs swap the roles (the fragment came
-    from the reverse strand).  Every SNP site takes a random listed allele, 0.5 %/base substitutions; no indels, no N.
+    from the reverse strand).  Every SNP site takes a random listed allele, 0.5 %/base substitutions; no N.  `damaged` of the
+    fragment-end mates get 9 % substitutions and a 2-base deletion (seed-and-verify misses them and the Smith-Waterman rescue runs, as in
+    make_pairs), `orphan` of them are random bases; both 0 by default: no indels.
     start1 / start2: the leftmost genome position of mate 2p / 2p + 1."""
     import torch
     dev, n = genome.device, genome.numel()
@@ -242,6 +244,23 @@ def make_pairs_hash(genome, site, n_pairs, L, seed=2, batch=0, insert_mean=400, 
         return torch.where(err, ((frag.to(torch.int64) + 1 + hbits(seed, st(stream + 2), cell) % 3) & 3).to(torch.uint8), frag)
 
     left, right = window(f0, 5), window(f0 + isz - L, 8)
+    if damaged > 0 or orphan > 0:
+        u = hbits(seed, st(12), pid) % 100000
+        is_dmg, is_orph = u < int(damaged * 100000), (u >= int(damaged * 100000)) & (u < int((damaged + orphan) * 100000))
+        # damaged: the L + 2 bases that end where the fragment ends, two of them (at p, p + 1) deleted, 9 % substitutions on top
+        ar2 = torch.arange(L + 2, dtype=torch.int64, device=dev)
+        idx = (f0 + isz - L - 2)[:, None] + ar2[None, :]
+        wide = genome[idx]
+        m = site[idx]
+        cell = pid[:, None] * (L + 2) + ar2[None, :]
+        wide = torch.where(m != 0, _pick_table(dev)[m.to(torch.int64), hbits(seed, st(13), cell) % 12], wide)
+        err = (hbits(seed, st(14), cell) % 100) < 9
+        wide = torch.where(err, ((wide.to(torch.int64) + 1 + hbits(seed, st(15), cell) % 3) & 3).to(torch.uint8), wide)
+        p = 20 + hbits(seed, st(12), pid + n_pairs) % (L - 40)
+        take = ar[None, :] + 2 * (ar[None, :] >= p[:, None]).to(torch.int64)
+        dmg = torch.gather(wide, 1, take)
+        rnd = (hbits(seed, st(13), pid[:, None] * L + ar[None, :] + 7 * n_pairs * (L + 2)) % 4).to(torch.uint8)
+        right = torch.where(is_dmg[:, None], dmg, torch.where(is_orph[:, None], rnd, right))
     rc = lambda x: 3 - torch.flip(x, dims=[1])
     flipped = (hbits(seed, st(11), pid) % 2) == 1
     m1 = torch.where(flipped[:, None], rc(right), left)

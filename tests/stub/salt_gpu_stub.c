@@ -1,7 +1,7 @@
 /* tests/stub/salt_gpu_stub.c -- TEST INFRASTRUCTURE: a stand-in for libsalt_gpu.so without a GPU, so that the host side of the `salt`
  * binary (option handling, dealing of chunks to the workers of several "GPUs", ordered output) can be tested in the build container.
  * Device d is a label; the per-batch work is done by the CPU oracle (oracle/salt_oracle.c, linked in) and its own SAM writer.
- * Only the entry points the text path of `salt` uses are real; the others fail loudly.  Never shipped, never loaded by salt_amd/. */
+ * The entry points `salt` calls are real (text path and host pipeline); the others are absent.  Never shipped, never loaded by salt_amd/. */
 #include "../../include/salt_gpu.h"
 #include "../../oracle/salt_oracle.h"
 #include <pthread.h>
@@ -47,10 +47,71 @@ int salt_gpu_ws_reserve_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint64_
 void salt_gpu_ws_destroy(salt_gpu_ws_t *ws) { if (ws) { free(ws->sam); free(ws); } }
 int salt_gpu_host_alloc(uint64_t bytes, void **ptr) { *ptr = malloc(bytes); return *ptr ? SALT_OK : SALT_E_NOMEM; }
 void salt_gpu_host_free(void *ptr) { free(ptr); }
+/* so_result_t -> salt_result_t: binary CIGARs; the CIGARs of gapped alternative hits (the device delivers them for sam_add_xa, sam.c:216-225)
+ * by the oracle's Landau-Vishkin traceback on the hit's strand */
+static int cigar_bin(const char *txt, uint16_t *ops, int cap)
+{
+    int n = 0;
+    while (*txt) {
+        int len = 0; while (*txt >= '0' && *txt <= '9') len = len * 10 + (*txt++ - '0');
+        const int op = *txt == 'M' ? 0 : *txt == 'I' ? 1 : *txt == 'D' ? 2 : -1;
+        if (op < 0 || n >= cap) return -1;
+        ops[n++] = (uint16_t)((len << 4) | op); ++txt;
+    }
+    return n;
+}
+static void to_row(const so_index_t *ora, const uint8_t *seq, int L, const so_result_t *q, salt_result_t *r)
+{
+    memset(r, 0, sizeof *r);
+    r->pos = q->pos; r->strand = (uint8_t)q->strand; r->n_diff = q->n_diff; r->is_gap = q->is_gap; r->mapq = q->mapq;
+    r->b0 = q->b0; r->b1 = q->b1; r->seq_start = (uint16_t)q->seq_start; r->seq_end = (uint16_t)q->seq_end;
+    r->n_hits[0] = (uint8_t)q->n_hits[0]; r->n_hits[1] = (uint8_t)q->n_hits[1];
+    if (q->pos != 0xFFFFFFFFu) { const int n = cigar_bin(q->cigar, r->cigar, SALT_MAX_CIGAR_OPS); r->n_cigar = (uint8_t)(n > 0 ? n : 0); }
+    so_arrays_t a; so_index_arrays(ora, &a);
+    int h = 0;
+    for (int s = 0; s < 2; ++s)
+        for (int j = 0; j < q->n_hits[s]; ++j, ++h) {
+            r->hits[s][j].pos = q->hits[s][j].pos; r->hits[s][j].n_diff = q->hits[s][j].n_diff; r->hits[s][j].is_gap = q->hits[s][j].is_gap; r->hits[s][j].strand = (uint16_t)s;
+            if (!q->hits[s][j].is_gap) continue;
+            uint8_t rd[4096]; char txt[SO_CIGAR_MAX];
+            for (int i = 0; i < L; ++i) { const uint8_t c = s ? seq[L - 1 - i] : seq[i]; rd[i] = (uint8_t)(s && c < 4 ? 3 - c : c); }
+            if (so_ed_diff_cigar(a.ref, q->hits[s][j].pos, (uint32_t)L + 4, rd, (uint32_t)L, q->hits[s][j].n_diff, txt, sizeof txt) >= 0) {
+                const int n = cigar_bin(txt, r->hit_cigar[h], SALT_MAX_CIGAR_OPS); r->hit_n_cigar[h] = (uint8_t)(n > 0 ? n : 0);
+            }
+        }
+}
+static void opt_from(const salt_gpu_ws_t *ws, const salt_aln_opt_t *o, so_opt_t *so)
+{
+    so_opt_default(ws->ix->ora, so);
+    so->l_overlap = o->l_overlap; so->max_seed = o->max_seed; so->max_locate = o->max_locate; so->seed_only_ref = o->seed_only_ref;
+}
+/* the host pipeline's per-batch calls (gzip, pipes, multi-line records, and what the text path hands over) */
 int salt_gpu_align_se(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint32_t n, const uint8_t *s, const uint32_t *f, salt_result_t *r)
-{ (void)ws; (void)o; (void)n; (void)s; (void)f; (void)r; return fail("salt_gpu_align_se is not part of the stub"); }
+{
+    if (getenv("SALT_STUB_NO_HOST")) return fail("salt_gpu_align_se is not part of the stub");
+    so_opt_t so; opt_from(ws, o, &so);
+    for (uint32_t i = 0; i < n; ++i) {
+        const int L = (int)(f[i + 1] - f[i]);
+        if (L <= 0 || L >= 4096) return fail("read length outside the stub's range");
+        so_result_t q; so_align_se1(ws->ix->ora, &so, s + f[i], L, &q, NULL);
+        to_row(ws->ix->ora, s + f[i], L, &q, r + i);
+        int n_amb = 0; for (int b = 0; b < L; ++b) n_amb += s[f[i] + b] > 3;
+        r[i].skipped = n_amb > 200;                          /* alnse.c:1328: the record is never built */
+    }
+    return SALT_OK;
+}
 int salt_gpu_align_pe(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const salt_pe_opt_t *pe, uint32_t n, const uint8_t *s, const uint32_t *f, salt_result_t *r)
-{ (void)ws; (void)o; (void)pe; (void)n; (void)s; (void)f; (void)r; return fail("salt_gpu_align_pe is not part of the stub"); }
+{
+    if (getenv("SALT_STUB_NO_PE") || getenv("SALT_STUB_NO_HOST")) return fail("salt_gpu_align_pe is not part of the stub");
+    so_opt_t so; opt_from(ws, o, &so);
+    for (uint32_t p = 0; p < n; ++p) {
+        const int l0 = (int)(f[2 * p + 1] - f[2 * p]), l1 = (int)(f[2 * p + 2] - f[2 * p + 1]);
+        if (l0 <= 0 || l1 <= 0 || l0 >= 4096 || l1 >= 4096) return fail("read length outside the stub's range");
+        so_result_t q[2]; so_align_pe1(ws->ix->ora, &so, pe->min_tlen, pe->max_tlen, s + f[2 * p], l0, s + f[2 * p + 1], l1, q);
+        to_row(ws->ix->ora, s + f[2 * p], l0, &q[0], r + 2 * p); to_row(ws->ix->ora, s + f[2 * p + 1], l1, &q[1], r + 2 * p + 1);
+    }
+    return SALT_OK;
+}
 
 static uint8_t nt4(int c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
 

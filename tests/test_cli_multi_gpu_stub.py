@@ -48,7 +48,7 @@ def test_salt_gpus_n_deals_chunks_and_keeps_the_input_order(case, gpus, stub_tre
 
 
 def test_salt_reports_a_device_error_and_exits_nonzero(stub_tree, tmp_path):
-    """Paired end goes through the host pipeline, which the stub does not serve: the device error must reach stderr and the exit code."""
+    """A device error must reach stderr and the exit code (the stub refuses paired-end calls here)."""
     d, prefix = stub_tree
     env = dict(os.environ, SALT_STUB_PREFIX=prefix, SALT_STUB_NO_PE="1", LD_LIBRARY_PATH=str(d / "lib"))
     out = subprocess.run([str(d / "bin" / "salt"), "-p", prefix, os.path.join(LAMBDA, "reads_pe_1.fq"), os.path.join(LAMBDA, "reads_pe_2.fq")],
@@ -84,3 +84,71 @@ def test_salt_pe_text_path_cuts_both_files_by_record_count(case, gpus, stub_tree
     f3.write_bytes(b"\n".join(lines[:-5]) + b"\n")
     bad = subprocess.run([str(d / "bin" / "salt")] + read_cases()[case] + [prefix, f1, str(f3)], capture_output=True, env=env)
     assert bad.returncode == 1 and b"different numbers of reads" in bad.stderr, bad.stderr[-300:]
+
+
+def _strip(out):
+    return b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+
+
+@pytest.mark.parametrize("gpus", [1, 8])
+def test_salt_text_path_hands_over_to_the_host_parser_where_the_input_stops_being_four_line(gpus, stub_tree, tmp_path):
+    """the text path is chosen from the first 256 KiB; a later multi-line record, a blank line or a blank last line is
+    something kseq.h reads (query.c:103-239), so the chunk the device parser refuses and everything behind it goes to the host
+    pipeline -- after the blocks before it are out, once, in order.  Eight device labels: every label takes chunks."""
+    d, prefix = stub_tree
+    want = open(os.path.join(LAMBDA, "expect_se_default.sam"), "rb").read()
+    recs = open(os.path.join(LAMBDA, "reads_se.fq"), "rb").read().split(b"\n")
+    recs = [recs[i:i + 4] for i in range(0, len(recs) - 3, 4)]
+    assert len(recs) == 2000
+    out = []
+    for i, r in enumerate(recs):
+        if i == 1500:                                           # far behind the sniffed head: sequence and quality wrapped over three lines
+            out += [r[0], r[1][:40], r[1][40:77], r[1][77:], r[2], r[3][:15], r[3][15:]]
+        elif i == 1700:
+            out += [b""] + r                                    # a blank line between records
+        else:
+            out += r
+    fq = tmp_path / "late_multiline.fq"
+    fq.write_bytes(b"\n".join(out) + b"\n\n\n")                 # and blank lines at the end
+    log = str(tmp_path / "stub.log")
+    env = dict(os.environ, SALT_STUB_PREFIX=prefix, SALT_STUB_LOG=log, SALT_CHUNK_BYTES="9000", LD_LIBRARY_PATH=str(d / "lib"))
+    res = subprocess.run([str(d / "bin" / "salt")] + read_cases()["se_default"] + ["-t", "8", "--gpus", str(gpus), prefix, str(fq)],
+                         capture_output=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stderr[-600:]
+    assert b"the host parser takes over" in res.stderr
+    assert _strip(res.stdout) == want
+    rows = [l.split() for l in open(log).read().splitlines()]
+    assert sum(int(r[1]) for r in rows) > 1000                  # the text path did the part in front of the first odd record (chunks behind it may have run and been dropped)
+    if gpus == 8:
+        assert {int(r[0]) for r in rows} == set(range(8))
+    # only a blank last line: everything through the text path but the last chunk
+    fq2 = tmp_path / "blank_tail.fq"
+    fq2.write_bytes(open(os.path.join(LAMBDA, "reads_se.fq"), "rb").read() + b"\n")
+    res = subprocess.run([str(d / "bin" / "salt")] + read_cases()["se_default"] + ["-t", "8", "--gpus", str(gpus), prefix, str(fq2)],
+                         capture_output=True, env=env, timeout=300)
+    assert res.returncode == 0 and _strip(res.stdout) == want, res.stderr[-600:]
+
+
+def test_salt_pe_text_path_neither_hangs_nor_shifts_pairs_on_odd_files(stub_tree, tmp_path):
+    """a mate file with a trailing blank line (line count not a multiple of four) or mate files of different lengths used to
+    leave workers waiting for a block that never came.  Now the chunk where it shows goes to the host pipeline: a blank tail is read
+    as the reference reads it, unequal files end with the error -- and nothing hangs (timeout)."""
+    d, prefix = stub_tree
+    want = open(os.path.join(LAMBDA, "expect_pe_default.sam"), "rb").read()
+    f1, f2 = os.path.join(LAMBDA, "reads_pe_1.fq"), os.path.join(LAMBDA, "reads_pe_2.fq")
+    env = dict(os.environ, SALT_STUB_PREFIX=prefix, SALT_CHUNK_BYTES="3000", LD_LIBRARY_PATH=str(d / "lib"))
+    args = [str(d / "bin" / "salt")] + read_cases()["pe_default"] + ["-t", "16", "--gpus", "8", prefix]
+    tail = tmp_path / "blank_tail.fq"
+    tail.write_bytes(open(f2, "rb").read() + b"\n")
+    for _ in range(3):                                         # the old hang needed a particular interleaving
+        res = subprocess.run(args + [f1, str(tail)], capture_output=True, env=env, timeout=300)
+        assert res.returncode == 0, res.stderr[-600:]
+        assert _strip(res.stdout) == want
+    lines = open(f2, "rb").read().split(b"\n")
+    short = tmp_path / "short.fq"
+    short.write_bytes(b"\n".join(lines[:-41]) + b"\n")          # ten records less
+    for _ in range(3):
+        res = subprocess.run(args + [f1, str(short)], capture_output=True, env=env, timeout=300)
+        assert res.returncode == 1 and b"different numbers of reads" in res.stderr, res.stderr[-600:]
+        got = _strip(res.stdout)
+        assert want.startswith(got[:len(got) - len(got) % 1])   # whatever came out is a prefix of the right answer: no shifted pairs

@@ -7,20 +7,23 @@ Per kernel and counter: mean over dispatches of the counter value (summed over t
 skipping the first two dispatches of each kernel (bench warm-up).
   hbm_bytes_per_launch = (FETCH_SIZE + WRITE_SIZE) x 1024, raw: for the gather shapes of these kernels tools/ubench/gather shows
       what FETCH_SIZE reports per random load (gather_rate.txt), so no x2 streaming correction is applied.
-  issue = per kernel: VALU / SALU / VMEM / LDS wave-instructions per launch, the clock the launch ran at
-      (GRBM_GUI_ACTIVE / 8 XCDs / duration), and valu_issue_frac = VALU x 2 cycles / (1024 SIMDs x duration x clock): the share of
-      the chip's vector issue slots the kernel used (MI355X_MICROARCH.md: a wave64 VALU instruction occupies its SIMD-32 for 2 cycles)."""
+  issue = per kernel: VALU / SALU / VMEM / LDS wave-instructions per launch and valu_issue_frac = VALU x 2 cycles / (1024 SIMDs x
+      duration x 2.4 GHz): the share of the chip's vector issue slots the kernel used (MI355X_MICROARCH.md: a wave64 VALU instruction
+      occupies its SIMD-32 for 2 cycles; 2.4 GHz is the peak clock, so the fraction is a lower bound).
+Profile runs are made with `bench.py --no-counters`: no launch of a counter-collecting kernel variant is among the dispatches."""
 import csv
 import json
 import sys
 from collections import defaultdict
 
-KERNELS = ("k_pack", "k_seed", "k_light", "k_heavy_pe", "k_heavy", "k_gapfin", "k_gap", "k_cigar", "k_pair", "k_sw", "k_pe_final", "k_sam", "k_fastq")
+KERNELS = ("k_pack", "k_seed", "k_light2", "k_light", "k_queue_pack", "k_heavy_pe_big", "k_heavy_pe", "k_heavy_big", "k_heavy", "k_gapfin", "k_gap", "k_cigar",
+           "k_pair", "k_sw", "k_pe_final", "k_fq_count", "k_fq_lines", "k_fq_parse", "k_fq_codes", "k_sam_len", "k_sam_write", "k_heads")
+CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md: peak engine clock; issue fractions are quoted against it (a lower bound of the true fraction)
 
 
 def short(name):
-    if "salt::k_light2<" in name or "salt::k_light2(" in name:     # the two-reads-per-wave variant of k_light; bench.py reports both as k_light
-        return "k_light"
+    """Every kernel under its own name: k_light2 (two reads per wave, what the timed steps run) and k_light (one read per wave: paired-end
+    mates, long reads, steps with the access counters on) are different kernels and are never folded together."""
     for k in KERNELS:
         if "salt::%s(" % k in name or "salt::%s<" % k in name:       # plain and templated kernels
             return k
@@ -76,11 +79,10 @@ def main():
         if "SQ_INSTS_VALU" not in v or k not in dur:
             continue
         ms = dur[k]
-        clock = v.get("GRBM_GUI_ACTIVE", 0) / 8.0 / (ms / 1e3) / 1e9 if v.get("GRBM_GUI_ACTIVE") else None      # GHz (reads high on launches shorter than ~0.3 ms)
-        ghz = min(clock, 2.4) if clock else 2.4
+        ghz = CLOCK_GHZ
         issue[k] = {"valu_wave_insts": int(v["SQ_INSTS_VALU"]), "salu_wave_insts": int(v.get("SQ_INSTS_SALU", 0)), "vmem_rd_wave_insts": int(v.get("SQ_INSTS_VMEM_RD", 0)),
                     "lds_wave_insts": int(v.get("SQ_INSTS_LDS", 0)), "waves": int(v.get("SQ_WAVES", 0)), "kernel_ms_rocprof": round(ms, 4),
-                    "clock_GHz_from_GRBM": round(clock, 3) if clock else None,
+                    "wait_any_frac": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 3) if v.get("SQ_WAIT_ANY") and v.get("SQ_WAVE_CYCLES") else None,
                     "valu_issue_frac": round(v["SQ_INSTS_VALU"] * 2 / (1024 * ms / 1e3 * ghz * 1e9), 4)}
     json.dump({"workload": workload, "kernel_ms_rocprof": dur, "per_kernel_mean": summary, "hbm_bytes_per_launch": traffic, "issue": issue}, open(out_path, "w"), indent=1)
     print(json.dumps({"traffic": traffic, "issue": {k: v["valu_issue_frac"] for k, v in issue.items()}}))
