@@ -715,7 +715,7 @@ __device__ __attribute__((noinline)) CandStats build_candidates(W &w)
     uint32_t n = 0, ns = 0, n_ctx_rows = 0;                   // rows that count against the cap; rows stored (ns < n only with the context table)
     bool full = false;
     const gp_u32x4 c_ctx = as_global(a.c_ctx);
-    const bool use_ctx = !PE && a.c_ctx != nullptr && !gap_mode;
+    const bool use_ctx = a.c_ctx != nullptr && !gap_mode;             // paired end too: a rejected row counts against both caps like any row (alnse.c:523-533)
     for (uint32_t i = 0; i < n_list[0] && !full; ++i) {
         const uint32_t sp = w.u.sai.sp[0][i], off = w.u.sai.off[0][i] & 0x7FFFFFFFu;
         const bool located = (w.u.sai.off[0][i] >> 31) != 0;                  // k_seed resolved this one-row interval to its position
@@ -783,14 +783,23 @@ __device__ __attribute__((noinline)) CandStats build_candidates(W &w)
     n_loci_out += n;
     n = ns;                                                   // what the passes below see
     WSYNC();
+    bool in_lds = pe_in_lds;
+    if (PE && !in_lds && n <= (uint32_t)MAXLOC) {
+        // the rows that were ENUMERATED outgrew the LDS list, the rows the context table let through do not: bring them in (one trip now
+        // instead of two or three per verify / rule pass)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        for (uint32_t i = lane; i < n; i += 64) w.loci[i] = loci[i];
+        loci = w.loci; in_lds = true;
+        WSYNC();
+    }
     pc.stamp(SALT_CTR_T_LOCATE);
-    if (!a.finish) return CandStats{ n, n_sa_c, n_sa_r, n_loci_out, pe_in_lds ? 1u : 0u, n_ctx_rej, n_ctx_rows };
+    if (!a.finish) return CandStats{ n, n_sa_c, n_sa_r, n_loci_out, in_lds ? 1u : 0u, n_ctx_rej, n_ctx_rows };
     sort_loci(loci, n);
     WSYNC();
     pc.stamp(SALT_CTR_T_SORT);
     const uint32_t n_out = dedup_loci(loci, n, gap_mode, L, ix.ref_len);
     pc.stamp(SALT_CTR_T_DEDUP);
-    return CandStats{ n_out, n_sa_c, n_sa_r, n_loci_out, pe_in_lds ? 1u : 0u, n_ctx_rej, n_ctx_rows };
+    return CandStats{ n_out, n_sa_c, n_sa_r, n_loci_out, in_lds ? 1u : 0u, n_ctx_rej, n_ctx_rows };
 }
 
 template <bool PE, class W>
@@ -1392,7 +1401,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         if (lanes_fit && g.cap && n_cand_nogap > 0) {
             // k_gap / k_gapfin / k_cigar take it from here: both strands' located rows go to the pool as they are (unsorted,
             // duplicates included -- rule_unsorted needs neither).  Strand 1's rows are still in `loci` (unless the context table
-            // thinned them: the gapped pass needs every row); strand 0's are located again.
+            // thinned them: the gapped pass needs every row); strand 0's are located again.  (Single end and paired end alike.)
             uint32_t slot = 0;
             if (lane == 0) slot = atomicAdd(&g.gctl[2], 1u);
             slot = (uint32_t)__shfl((int)slot, 0);
@@ -1402,7 +1411,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                 for (int k = 0; k < 2 && ok; ++k) {
                     const int strand = 1 - k;
                     uint32_t n = n_loc_s[1];
-                    if (strand == 0 || (!PE && ix.c_ctx != nullptr)) {
+                    if (strand == 0 || ix.c_ctx != nullptr) {
                         WSYNC();
                         const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, false, nullptr, 0 }, w);
                         if (PE) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }

@@ -866,13 +866,13 @@ extern "C" int salt_gpu_polish_sw(salt_gpu_polish_t *p, const uint8_t *codes, co
     PCHK(hipMalloc((void **)&d_req, (uint64_t)n_items * sizeof(PeSwReq))); PCHK(hipMemcpy(d_req, h_req.data(), (uint64_t)n_items * sizeof(PeSwReq), hipMemcpyHostToDevice));
     PCHK(hipMalloc((void **)&d_res, (uint64_t)n_items * sizeof(PeSwRes)));
     SwGeom geom = sw_geom(max_len, max_len, p->n_blocks / 8u);
-    if ((uint64_t)geom.n_blocks * 8u > (uint64_t)n_items + 7u) geom.n_blocks = (n_items + 7u) / 8u;
-    PCHK(hipMalloc((void **)&d_scr, (uint64_t)geom.n_blocks * 8 * geom.group_bytes));
-    const uint32_t ctl[3] = { n_items, 0, 0 };
-    PCHK(hipMalloc((void **)&d_ctl, 12)); PCHK(hipMemcpy(d_ctl, ctl, 12, hipMemcpyHostToDevice));
+    sw_geom_limit(geom, (n_items + 7u) / 8u);
+    PCHK(hipMalloc((void **)&d_scr, sw_scratch_bytes(geom)));
+    const uint32_t ctl[4] = { n_items, 0, 0, 0 };            // requests, k_sw's head, overflow count, k_swtb's head
+    PCHK(hipMalloc((void **)&d_ctl, 16)); PCHK(hipMemcpy(d_ctl, ctl, 16, hipMemcpyHostToDevice));
     IndexView v; memset(&v, 0, sizeof v);
     v.ref_len = (uint32_t)p->l_pac;                            // k_sw's range check; mode 2 reads the 2-bit genome only
-    launch_sw(v, p->d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 1, d_ctl + 2, d_scr, geom, max_len, nullptr);
+    launch_sw(v, p->d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 1, d_ctl + 3, d_ctl + 2, d_scr, geom, max_len, nullptr);
     PCHK(hipGetLastError());
     PCHK(hipDeviceSynchronize());
     uint32_t h_ctl[3];
@@ -1055,15 +1055,15 @@ extern "C" int salt_gpu_diag_ssw(uint32_t n_cases, const uint8_t *aware, const u
     HIPCHK(hipMalloc((void **)&d_res, (uint64_t)n_cases * sizeof(PeSwRes)));
     uint64_t diag_max_win = 1;
     for (uint32_t i = 0; i < n_cases; ++i) if (ref_offs[i + 1] - ref_offs[i] > diag_max_win) diag_max_win = ref_offs[i + 1] - ref_offs[i];
+    if (diag_max_len > SALT_MAX_READ_LEN) return fail(SALT_E_INVAL, "read longer than SALT_MAX_READ_LEN");
     SwGeom geom = sw_geom(diag_max_len, diag_max_win, 1);
-    geom.n_blocks = blocks;
-    HIPCHK(hipMalloc((void **)&d_scr, (uint64_t)blocks * 8 * geom.group_bytes));
-    const uint32_t ctl[3] = { n_cases, 0, 0 };
-    HIPCHK(hipMalloc((void **)&d_ctl, 12)); HIPCHK(hipMemcpy(d_ctl, ctl, 12, hipMemcpyHostToDevice));
+    geom.n_blocks = blocks; geom.tb_blocks = blocks;
+    HIPCHK(hipMalloc((void **)&d_scr, sw_scratch_bytes(geom)));
+    const uint32_t ctl[4] = { n_cases, 0, 0, 0 };             // requests, k_sw's head, overflow count, k_swtb's head
+    HIPCHK(hipMalloc((void **)&d_ctl, 16)); HIPCHK(hipMemcpy(d_ctl, ctl, 16, hipMemcpyHostToDevice));
     IndexView v; memset(&v, 0, sizeof v);
     v.ref = d_ref; v.ref_len = (uint32_t)n_sym;
-    if (diag_max_len > SALT_MAX_READ_LEN) return fail(SALT_E_INVAL, "read longer than SALT_MAX_READ_LEN");
-    launch_sw(v, d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 1, d_ctl + 2, d_scr, geom, diag_max_len, nullptr);
+    launch_sw(v, d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 1, d_ctl + 3, d_ctl + 2, d_scr, geom, diag_max_len, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     std::vector<PeSwRes> h_res(n_cases);
@@ -1268,12 +1268,9 @@ static int pe_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const sa
     uint64_t max_win = (uint64_t)pe->max_tlen + max_len + 2;
     if (max_win > l_pac + 1) max_win = l_pac + 1;
     SwGeom geom = sw_geom(max_len, max_win, ws->sw_blocks);
-    {   // one group (8 lanes) per rescue in flight; rescues are a few per cent of the mates, so a small batch does not need the full grid --
-        // nor its scratch (8 GiB at 2 x 150: a quarter of a second of hipMalloc at the first call of every workspace)
-        const uint32_t enough = n_pairs / 96u < 256u ? 256u : n_pairs / 96u;
-        if (geom.n_blocks > enough && ws->sw_scr_bytes < (uint64_t)geom.n_blocks * 8 * geom.group_bytes) geom.n_blocks = enough;
-    }
-    const uint64_t need = (uint64_t)geom.n_blocks * 8 * geom.group_bytes;
+    // one group (8 lanes) per rescue in flight; rescues are a few per cent of the mates, so a small batch does not need the full grid
+    sw_geom_limit(geom, n_pairs / 96u < 256u ? 256u : n_pairs / 96u);
+    const uint64_t need = sw_scratch_bytes(geom);
     if (need > ws->sw_scr_bytes) {
         HIPCHK(hipStreamSynchronize(st));
         hipFree(ws->d_sw_scr); ws->d_sw_scr = nullptr; ws->sw_scr_bytes = 0;
@@ -1282,7 +1279,7 @@ static int pe_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const sa
         ws->sw_scr_bytes = need;
     }
     launch_sw(ws->ix->view, ws->ix->d_pac, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_req, ws->d_pctl, ws->d_swres,
-              ws->d_pctl + 1, ws->d_pctl + 4, ws->d_sw_scr, geom, max_len, st);
+              ws->d_pctl + 1, ws->d_pctl + 7, ws->d_pctl + 4, ws->d_sw_scr, geom, max_len, st);   // pctl: requests, k_sw head, CIGAR items + head, overflow, (diagnostics), k_swtb head
     if (ev) HIPCHK(hipEventRecord(ev[9], st));
     launch_pe_final(ws->ix->view, PackGeom::make(max_len), n_pairs, ws->d_pm, static_cast<salt_result_t *>(d_results), ws->d_pairs, ws->d_swres, ws->d_lvtab,
                     ws->d_pcq, ws->d_pctl + 2, ws->heavy_blocks, st);

@@ -84,25 +84,29 @@ size_t lv_table_bytes();                // per-block LV traceback table (global 
 // ---- paired end (salt_pe.hip) ----
 static const uint32_t SW_MAX_SEG = 64;              // stripes: reads up to 512 bases
 static const uint32_t SW_BAND_W = 1100;             // ints per banded-SW row buffer (band width <= 548)
-// Global scratch of one 8-lane k_sw group, sized per call from the batch (sw_geom): per-column maxima of the longest rescue
-// window the insert-size options allow (2 B per column), the three banded-SW rows, and the traceback's direction bytes
-// (3 x read length x band cells, up to the widest band the row buffers hold).
+// Scratch of one Smith-Waterman launch, sized per call from the batch (sw_geom): k_sw's 8-lane groups keep the per-column maxima of the
+// longest rescue window the insert-size options allow (2 B per column); k_swtb's groups three band rows and one direction byte per cell for
+// alignments whose band outgrows its LDS (bands up to SW_BAND_W cells).
 struct SwGeom {
-    uint32_t maxcol_bytes, group_bytes, n_blocks;
+    uint32_t maxcol_bytes, n_blocks;           // k_sw
+    uint32_t tb_group_bytes, tb_blocks;        // k_swtb
 };
 SwGeom sw_geom(uint32_t max_len, uint64_t max_window, uint32_t cus);
+void sw_geom_limit(SwGeom &g, uint32_t blocks);            // small batches: no more blocks than that (and their scratch)
+uint64_t sw_scratch_bytes(const SwGeom &g);
 struct PeSwReq { uint32_t start, end, mate; uint8_t strand, aware; uint16_t pad; };          // mate: index of the rescued mate (2p or 2p+1);
                                                                                             // aware: 0 plain, 1 SNP-aware, 2 polish matrix; pad bit 0: score only
 struct PeSwRes { int32_t score1, score2, ref_begin, ref_end, read_begin, read_end; uint32_t start, strand; uint16_t n_cigar, ok; uint16_t cigar[SALT_MAX_CIGAR_OPS]; };
 struct PePair { uint32_t req0; uint8_t n_req; uint8_t rescued[2]; uint8_t pad; };             // requests req0 .. req0+n_req-1, in the order tried
 void launch_pair(uint32_t n_pairs, uint32_t min_tlen, uint32_t max_tlen, uint32_t l_pac, const uint32_t *offs, salt_result_t *res,
                  PePair *pairs, PeSwReq *req, uint32_t *pctl, hipStream_t st);
-// overflow: counts rescues this build cannot finish as the reference would (window beyond the scratch, band beyond SW_BAND_W);
-// the caller turns a non-zero count into an error instead of returning rows that differ from the reference's
+// k_sw (scores, end and begin points) then k_swtb (banded traceback -> CIGAR); head / tb_head: the two kernels' queue heads (zeroed by the caller).
+// overflow: counts rescues this build cannot finish as the reference would (window beyond the scratch, band beyond SW_BAND_W, more than
+// SALT_MAX_CIGAR_OPS operations); the caller turns a non-zero count into an error instead of returning rows that differ from the reference's
 void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, const uint32_t *offs, const PeSwReq *req, const uint32_t *pctl,
-               PeSwRes *res, uint32_t *head, uint32_t *overflow, uint8_t *scratch, SwGeom g, uint32_t max_len, hipStream_t st);
-static const uint32_t SW_MAX_BLOCKS_PER_CU = 8;    // k_sw blocks per CU at most (LDS allows 8 for 150-bp mates)
-static const uint64_t SW_SCRATCH_TOTAL = 8ull << 30;   // the grid shrinks before its groups' scratch passes 8 GiB
+               PeSwRes *res, uint32_t *head, uint32_t *tb_head, uint32_t *overflow, uint8_t *scratch, SwGeom g, uint32_t max_len, hipStream_t st);
+static const uint32_t SW_MAX_BLOCKS_PER_CU = 16;   // one-wave blocks per CU at most
+static const uint64_t SW_SCRATCH_TOTAL = 2ull << 30;   // k_swtb's grid shrinks before its groups' global scratch passes 2 GiB
 uint32_t sw_blocks_per_cu(uint32_t max_len);
 void launch_pe_final(const IndexView &ix, const PackGeom &pg, uint32_t n_pairs, const uint32_t *pm, salt_result_t *res, const PePair *pairs,
                      const PeSwRes *sw, void *lvtab, uint32_t *citems, uint32_t *cctl, uint32_t n_blocks, hipStream_t st);   // cctl[0] count, cctl[1] head

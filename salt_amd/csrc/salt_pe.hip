@@ -228,105 +228,142 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
     if (dbg_cols && lane == 0) { atomicAdd(dbg_cols, n_cols); atomicAdd(dbg_cols + 1, n_lazy); }
 }
 
-// banded_sw (ssw.c:549-727) by one lane; h_b/e_b/h_c and the direction bytes live in this group's global scratch.
-// Returns the number of ops written to cig (len<<4|op), 0 on a traceback error (as the reference: no CIGAR), -1 when the
-// band, the direction bytes or the CIGAR (SALT_MAX_CIGAR_OPS) would not fit (the caller counts that as an overflow).
-// lrows / lref: this group's LDS copies -- three rows of SW_LDS_BAND ints for bands that fit, and the alignment's reference
-// symbols (one per byte) when refLen <= SW_LDS_REF; the global scratch serves wider bands.  Inside a row every value a cell needs
-// again (the left neighbour's H, the upper-left H, this cell's E / F directions) stays in a register: the only loads are the two
-// upper-row values, so the lane never waits for its own stores to come back from memory.
-static constexpr int SW_LDS_BAND = 128, SW_LDS_REF = 512;
-__device__ int sw_banded(const IndexView &ix, const uint8_t *pac, int aware, uint32_t ref0, const uint8_t *read, int refLen, int readLen,
-                         int score, int band_width, int32_t *ghb, int32_t *geb, int32_t *ghc, int32_t *lrows, const uint8_t *lref,
-                         int8_t *direction, uint32_t dir_cap, uint16_t *cig, int cig_cap)
+// ---------------------------------------------------------------------------------------------
+// The banded traceback of ssw_align (banded_sw, ssw.c:549-727), re-designed for eight lanes per alignment (k_swtb below).
+//
+// What the reference computes: a banded DP over the slice [ref_begin, ref_end] x [read_begin, read_end] the two striped passes found,
+// row by row (i = read position), the band [i - w, i + w] of every row kept in arrays indexed from the band's left end, three
+// direction codes per cell; w doubles until the best cell reaches the alignment's score; then a walk back from the last cell.
+// Here a row is ONE step of the group: lane t takes cell beg + t (rows wider than eight cells go in chunks with a carry), E comes from
+// the row above element-wise, and the in-row recurrence F[j] = max(H[j-1] - go, F[j-1] - ge) is a max-plus prefix scan over the lanes
+// (DPP row shifts): opening a gap from an H that is itself an F never beats extending that F (go > ge), so
+//     F[j] = max( -(j - beg + 1) ge ,  max_{j' < j} ( A[j'] - go - (j - 1 - j') ge ) ),   A = max(E+, diagonal)  (H without its F term)
+// gives the same F -- and the same "opened or extended" direction bit, taken from the finished neighbours (H[j-1] - go > F[j-1] - ge).
+// The three direction codes of a cell (ssw.c: 1 diagonal, 2 / 3 from E extended / opened, 4 / 5 from F extended / opened) are one
+// nibble: which of {diagonal, E, F} made H, E's bit, F's bit -- a byte per cell in the cell order of the reference's direction
+// array, in LDS for the bands mate rescue produces (a few cells wide), in global scratch beyond.  Kept exactly: the band arrays with
+// their indices (rows shifted by one once i > w), the cells the reference zeroes at the band's right edge (also when that edge is
+// the slice's end and the cell above is real), band doubling with the running maximum, the walk and its run-length bookkeeping.
+// ---------------------------------------------------------------------------------------------
+struct TbGeom { uint32_t read_b, ref_b, row_w, dir_b, group_b; };       // per-group LDS: read bases | reference symbols | 3 rows x row_w ints | direction bytes
+static constexpr int TB_NEG = -(1 << 28);
+
+// one pass at band half-width bw; returns the largest H of the pass (all 8 lanes).  RL / DL: rows / direction bytes in LDS (else global)
+template <bool RL, bool DL>
+__device__ __forceinline__ int tb_band_pass(int32_t *__restrict__ hb, int32_t *__restrict__ eb, int32_t *__restrict__ hc, uint8_t *__restrict__ dir,
+                                            const uint8_t *rd, const uint8_t *rf, const IndexView &ix, const uint8_t *pac, const int aware,
+                                            const uint32_t ref0, const int refLen, const int readLen, const int bw)
 {
-#define SET_U(u, w, i, j) { int x_ = (i) - (w); x_ = x_ > 0 ? x_ : 0; (u) = (j) - x_ + 1; }
-#define SET_D(u, w, i, j, p) { int x_ = (i) - (w); x_ = x_ > 0 ? x_ : 0; x_ = (j) - x_; (u) = x_ * 3 + p; }
-    const int go = 3, ge = 1;
-    int i, j, e = 0, f, temp1, temp2, l, max = 0, width, width_d;
-    int8_t *direction_line = direction;
-    const bool ref_in_lds = lref != nullptr && refLen <= SW_LDS_REF;
-    do {
-        width = band_width * 2 + 3; width_d = band_width * 2 + 1;
-        if (width > (int)SW_BAND_W || (uint64_t)width_d * (uint64_t)readLen * 3u + 8u > dir_cap) return -1;
-        const bool in_lds = lrows != nullptr && width <= SW_LDS_BAND;
-        int32_t *hb = in_lds ? lrows : ghb, *eb = in_lds ? lrows + SW_LDS_BAND : geb, *hc = in_lds ? lrows + 2 * SW_LDS_BAND : ghc;
-        for (j = 1; j < width - 1; ++j) hb[j] = 0;
-        for (i = 0; i < readLen; ++i) {
-            int beg = 0, end = refLen - 1, u = 0, edge;
-            j = i - band_width; beg = beg > j ? beg : j;
-            j = i + band_width; end = end < j ? end : j;
-            edge = end + 1 < width - 1 ? end + 1 : width - 1;
-            f = hb[0] = eb[0] = hb[edge] = eb[edge] = hc[0] = 0;
-            direction_line = direction + width_d * i * 3;
-            const uint32_t rc = read[i];
-            int hc_left = 0, hb_diag = 0;                        // hc[b] (= hc[0] for the first cell) and hb[d]
-            if (beg <= end) { int d; SET_U(d, band_width, i - 1, beg - 1); hb_diag = hb[d]; }
-            for (j = beg; j <= end; ++j) {
-                int e1, f1, de, df, dh;
-                SET_U(u, band_width, i, j); SET_U(e, band_width, i - 1, j);
-                SET_D(de, band_width, i, j, 0); SET_D(df, band_width, i, j, 1); SET_D(dh, band_width, i, j, 2);
-                const int hb_up = hb[e], eb_up = eb[e];
-                temp1 = i == 0 ? -go : hb_up - go;
-                temp2 = i == 0 ? -ge : eb_up - ge;
-                const int eb_u = temp1 > temp2 ? temp1 : temp2;
-                eb[u] = eb_u;
-                const int8_t dir_e = temp1 > temp2 ? 3 : 2;
-                direction_line[de] = dir_e;
-                temp1 = hc_left - go; temp2 = f - ge;
-                f = temp1 > temp2 ? temp1 : temp2;
-                const int8_t dir_f = temp1 > temp2 ? 5 : 4;
-                direction_line[df] = dir_f;
-                e1 = eb_u > 0 ? eb_u : 0; f1 = f > 0 ? f : 0;
-                temp1 = e1 > f1 ? e1 : f1;
-                const uint32_t sym = ref_in_lds ? (uint32_t)lref[j] : ref_symbol(ix, pac, aware, ref0 + (uint32_t)j);
-                temp2 = hb_diag + sw_score(aware, sym, rc);
-                const int hc_u = temp1 > temp2 ? temp1 : temp2;
-                hc[u] = hc_u;
-                if (hc_u > max) max = hc_u;
-                direction_line[dh] = temp1 <= temp2 ? (int8_t)1 : (e1 > f1 ? dir_e : dir_f);
-                hc_left = hc_u; hb_diag = hb_up;                 // next cell: b = this u, d = this e
+    const int lane = (int)(threadIdx.x & 7u);
+    const int go = 3, ge = 1;                                                   // aln.h:137-138
+    const int width = 2 * bw + 3, width_d = 2 * bw + 1;
+    auto gsync = [&]() {                                                        // the group's lanes hand rows to each other
+        if (RL && DL) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }       // global rows: stores drained before the loads
+    };
+    for (int t = 1 + lane; t < width - 1; t += 8) hb[t] = 0;
+    int mx = 0;
+    for (int i = 0; i < readLen; ++i) {
+        const int x = i - bw > 0 ? i - bw : 0, xp = i - 1 - bw > 0 ? i - 1 - bw : 0;        // left ends of this row's and the upper row's band
+        const int beg = x, end = refLen - 1 < i + bw ? refLen - 1 : i + bw;
+        const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
+        gsync();
+        if (lane == 0) { hb[0] = 0; eb[0] = 0; hb[edge] = 0; eb[edge] = 0; hc[0] = 0; }
+        gsync();
+        const uint32_t rc = rd[i];
+        uint8_t *drow = dir + (size_t)i * (size_t)width_d;
+        const bool one = end - beg < 8;                                          // the whole row in one step: no copy through hc
+        int carry = TB_NEG, prevH = 0, prevF = 0;                                // cell beg - 1: hc[0] = 0, f = 0
+        for (int c0 = beg; c0 <= end; c0 += 8) {
+            const int j = c0 + lane;
+            const bool act = j <= end;
+            const int u = j - x + 1, e = j - xp + 1;
+            int hb_e = 0, eb_e = 0, hb_d = 0; uint32_t sym = 0;
+            if (act) { hb_e = hb[e]; eb_e = eb[e]; hb_d = hb[e - 1]; sym = rf ? (uint32_t)rf[j] : ref_symbol(ix, pac, aware, ref0 + (uint32_t)j); }
+            const int t1 = i == 0 ? -go : hb_e - go, t2 = i == 0 ? -ge : eb_e - ge;
+            const int E = t1 > t2 ? t1 : t2, e_open = t1 > t2 ? 1 : 0;
+            const int e1 = E > 0 ? E : 0;
+            const int diag = hb_d + sw_score(aware, sym, rc);
+            const int A = e1 > diag ? e1 : diag;
+            // max-plus scan: inclusive prefix maximum of g = A - go + j ge over the group's lanes, then one lane down, then the chunks before
+            int inc = act ? A - go + j * ge : TB_NEG;
+            { const int t = dpp_row_shr<1>(inc); if (lane >= 1) inc = inc > t ? inc : t; }
+            { const int t = dpp_row_shr<2>(inc); if (lane >= 2) inc = inc > t ? inc : t; }
+            { const int t = dpp_row_shr<4>(inc); if (lane >= 4) inc = inc > t ? inc : t; }
+            int exc = dpp_row_shr<1>(inc);
+            if (lane == 0) exc = TB_NEG;
+            exc = exc > carry ? exc : carry;
+            const int f_init = -(j - beg + 1) * ge, f_open = exc - (j - 1) * ge;
+            const int f = f_init > f_open ? f_init : f_open;
+            const int f1 = f > 0 ? f : 0;
+            const int tt = e1 > f1 ? e1 : f1;
+            const int H = tt > diag ? tt : diag;
+            int Hl = dpp_row_shr<1>(H), fl = dpp_row_shr<1>(f);
+            if (lane == 0) { Hl = prevH; fl = prevF; }
+            const int f_opened = (Hl - go > fl - ge) ? 1 : 0;
+            const int hsel = tt <= diag ? 0 : (e1 > f1 ? 1 : 2);
+            if (act) {
+                eb[u] = E;
+                if (one) hb[u] = H; else hc[u] = H;                              // (every read of hb in this step is already issued)
+                drow[j - x] = (uint8_t)(hsel | (e_open << 2) | (f_opened << 3));
+                mx = mx > H ? mx : H;
             }
-            for (j = 1; j <= u; ++j) hb[j] = hc[j];
+            if (!one) {
+                const int last = (int)((threadIdx.x & 56u) + 7u);
+                const int c7 = __shfl(inc, last); carry = carry > c7 ? carry : c7;
+                prevH = __shfl(H, last); prevF = __shfl(f, last);
+            }
         }
-        band_width *= 2;
-    } while (max < score);
-    band_width /= 2;
-    i = readLen - 1; j = refLen - 1; e = 0; l = 0; f = max = 0; temp2 = 2;
-    uint16_t c[SALT_MAX_CIGAR_OPS + 4];
-    while (i > 0) {
-        SET_D(temp1, band_width, i, j, temp2);
-        switch (direction_line[temp1]) {
-        case 1: --i; --j; temp2 = 2; direction_line -= width_d * 3; f = 0; break;
-        case 2: --i; temp2 = 0; direction_line -= width_d * 3; f = 1; break;
-        case 3: --i; temp2 = 2; direction_line -= width_d * 3; f = 1; break;
-        case 4: --j; temp2 = 1; f = 2; break;
-        case 5: --j; temp2 = 2; f = 2; break;
-        default: return 0;
+        if (!one) {
+            gsync();
+            const int u_last = end - x + 1;
+            for (int t = 1 + lane; t <= u_last; t += 8) hb[t] = hc[t];
         }
-        if (f == max) ++e;
-        else { ++l; if (l > SALT_MAX_CIGAR_OPS) return -1; c[l - 1] = (uint16_t)(e << 4 | max); max = f; e = 1; }
     }
-    if (f == 0) { ++l; if (l > SALT_MAX_CIGAR_OPS) return -1; c[l - 1] = (uint16_t)((e + 1) << 4); }
-    else { l += 2; if (l > SALT_MAX_CIGAR_OPS) return -1; c[l - 2] = (uint16_t)(e << 4 | f); c[l - 1] = 16; }
-    if (l > cig_cap) return -1;
-    for (i = 0; i < l; ++i) cig[i] = c[l - 1 - i];
-    return l;
-#undef SET_U
-#undef SET_D
+    gsync();
+    return dpp_max8(mx);
+}
+
+// the walk back (ssw.c:650-713) by the group's first lane: (len << 4 | op) runs into cig[], first operation first.
+// Returns their number, 0 on a walk that leaves the direction bytes (the reference's "Trace back error": no CIGAR), -1 when more than cap.
+__device__ __forceinline__ int tb_walk(const uint8_t *dir, const int64_t n_dir, const int refLen, const int readLen, const int bw, uint16_t *stack, uint16_t *cig, const int cap)
+{
+    const int width_d = 2 * bw + 1;
+    int i = readLen - 1, j = refLen - 1, run = 0, n = 0, op = 0, cur = 0, from = 2;        // from: the entry of the cell to read (0 E, 1 F, 2 H)
+    while (i > 0) {
+        const int x = i - bw > 0 ? i - bw : 0;
+        const int64_t at = (int64_t)i * width_d + (j - x);
+        if (at < 0 || at >= n_dir) return 0;
+        const uint32_t cell = dir[at];
+        const uint32_t hsel = cell & 3u, e_open = (cell >> 2) & 1u, f_opened = (cell >> 3) & 1u;
+        const int code = from == 0 ? 2 + (int)e_open : from == 1 ? 4 + (int)f_opened : hsel == 0 ? 1 : hsel == 1 ? 2 + (int)e_open : 4 + (int)f_opened;
+        if (code == 1) { --i; --j; from = 2; op = 0; }                          // diagonal: M
+        else if (code == 2) { --i; from = 0; op = 1; }                          // E extended: I, stay in E
+        else if (code == 3) { --i; from = 2; op = 1; }                          // E opened: I, back to H
+        else if (code == 4) { --j; from = 1; op = 2; }                          // F extended: D, stay in F
+        else { --j; from = 2; op = 2; }                                         // F opened: D
+        if (op == cur) ++run;
+        else { if (n >= cap + 3) return -1; stack[n++] = (uint16_t)(run << 4 | cur); cur = op; run = 1; }
+    }
+    if (n + 2 > cap + 3) return -1;
+    if (op == 0) stack[n++] = (uint16_t)((run + 1) << 4);                       // row 0's cell joins a run of M ...
+    else { stack[n++] = (uint16_t)(run << 4 | op); stack[n++] = 16; }           // ... or is "1M" of its own
+    if (n > cap) return -1;
+    for (int t = 0; t < n; ++t) cig[t] = stack[n - 1 - t];
+    return n;
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_sw: persistent groups of 8 lanes pull rescue requests
+// k_sw: persistent groups of 8 lanes pull rescue requests -- the two striped passes of ssw_align (scores, end and begin points, second
+// best).  A request that needs its CIGAR leaves with ok = 2 and is finished by k_swtb.
 // ---------------------------------------------------------------------------------------------
 template <int SEG>                     // 0: stripe rows in LDS (any read length); > 0: in registers, segLen <= SEG
 __global__ void __launch_bounds__(64)
 k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
      const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
-     uint32_t *__restrict__ overflow, uint8_t *__restrict__ scratch, uint32_t maxcol_bytes, uint32_t group_bytes, uint32_t seg, uint32_t mc_cols,
-     int dbg_skip_tb_arg)
+     uint32_t *__restrict__ overflow, uint8_t *__restrict__ scratch, uint32_t maxcol_bytes, uint32_t seg, int dbg_arg)
 {
-    const int dbg_skip_tb = SALT_DIAG_VAL(dbg_skip_tb_arg);
+    const int dbg = SALT_DIAG_VAL(dbg_arg);                      // diagnostics build only: 2 = phase clocks, 4 / 8 = column counts of the forward / reverse pass
     extern __shared__ __attribute__((aligned(16))) uint8_t sw_lds[];
     const uint32_t grp = threadIdx.x >> 3, lane = threadIdx.x & 7u;
     SwLds s;
@@ -338,23 +375,18 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
         s.H[0] = s.H[1] = s.E = s.Hmax = nullptr;
         s.read = sw_lds + (size_t)grp * ((8u * seg + 15u) & ~15u);
     }
-    // windows of up to mc_cols columns keep their per-column maxima in LDS (no global store inside the column loop)
-    uint16_t *const mc_lds = reinterpret_cast<uint16_t *>(sw_lds + 8u * ((8u * seg + 15u) & ~15u)) + (size_t)grp * mc_cols;
-    // banded traceback (register variants): three band rows and the alignment's reference symbols per group
-    uint8_t *const tb_base = sw_lds + 8u * ((8u * seg + 15u) & ~15u) + 8u * mc_cols * 2u + (size_t)grp * (3u * SW_LDS_BAND * 4u + SW_LDS_REF);
-    int32_t *const tb_rows = SEG ? reinterpret_cast<int32_t *>(tb_base) : nullptr;
-    uint8_t *const tb_ref = SEG ? tb_base + 3u * SW_LDS_BAND * 4u : nullptr;
     const uint32_t n_req = pctl[0];
-    uint8_t *my = scratch + ((size_t)blockIdx.x * 8 + grp) * group_bytes;
-    uint16_t *maxColumn = reinterpret_cast<uint16_t *>(my);
-    int32_t *hb = reinterpret_cast<int32_t *>(my + maxcol_bytes), *eb = hb + SW_BAND_W, *hc = eb + SW_BAND_W;
-    int8_t *direction = reinterpret_cast<int8_t *>(hc + SW_BAND_W);
-    const uint32_t dir_cap = group_bytes - maxcol_bytes - 3u * SW_BAND_W * 4u;
+    uint16_t *maxColumn = reinterpret_cast<uint16_t *>(scratch + ((size_t)blockIdx.x * 8 + grp) * maxcol_bytes);
+    // The wave pulls eight requests at a time, one per group, and leaves as a whole (a uniform exit): groups that drew a number past the
+    // end sit the round out.  (Groups pulling one request each and leaving one by one is the shape this loop had; with hipcc 7.2 the kernel
+    // then never finished once the traceback had moved out of it -- tools/dbg/sw_hang.hip reproduces that -- so the exit is kept uniform.)
     for (;;) {
-        uint32_t it = 0;
-        if (lane == 0) it = atomicAdd(head, 1u);
-        it = (uint32_t)__shfl((int)it, 0, 8);
-        if (it >= n_req) break;
+        uint32_t base = 0;
+        if (threadIdx.x == 0) base = atomicAdd(head, 8u);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n_req) break;
+        const uint32_t it = base + grp;
+        if (it >= n_req) continue;
         const PeSwReq rq = req[it];
         PeSwRes out; out.score1 = 0; out.score2 = 0; out.ref_begin = -1; out.ref_end = 0; out.read_begin = -1; out.read_end = 0; out.n_cigar = 0; out.ok = 0; out.start = rq.start; out.strand = rq.strand;
         const uint32_t off = offs[rq.mate], L = offs[rq.mate + 1] - off;
@@ -363,7 +395,7 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
         const bool sane = rq.start < ix.ref_len && refLen > 0;
         const bool fits = sane && (uint64_t)refLen * 2u <= maxcol_bytes && L <= seg * 8u;
         if (sane && !fits && lane == 0) atomicAdd(overflow, 1u);
-        if (fits) {
+        if (fits && !(dbg & 32)) {
             // the mate's bases on the requested strand
             for (uint32_t i = lane; i < L; i += 8) {
                 uint32_t c = rq.strand ? seqs[off + (L - 1 - i)] : seqs[off + i];
@@ -371,65 +403,119 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
                 s.read[i] = (uint8_t)(c > 4 ? 4 : c);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-            const unsigned long long t0 = dbg_skip_tb & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
+            const unsigned long long t0 = dbg & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
             int max1, end_ref1, end_read1;
-            const bool mc_in_lds = SEG != 0 && (uint32_t)refLen <= mc_cols;
             auto fwd = [&](int q) -> uint32_t { return s.read[q]; };
             if (SEG == 0) sw_word_pass(ix, pac, aware, s, rq.start, 0, refLen, (int)L, fwd, 0xFFFF, maxColumn, max1, end_ref1, end_read1);
-            else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, aware, rq.start, 0, refLen, (int)L, fwd, 0xFFFF, maxColumn, mc_in_lds ? mc_lds : (uint16_t *)nullptr,
-                                                   max1, end_ref1, end_read1, (dbg_skip_tb & 4) ? overflow + 1 : nullptr);
+            else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, aware, rq.start, 0, refLen, (int)L, fwd, 0xFFFF, maxColumn, (uint16_t *)nullptr,
+                                                   max1, end_ref1, end_read1, (dbg & 4) ? overflow + 1 : nullptr);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
             // second best outside +-maskLen around the end column (ssw.c:529-542), maskLen = L/2 >= 15 or none
             int score2 = 0;
             const int maskLen = (int)L / 2;
-            if (maskLen >= 15) {
+            if (maskLen >= 15 && !(dbg & 64)) {
                 int edge = end_ref1 - maskLen > 0 ? end_ref1 - maskLen : 0;
-                for (int i = (int)lane; i < edge; i += 8) { int v = mc_in_lds ? mc_lds[i] : maxColumn[i]; score2 = score2 > v ? score2 : v; }
+                for (int i = (int)lane; i < edge; i += 8) { int v = maxColumn[i]; score2 = score2 > v ? score2 : v; }
                 edge = end_ref1 + maskLen > refLen ? refLen : end_ref1 + maskLen;
-                for (int i = edge + (int)lane; i < refLen; i += 8) { int v = mc_in_lds ? mc_lds[i] : maxColumn[i]; score2 = score2 > v ? score2 : v; }
-                for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(score2, o, 8); score2 = score2 > t ? score2 : t; }
+                for (int i = edge + (int)lane; i < refLen; i += 8) { int v = maxColumn[i]; score2 = score2 > v ? score2 : v; }
+                score2 = dpp_max8(score2);
             }
-            if (rq.pad & 1u) {                                       // score only (polish's first pass over every hit: ssw_align flag 0)
-                out.score1 = max1; out.score2 = score2; out.ref_end = end_ref1; out.read_end = end_read1;
-                if (lane == 0) res[it] = out;
-                continue;
+            out.score1 = max1; out.score2 = score2; out.ref_end = end_ref1; out.read_end = end_read1;
+            if (!(rq.pad & 1u) && !(dbg & 16)) {                     // (pad bit 0: score only -- polish's first pass over every hit: ssw_align flag 0)
+                const unsigned long long t1 = dbg & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
+                // reverse pass from the end point to find the beginning (ssw.c:817-830)
+                int max2, beg_ref, beg_read_rev;
+                auto rev = [&](int q) -> uint32_t { return s.read[end_read1 - q]; };
+                if (SEG == 0) sw_word_pass(ix, pac, aware, s, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, max2, beg_ref, beg_read_rev);
+                else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, aware, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, (uint16_t *)nullptr,
+                                                       max2, beg_ref, beg_read_rev, (dbg & 8) ? overflow + 1 : nullptr);
+                out.ref_begin = beg_ref; out.read_begin = end_read1 - beg_read_rev;
+                out.ok = 2;                                          // the banded traceback is k_swtb's
+                if ((dbg & 2) && lane == 0) {                        // phase clocks (10 ns ticks)
+                    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+                    atomicAdd(overflow + 1, (uint32_t)(t1 - t0)); atomicAdd(overflow + 2, (uint32_t)(t2 - t1));
+                }
             }
-            const unsigned long long t1 = dbg_skip_tb & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
-            // reverse pass from the end point to find the beginning (ssw.c:817-830)
-            int max2, beg_ref, beg_read_rev;
-            auto rev = [&](int q) -> uint32_t { return s.read[end_read1 - q]; };
-            if (SEG == 0) sw_word_pass(ix, pac, aware, s, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, max2, beg_ref, beg_read_rev);
-            else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, aware, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, (uint16_t *)nullptr,
-                                                   max2, beg_ref, beg_read_rev, (dbg_skip_tb & 8) ? overflow + 1 : nullptr);
-            const int read_begin = end_read1 - beg_read_rev;
-            out.score1 = max1; out.score2 = score2; out.ref_begin = beg_ref; out.ref_end = end_ref1; out.read_begin = read_begin; out.read_end = end_read1;
-            const unsigned long long t2 = dbg_skip_tb & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
-            // banded traceback for the CIGAR (ssw.c:837-848)
-            int n_cig = 0;
-            if (SEG != 0 && !(dbg_skip_tb & 1)) {                      // the alignment's reference symbols, by all 8 lanes
-                const int rfl = end_ref1 - beg_ref + 1;
-                if (rfl > 0 && rfl <= SW_LDS_REF)
-                    for (int t = (int)lane; t < rfl; t += 8) tb_ref[t] = (uint8_t)ref_symbol(ix, pac, aware, rq.start + (uint32_t)beg_ref + (uint32_t)t);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-            }
-            if (lane == 0) {
-                const int rfl = end_ref1 - beg_ref + 1, rdl = end_read1 - read_begin + 1;
-                int bw = rfl - rdl; bw = (bw < 0 ? -bw : bw) + 1;
-                if (dbg_skip_tb & 1) { out.cigar[0] = (uint16_t)(rdl << 4); n_cig = 1; }
-                else if (rfl > 0 && rdl > 0)
-                    n_cig = sw_banded(ix, pac, aware, rq.start + (uint32_t)beg_ref, s.read + read_begin, rfl, rdl, max1, bw, hb, eb, hc, tb_rows, tb_ref,
-                                      direction, dir_cap, out.cigar, SALT_MAX_CIGAR_OPS);
-            }
-            if (lane == 0 && n_cig < 0) { atomicAdd(overflow, 1u); n_cig = 0; }
-            if ((dbg_skip_tb & 2) && lane == 0) {                                       // phase clocks (10 ns ticks), diagnostics only
-                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-                atomicAdd(overflow + 1, (uint32_t)(t1 - t0)); atomicAdd(overflow + 2, (uint32_t)(t2 - t1)); atomicAdd(overflow + 3, (uint32_t)(t3 - t2));
-            }
-            n_cig = __shfl(n_cig, 0, 8);
-            out.n_cigar = (uint16_t)n_cig;
-            out.ok = (uint16_t)((n_cig > 0 && end_read1 - read_begin + 1 >= 20) ? 1 : 0);   // alnpe.c:297 (filters = 0, filterd = 20)
         }
-        if (lane == 0) res[it] = out;
+        if (lane == 0) {                                             // the row without its CIGAR words (k_swtb writes them)
+            PeSwRes *o = res + it;
+            o->score1 = out.score1; o->score2 = out.score2; o->ref_begin = out.ref_begin; o->ref_end = out.ref_end; o->read_begin = out.read_begin; o->read_end = out.read_end;
+            o->start = out.start; o->strand = out.strand; o->n_cigar = 0; o->ok = out.ok;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_swtb: the banded traceback of the requests k_sw left with ok = 2 (ssw.c:837-848), eight lanes per alignment (tb_band_pass)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_swtb(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+       const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
+       uint32_t *__restrict__ overflow, uint8_t *__restrict__ scratch, uint32_t group_bytes, TbGeom tg, int dbg_arg)
+{
+    const int dbg_max_bw = SALT_DIAG_VAL(dbg_arg);               // diagnostics build only: bands wider than this count as overflow
+    extern __shared__ __attribute__((aligned(16))) uint8_t tb_lds[];
+    const uint32_t grp = threadIdx.x >> 3, lane = threadIdx.x & 7u;
+    uint8_t *const rd = tb_lds + (size_t)grp * tg.group_b, *const rf = rd + tg.read_b;
+    int32_t *const lrows = reinterpret_cast<int32_t *>(rf + tg.ref_b);
+    uint8_t *const ldir = reinterpret_cast<uint8_t *>(lrows + 3 * tg.row_w);
+    uint8_t *const my = scratch + ((size_t)blockIdx.x * 8 + grp) * group_bytes;          // global: three rows of SW_BAND_W ints, then direction bytes
+    int32_t *const grows = reinterpret_cast<int32_t *>(my);
+    uint8_t *const gdir = my + 3u * SW_BAND_W * 4u;
+    const uint64_t gdir_cap = group_bytes > 3u * SW_BAND_W * 4u ? group_bytes - 3u * SW_BAND_W * 4u : 0u;
+    const uint32_t n_req = pctl[0];
+    for (;;) {                                                       // eight requests per pull, a uniform exit (see k_sw)
+        uint32_t base = 0;
+        if (threadIdx.x == 0) base = atomicAdd(head, 8u);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n_req) break;
+        const uint32_t it = base + grp;
+        if (it >= n_req) continue;
+        PeSwRes *o = res + it;
+        if (o->ok != 2) continue;
+        const PeSwReq rq = req[it];
+        const int ref_begin = o->ref_begin, ref_end = o->ref_end, read_begin = o->read_begin, read_end = o->read_end, score = o->score1;
+        const int rfl = ref_end - ref_begin + 1, rdl = read_end - read_begin + 1, aware = rq.aware;
+        const uint32_t off = offs[rq.mate], L = offs[rq.mate + 1] - off;
+        int n_cig = 0;
+        if (rfl > 0 && rdl > 0 && (uint32_t)rdl <= tg.read_b) {
+            const uint32_t ref0 = rq.start + (uint32_t)ref_begin;
+            for (int t = (int)lane; t < rdl; t += 8) {               // the aligned part of the mate on the requested strand
+                const uint32_t q = (uint32_t)(read_begin + t);
+                uint32_t c = rq.strand ? seqs[off + (L - 1 - q)] : seqs[off + q];
+                if (rq.strand && c < 4) c = 3 - c;
+                rd[t] = (uint8_t)(c > 4 ? 4 : c);
+            }
+            const bool ref_in_lds = (uint32_t)rfl <= tg.ref_b;
+            if (ref_in_lds) for (int t = (int)lane; t < rfl; t += 8) rf[t] = (uint8_t)ref_symbol(ix, pac, aware, ref0 + (uint32_t)t);
+            int bw = rfl - rdl; bw = (bw < 0 ? -bw : bw) + 1;
+            int mx = 0;
+            bool fits = true, dir_lds = true;
+            for (;;) {                                               // band doubling (ssw.c:570-631): until the band holds the alignment's score
+                const int width = 2 * bw + 3, width_d = 2 * bw + 1;
+                const bool rows_lds = (uint32_t)width <= tg.row_w;
+                dir_lds = (uint64_t)width_d * (uint64_t)rdl <= tg.dir_b;
+                if (width > (int)SW_BAND_W || (!dir_lds && (uint64_t)width_d * (uint64_t)rdl > gdir_cap) || (dbg_max_bw && bw > dbg_max_bw)) { fits = false; break; }
+                int m;
+                const uint8_t *rfp = ref_in_lds ? rf : nullptr;
+                if (rows_lds && dir_lds) m = tb_band_pass<true, true>(lrows, lrows + tg.row_w, lrows + 2 * tg.row_w, ldir, rd, rfp, ix, pac, aware, ref0, rfl, rdl, bw);
+                else if (rows_lds) m = tb_band_pass<true, false>(lrows, lrows + tg.row_w, lrows + 2 * tg.row_w, gdir, rd, rfp, ix, pac, aware, ref0, rfl, rdl, bw);
+                else if (dir_lds) m = tb_band_pass<false, true>(grows, grows + SW_BAND_W, grows + 2 * SW_BAND_W, ldir, rd, rfp, ix, pac, aware, ref0, rfl, rdl, bw);
+                else m = tb_band_pass<false, false>(grows, grows + SW_BAND_W, grows + 2 * SW_BAND_W, gdir, rd, rfp, ix, pac, aware, ref0, rfl, rdl, bw);
+                mx = mx > m ? mx : m;                                // the reference's maximum runs over all passes
+                if (mx >= score) break;
+                bw *= 2;
+            }
+            if (!fits) n_cig = -1;
+            else if (lane == 0) n_cig = tb_walk(dir_lds ? ldir : gdir, (int64_t)(2 * bw + 1) * rdl, rfl, rdl, bw, reinterpret_cast<uint16_t *>(lrows), o->cigar, SALT_MAX_CIGAR_OPS);
+            n_cig = __shfl(n_cig, 0, 8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        } else if (rfl > 0 && rdl > 0) n_cig = -1;
+        if (lane == 0) {
+            if (n_cig < 0) { atomicAdd(overflow, 1u); n_cig = 0; }
+            o->n_cigar = (uint16_t)n_cig;
+            o->ok = (uint16_t)((n_cig > 0 && rdl >= 20) ? 1 : 0);      // alnpe.c:297 (filters = 0, filterd = 20)
+        }
     }
 }
 
@@ -511,8 +597,6 @@ void launch_pair(uint32_t n_pairs, uint32_t min_tlen, uint32_t max_tlen, uint32_
     if (n_pairs) hipLaunchKernelGGL(k_pair, dim3((n_pairs + 255) / 256), dim3(256), 0, st, n_pairs, min_tlen, max_tlen, l_pac, offs, res, pairs, req, pctl);
 }
 
-// Blocks per CU are bounded by the dynamic LDS (8 groups x sw_group_bytes), i.e. by the longest read of the batch:
-// 150-bp mates fit 8 blocks per CU where 512-bp reads fit 4.
 // stripe rows in registers for reads up to 256 bases (13 / 19 / 32 stripes of 8), in LDS beyond
 static int sw_seg_variant(uint32_t max_len)
 {
@@ -520,12 +604,12 @@ static int sw_seg_variant(uint32_t max_len)
     const uint32_t seg = (max_len + 7) / 8;
     return lds_only ? 0 : seg <= 13 ? 13 : seg <= 19 ? 19 : seg <= 32 ? 32 : 0;
 }
-static const uint32_t SW_MC_COLS = 0;               // per-column maxima in LDS for windows up to this many columns: measured, no gain -> off
 uint32_t sw_lds_bytes(uint32_t max_len)
 {
     const uint32_t seg = (max_len + 7) / 8, rd = (8u * seg + 15u) & ~15u;
-    return sw_seg_variant(max_len) ? 8u * rd + 8u * SW_MC_COLS * 2u + 8u * (3u * SW_LDS_BAND * 4u + SW_LDS_REF) : 8u * (4u * seg * 16u + rd);
+    return sw_seg_variant(max_len) ? 8u * rd : 8u * (4u * seg * 16u + rd);
 }
+// one-wave blocks per CU: what registers (the register variants) or LDS (the LDS variant) admit
 uint32_t sw_blocks_per_cu(uint32_t max_len)
 {
     int n = 0;
@@ -534,33 +618,53 @@ uint32_t sw_blocks_per_cu(uint32_t max_len)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64, sw_lds_bytes(max_len)) != hipSuccess || n < 1) n = 1;
     return (uint32_t)(n > (int)SW_MAX_BLOCKS_PER_CU ? (int)SW_MAX_BLOCKS_PER_CU : n);
 }
-// Scratch geometry of one k_sw launch: the per-column maxima cover the longest window (max_window columns), the direction
-// bytes the widest band the row buffers hold; the grid is cut back before the groups' scratch passes SW_SCRATCH_TOTAL.
+// k_swtb's LDS per group: the aligned part of the mate, the reference symbols of alignments up to twice the read length, three band rows
+// of 32 cells (band half-width <= 14) and direction bytes for 13 cells per row (half-width <= 6): what mate rescue produces
+static TbGeom tb_geom(uint32_t max_len)
+{
+    TbGeom t;
+    t.read_b = (max_len + 15u) & ~15u;
+    t.ref_b = (2u * max_len + 15u) & ~15u; if (t.ref_b > 1024u) t.ref_b = 1024u;
+    t.row_w = 32;
+    t.dir_b = (13u * max_len + 15u) & ~15u; if (t.dir_b > 4096u) t.dir_b = 4096u;
+    t.group_b = t.read_b + t.ref_b + 3u * t.row_w * 4u + t.dir_b;
+    return t;
+}
+// Scratch geometry of one launch: k_sw's groups keep the per-column maxima of the longest window (max_window columns) in global memory;
+// k_swtb's groups three band rows and the direction bytes of the widest band the rows hold (one byte per cell) for alignments whose band
+// outgrows the LDS -- its grid is cut back before that passes SW_SCRATCH_TOTAL.
 SwGeom sw_geom(uint32_t max_len, uint64_t max_window, uint32_t cus)
 {
     SwGeom g;
     const uint64_t mc = (2 * max_window + 255) & ~255ull;
-    const uint64_t dir = (3ull * max_len * (SW_BAND_W - 3) + 8 + 255) & ~255ull;
-    const uint64_t grp = mc + 3ull * SW_BAND_W * 4 + dir;
-    g.maxcol_bytes = (uint32_t)mc; g.group_bytes = (uint32_t)grp;
-    uint64_t blocks = (uint64_t)cus * sw_blocks_per_cu(max_len);
-    const uint64_t cap = SW_SCRATCH_TOTAL / (8 * grp);
-    if (blocks > cap) blocks = cap;
-    g.n_blocks = (uint32_t)(blocks ? blocks : 1);
+    g.maxcol_bytes = (uint32_t)mc;
+    g.n_blocks = cus * sw_blocks_per_cu(max_len);
+    if (!g.n_blocks) g.n_blocks = 1;
+    const uint64_t dir = ((uint64_t)max_len * (SW_BAND_W - 3) + 255) & ~255ull;
+    g.tb_group_bytes = (uint32_t)(3ull * SW_BAND_W * 4 + dir);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_swtb, 64, 8u * tb_geom(max_len).group_b) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > (int)SW_MAX_BLOCKS_PER_CU) per_cu = (int)SW_MAX_BLOCKS_PER_CU;
+    uint64_t tb = (uint64_t)cus * (uint32_t)per_cu;
+    const uint64_t cap = SW_SCRATCH_TOTAL / (8ull * g.tb_group_bytes);
+    if (tb > cap) tb = cap;
+    g.tb_blocks = (uint32_t)(tb ? tb : 1);
     return g;
 }
+void sw_geom_limit(SwGeom &g, uint32_t blocks) { if (blocks < 1) blocks = 1; if (g.n_blocks > blocks) g.n_blocks = blocks; if (g.tb_blocks > blocks) g.tb_blocks = blocks; }
+uint64_t sw_scratch_bytes(const SwGeom &g) { return (uint64_t)g.n_blocks * 8 * g.maxcol_bytes + (uint64_t)g.tb_blocks * 8 * g.tb_group_bytes; }
 
 void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, const uint32_t *offs, const PeSwReq *req, const uint32_t *pctl,
-               PeSwRes *res, uint32_t *head, uint32_t *overflow, uint8_t *scratch, SwGeom g, uint32_t max_len, hipStream_t st)
+               PeSwRes *res, uint32_t *head, uint32_t *tb_head, uint32_t *overflow, uint8_t *scratch, SwGeom g, uint32_t max_len, hipStream_t st)
 {
     const uint32_t seg = (max_len + 7) / 8;
 #ifdef SALT_DIAG
-    const int skip_tb = getenv("SALT_GPU_SW_SKIP_TB") ? atoi(getenv("SALT_GPU_SW_SKIP_TB")) : 0;     // diagnostics: 1 = no traceback, 2 = phase clocks
+    const int dbg = getenv("SALT_GPU_SW_SKIP_TB") ? atoi(getenv("SALT_GPU_SW_SKIP_TB")) : 0;     // diagnostics: 2 = phase clocks, 4 / 8 = column counts
 #else
-    const int skip_tb = 0;
+    const int dbg = 0;
 #endif
 #define SALT_LAUNCH_SW(V) hipLaunchKernelGGL(k_sw<V>, dim3(g.n_blocks), dim3(64), sw_lds_bytes(max_len), st, ix, pac, seqs, offs, req, pctl, res, head, \
-                                             overflow, scratch, g.maxcol_bytes, g.group_bytes, seg, (V) ? SW_MC_COLS : 0u, skip_tb)
+                                             overflow, scratch, g.maxcol_bytes, seg, dbg)
     switch (sw_seg_variant(max_len)) {
     case 13: SALT_LAUNCH_SW(13); break;
     case 19: SALT_LAUNCH_SW(19); break;
@@ -568,6 +672,14 @@ void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, con
     default: SALT_LAUNCH_SW(0); break;
     }
 #undef SALT_LAUNCH_SW
+    const TbGeom tg = tb_geom(max_len);
+    int tb_dbg = 0;
+#ifdef SALT_DIAG
+    if (getenv("SALT_GPU_NO_TB")) return;                                                       // diagnostics: no traceback (no CIGARs)
+    if (getenv("SALT_GPU_TB_MAXBW")) tb_dbg = atoi(getenv("SALT_GPU_TB_MAXBW"));
+#endif
+    hipLaunchKernelGGL(k_swtb, dim3(g.tb_blocks), dim3(64), 8u * tg.group_b, st, ix, pac, seqs, offs, req, pctl, res, tb_head, overflow,
+                       scratch + (uint64_t)g.n_blocks * 8 * g.maxcol_bytes, g.tb_group_bytes, tg, tb_dbg);
 }
 
 } // namespace salt
