@@ -110,7 +110,7 @@ def main():
     args = ap.parse_args()
 
     if args.mode == "pe":
-        args.steps, args.warmup, args.batches, args.e2e_reads, args.e2e_pairs = 1, 1, 1, 0, 0
+        args.steps, args.warmup, args.batches, args.e2e_reads, args.e2e_pairs = max(1, args.streams), 1, 1, 0, 0
     if args.mode == "se":
         args.pe_pairs = 0
     rank = int(os.environ.get("RANK", "0"))

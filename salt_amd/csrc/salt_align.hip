@@ -369,21 +369,23 @@ __device__ __forceinline__ uint4 seed_r_rest(const IndexView &ix, const SeedPara
     return make_uint4(kr, lr, s - ext, 1);
 }
 
+static constexpr uint32_t WQ_SEG = 64, WQ_STRIDE = 64;            // segments per walk queue; words between their counters
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
-       uint4 *__restrict__ sai_c, uint4 *__restrict__ sai_r, unsigned long long *__restrict__ ctr)
+       uint4 *__restrict__ sai_c, uint4 *__restrict__ sai_r, uint4 *__restrict__ wq, uint32_t *__restrict__ wq_cnt, uint32_t wq_seg_cap,
+       unsigned long long *__restrict__ ctr)
 {
-    // walks still to do, collected per block: [0][..] R searches, [1][..] C searches: (lane of the block that owns the seed, k, l)
-    __shared__ uint32_t q_who[2][256], q_k[2][256], q_l[2][256];
-    __shared__ uint32_t q_n[2];
-    const uint64_t block_item0 = (uint64_t)blockIdx.x * blockDim.x;
-    const uint64_t item = block_item0 + threadIdx.x, n_items = (uint64_t)sp.n_reads * 2u * sp.spr;
+    // walks still to do go to the queues k_seed_walk drains: [0] R searches, [1] C searches.  The block counts its walks in LDS, reserves
+    // their slots in ONE of WQ_SEG segments per list with one atomic (an atomic on one address is served every ~11 ns: 31 000 blocks on one
+    // counter would be a third of a millisecond) and every lane stores its own record.
+    __shared__ uint32_t q_n[2], q_base[2];
+    const uint64_t item = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_items = (uint64_t)sp.n_reads * 2u * sp.spr;
     const uint64_t lt = (1ull << lane_id()) - 1ull;
     uint32_t n_lkt = 0, n_occ_c = 0, n_occ_r = 0;
-    if (threadIdx.x < 2) q_n[threadIdx.x] = 0;
+    if (threadIdx.x < 2) { q_n[threadIdx.x] = 0; q_base[threadIdx.x] = 0; }
     __syncthreads();
     bool pend_c = false, pend_r = false;
-    uint32_t pk_c = 0, pl_c = 0, pk_r = 0, pl_r = 0;
+    uint32_t pk_c = 0, pl_c = 0, pk_r = 0, pl_r = 0, at_r = 0, at_c = 0;
     if (item < n_items) {
         const SeedCtx c = seed_ctx(sp, tb, (uint32_t)item, ix.r_lkt_len);
         uint4 oc = make_uint4(1, 0, 0, 0), orr = make_uint4(1, 0, 0, 0);
@@ -455,20 +457,14 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
         uint32_t br = 0, bc = 0;
         if (lane_id() == 0) { if (mr) br = atomicAdd(&q_n[0], (uint32_t)__popcll(mr)); if (mc) bc = atomicAdd(&q_n[1], (uint32_t)__popcll(mc)); }
         br = (uint32_t)__shfl((int)br, 0); bc = (uint32_t)__shfl((int)bc, 0);
-        if (pend_r) { const uint32_t at = br + (uint32_t)__popcll(mr & lt); q_who[0][at] = threadIdx.x; q_k[0][at] = pk_r; q_l[0][at] = pl_r; }
-        if (pend_c) { const uint32_t at = bc + (uint32_t)__popcll(mc & lt); q_who[1][at] = threadIdx.x; q_k[1][at] = pk_c; q_l[1][at] = pl_c; }
+        at_r = br + (uint32_t)__popcll(mr & lt); at_c = bc + (uint32_t)__popcll(mc & lt);
     }
     __syncthreads();
-    // adopt: lane t takes walk t of the concatenated lists (R first)
-    const uint32_t nr = q_n[0], nc = q_n[1];
-    for (uint32_t t = threadIdx.x; t < nr + nc; t += blockDim.x) {
-        const uint32_t which = t < nr ? 0u : 1u, at = which ? t - nr : t;
-        const uint64_t it = block_item0 + q_who[which][at];
-        const SeedCtx c = seed_ctx(sp, tb, (uint32_t)it, ix.r_lkt_len);
-        const int i_top = (int)(c.k - c.W) - 1;
-        if (which == 0) sai_r[it] = seed_r_rest(ix, sp, c, q_k[0][at], q_l[0][at], i_top, n_occ_r);
-        else sai_c[it] = seed_c_rest(ix, sp, c, q_k[1][at], q_l[1][at], i_top, n_occ_c, n_lkt);
-    }
+    const uint32_t seg = blockIdx.x & (WQ_SEG - 1u);
+    if (threadIdx.x < 2 && q_n[threadIdx.x]) q_base[threadIdx.x] = atomicAdd(&wq_cnt[(threadIdx.x * WQ_SEG + seg) * WQ_STRIDE], q_n[threadIdx.x]);
+    __syncthreads();
+    if (pend_r) wq[(size_t)seg * wq_seg_cap + q_base[0] + at_r] = make_uint4((uint32_t)item, pk_r, pl_r, 0u);
+    if (pend_c) wq[((size_t)WQ_SEG + seg) * wq_seg_cap + q_base[1] + at_c] = make_uint4((uint32_t)item, pk_c, pl_c, 0u);
     if (ctr) {                                                // one atomic per wave and counter
         for (int o = 32; o > 0; o >>= 1) {
             n_lkt += __shfl_down(n_lkt, o); n_occ_c += __shfl_down(n_occ_c, o); n_occ_r += __shfl_down(n_occ_r, o);
@@ -477,6 +473,37 @@ k_seed(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb,
             atomicAdd(ctr + SALT_CTR_LKT, n_lkt & 1023u); atomicAdd(ctr + SALT_CTR_OCC_C, n_occ_c); atomicAdd(ctr + SALT_CTR_OCC_R, n_occ_r);
             atomicAdd(ctr + SALT_CTR_D_WLKT, n_lkt & 1023u); atomicAdd(ctr + SALT_CTR_D_COCC_SEED, n_occ_c); atomicAdd(ctr + SALT_CTR_D_ROCC_SEED, n_occ_r);
             atomicAdd(ctr + SALT_CTR_D_SA_SEED, (n_lkt >> 10) & 2047u); atomicAdd(ctr + SALT_CTR_D_TEXT_SEED, n_lkt >> 21);
+        }
+    }
+}
+
+// k_seed_walk: the walks k_seed queued, one per lane and lanes densely packed: R searches first, then C searches (similar lengths side by
+// side: a wave pays for the longest of its 64 walks).  Inside k_seed a block of 256 seeds kept ~70 lanes busy with walks while it held its
+// wave slots; here every lane of every resident wave has one, which is what raises the number of requests in flight.  Block b serves
+// segment b % WQ_SEG with the other blocks of that segment, in strides.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_seed_walk(IndexView ix, SeedParams sp, const uint32_t *__restrict__ tb, uint4 *__restrict__ sai_c, uint4 *__restrict__ sai_r,
+            const uint4 *__restrict__ wq, const uint32_t *__restrict__ wq_cnt, uint32_t wq_seg_cap, unsigned long long *__restrict__ ctr)
+{
+    const uint32_t seg = blockIdx.x & (WQ_SEG - 1u), bb = blockIdx.x / WQ_SEG, nbb = gridDim.x / WQ_SEG;
+    uint32_t n_aux = 0, n_occ_c = 0, n_occ_r = 0;
+    for (uint32_t which = 0; which < 2; ++which) {
+        const uint32_t n = wq_cnt[(which * WQ_SEG + seg) * WQ_STRIDE];
+        const uint4 *q = wq + ((size_t)which * WQ_SEG + seg) * wq_seg_cap;
+        for (uint32_t t = bb * 256u + threadIdx.x; t < n; t += nbb * 256u) {
+            const uint4 e = q[t];
+            const SeedCtx c = seed_ctx(sp, tb, e.x, ix.r_lkt_len);
+            const int i_top = (int)(c.k - c.W) - 1;
+            if (which == 0) sai_r[e.x] = seed_r_rest(ix, sp, c, e.y, e.z, i_top, n_occ_r);
+            else sai_c[e.x] = seed_c_rest(ix, sp, c, e.y, e.z, i_top, n_occ_c, n_aux);
+        }
+    }
+    if (ctr) {
+        for (int o = 32; o > 0; o >>= 1) { n_aux += __shfl_down(n_aux, o); n_occ_c += __shfl_down(n_occ_c, o); n_occ_r += __shfl_down(n_occ_r, o); }
+        if (lane_id() == 0) {
+            atomicAdd(ctr + SALT_CTR_OCC_C, n_occ_c); atomicAdd(ctr + SALT_CTR_OCC_R, n_occ_r);
+            atomicAdd(ctr + SALT_CTR_D_COCC_SEED, n_occ_c); atomicAdd(ctr + SALT_CTR_D_ROCC_SEED, n_occ_r);
+            atomicAdd(ctr + SALT_CTR_D_SA_SEED, (n_aux >> 10) & 2047u); atomicAdd(ctr + SALT_CTR_D_TEXT_SEED, n_aux >> 21);
         }
     }
 }
@@ -893,6 +920,46 @@ __device__ __forceinline__ void verify_quads(const uint32_t *__restrict__ ref, u
             if (c0 + CPW * g >= n) break;
             const uint32_t mism = quad_mismatch<LN>(x[g], pos[g], pmw, nvalid);
             if (act[g] && sub == 0) out[c0 + CPW * g + q] = (uint8_t)((mism > 3 || pos[g] == 0xFFFFFFFFu) ? INF : mism);
+        }
+    }
+}
+
+// Reads of 121 .. 248 bases (150-base mates), two phases.  A window is 76+ bytes: eight lanes per candidate move 128 (two or three
+// 64-byte sectors), and nearly every located row of a repeat read is a false one.  Phase 1 looks at the first 120 bases only -- four
+// lanes, one 64-byte stretch per candidate, 128 candidates in flight: a candidate with more than 3 mismatches there cannot pass
+// ed_mismatch(..., 3) (editdistance.c:88-163 counts over the whole read).  Phase 2 counts the few survivors over the whole read with
+// eight lanes each.  Same out[] as verify_quads<G, 8>.
+__device__ __forceinline__ void verify_two_phase(const uint32_t *__restrict__ ref, uint32_t ref_len, const uint32_t *pm, uint32_t L,
+                                                 const uint32_t *cand, uint32_t n, uint8_t *out)
+{
+    verify_quads<8, 4>(ref, ref_len, pm, 120u, cand, n, out);                  // partial counts (<= 3) or INF
+    WSYNC();
+    const uint32_t lane = lane_id(), sub = lane & 7u, q = lane >> 3;
+    const uint32_t nw = (L + 7) >> 3;
+    const uint32_t nvalid = L > 32u * sub ? (L - 32u * sub < 32u ? L - 32u * sub : 32u) : 0u;
+    uint32_t pmw[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) pmw[t] = (4 * sub + t) < nw ? pm[4 * sub + t] : 0u;
+    const bool need = 4u * sub < nw + 1u;                                    // this lane's words overlap the window (the rest is never fetched)
+    for (uint32_t b = 0; b < n; b += 64) {
+        const uint32_t i = b + lane;
+        uint64_t m = __ballot(i < n && out[i] != INF);
+        while (m) {                                                          // (uniform) eight survivors per trip, one per lane group
+            uint64_t mm = m; uint32_t c = 0xFFFFFFFFu;
+            for (uint32_t k = 0; k < 8; ++k) {                               // group q takes the q-th survivor
+                if (!mm) break;
+                const uint32_t bit = (uint32_t)__ffsll((long long)mm) - 1u;
+                if (k == q) c = b + bit;
+                mm &= mm - 1;
+            }
+            m = mm;
+            const bool act = c != 0xFFFFFFFFu;
+            uint32_t pos = act ? cand[c] : 0u;
+            if (pos >= ref_len) pos = 0xFFFFFFFFu;                           // (cannot survive phase 1; kept for symmetry with verify_quads)
+            u32x4_a4 x = { 0u, 0u, 0u, 0u };
+            if (act && need && pos != 0xFFFFFFFFu) x = *reinterpret_cast<const u32x4_a4 *>(ref + (pos >> 3) + 4 * sub);
+            const uint32_t mism = quad_mismatch<8>(x, pos, pmw, nvalid);
+            if (act && sub == 0) out[c] = (uint8_t)((mism > 3 || pos == 0xFFFFFFFFu) ? INF : mism);
         }
     }
 }
@@ -1369,7 +1436,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         if (SALT_DIAG_VAL(ap.heavy_stop) == 1) continue;
         auto verify_all = [&](uint32_t n) {                   // cand_e[i] = min(mismatches, INF) of loci[i], loads of 128 candidates in flight
             if (L <= 120) verify_quads<8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
-            else if (L <= 248) verify_quads<8, 8>(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
+            else if (L <= 248) verify_two_phase(ix.ref, ix.ref_len, w.pm[strand], L, loci, n, cand_e);
             else for (uint32_t i = lane; i < n; i += 64) cand_e[i] = (uint8_t)mismatch_capped(ix, w.pm[strand], L, loci[i]);
             WSYNC();
         };
@@ -1446,7 +1513,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                             atomicAdd(ctr + SALT_CTR_LV, ns[0] + ns[1]); atomicAdd(ctr + SALT_CTR_READS, 1ull);
                             atomicAdd(ctr + SALT_CTR_BASES, L); atomicAdd(ctr + SALT_CTR_LOCI, c_loci);
                             atomicAdd(ctr + SALT_CTR_D_SA_HEAVY, c_sa_c + c_sa_r);
-                            atomicAdd(ctr + SALT_CTR_D_VERIFY_HEAVY, c_verify * (L <= 120 ? 4u : L <= 248 ? 8u : (((L + 7) >> 3) + 4u) / 4u));
+                            atomicAdd(ctr + SALT_CTR_D_VERIFY_HEAVY, c_verify * (L <= 248 ? 4u : (((L + 7) >> 3) + 4u) / 4u));      // 121 .. 248 bases: phase 1 of verify_two_phase (the survivors' second look is not counted)
                             atomicAdd(ctr + SALT_CTR_D_OUT_HEAVY, 5u * (ns[0] + ns[1]) + 16u);      // the located rows + distances handed to k_gap
                             if (ix.c_ctx) { atomicAdd(ctr + SALT_CTR_D_CTX_ROWS, c_ctx_rows); atomicAdd(ctr + SALT_CTR_D_CTX_REJECTED, c_ctx_rej); }
                         }
@@ -1587,7 +1654,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             atomicAdd(ctr + SALT_CTR_LV, c_lv); atomicAdd(ctr + SALT_CTR_READS, 1ull);
             atomicAdd(ctr + SALT_CTR_BASES, L); atomicAdd(ctr + SALT_CTR_LOCI, c_loci);
             atomicAdd(ctr + SALT_CTR_D_SA_HEAVY, c_sa_c + c_sa_r);
-            atomicAdd(ctr + SALT_CTR_D_VERIFY_HEAVY, c_verify * (L <= 120 ? 4u : L <= 248 ? 8u : (((L + 7) >> 3) + 4u) / 4u));
+            atomicAdd(ctr + SALT_CTR_D_VERIFY_HEAVY, c_verify * (L <= 248 ? 4u : (((L + 7) >> 3) + 4u) / 4u));      // 121 .. 248 bases: phase 1 of verify_two_phase (the survivors' second look is not counted)
             atomicAdd(ctr + SALT_CTR_D_OUT_HEAVY, 128u);
             if (ix.c_ctx) { atomicAdd(ctr + SALT_CTR_D_CTX_ROWS, c_ctx_rows); atomicAdd(ctr + SALT_CTR_D_CTX_REJECTED, c_ctx_rej); }
         }
@@ -1634,8 +1701,13 @@ __device__ __forceinline__ void heavy_body(const IndexView &ix, const AlignParam
     }
 }
 
+#ifdef SALT_HEAVY_WAVES                     /* A/B builds: cap the registers of the persistent kernels for that many waves per SIMD */
+#define HEAVY_OCC __attribute__((amdgpu_waves_per_eu(SALT_HEAVY_WAVES, SALT_HEAVY_WAVES)))
+#else
+#define HEAVY_OCC
+#endif
 #define HEAVY_KERNEL(NAME, PE, LDS)                                                                                     \
-__global__ void __launch_bounds__(64)                                                                                   \
+__global__ void __launch_bounds__(64) HEAVY_OCC                                                                         \
 NAME(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,                                                     \
      const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,             \
      const uint32_t *__restrict__ queue, unsigned long long *__restrict__ ctr,                                          \
@@ -2384,13 +2456,20 @@ void launch_pe_final(const IndexView &ix, const PackGeom &pg, uint32_t n_pairs, 
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (called from salt_gpu.hip)
 // ---------------------------------------------------------------------------------------------
-void launch_seed(const IndexView &ix, const SeedParams &sp, const uint32_t *tb, const uint8_t *, const uint32_t *, uint4 *sai_c,
-                 uint4 *sai_r, unsigned long long *ctr, hipStream_t st)
+uint32_t seed_wq_seg_cap(uint64_t items) { return (uint32_t)(((items + 255) / 256 + WQ_SEG - 1) / WQ_SEG) * 256u; }      // every seed of every block of a segment
+size_t seed_wq_words(uint64_t items) { return (size_t)2 * WQ_SEG * seed_wq_seg_cap(items) * 4; }                              // uint4 records of both lists, in words
+uint32_t seed_wq_cnt_words() { return 2u * WQ_SEG * WQ_STRIDE; }
+void launch_seed(const IndexView &ix, const SeedParams &sp, const uint32_t *tb, uint4 *sai_c, uint4 *sai_r, uint4 *wq, uint32_t *wq_cnt,
+                 uint32_t walk_blocks, unsigned long long *ctr, hipStream_t st)
 {
     uint64_t items = (uint64_t)sp.n_reads * 2u * sp.spr;
     if (!items) return;
     uint32_t blocks = (uint32_t)((items + 255) / 256);
-    hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(256), 0, st, ix, sp, tb, sai_c, sai_r, ctr);
+    const uint32_t cap = seed_wq_seg_cap(items);
+    hipMemsetAsync(wq_cnt, 0, (size_t)seed_wq_cnt_words() * 4, st);
+    hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(256), 0, st, ix, sp, tb, sai_c, sai_r, wq, wq_cnt, cap, ctr);
+    walk_blocks = (walk_blocks + WQ_SEG - 1) / WQ_SEG * WQ_SEG;
+    hipLaunchKernelGGL(k_seed_walk, dim3(walk_blocks), dim3(256), 0, st, ix, sp, tb, sai_c, sai_r, wq, wq_cnt, cap, ctr);
 }
 
 void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint8_t *, const uint32_t *, const uint4 *sai_c,

@@ -38,6 +38,7 @@ struct salt_gpu_ws {
     uint32_t max_reads = 0; uint64_t max_bases = 0;
     uint8_t *d_seqs = nullptr; uint32_t *d_offs = nullptr; salt_result_t *d_results = nullptr;
     uint4 *d_sai_c = nullptr, *d_sai_r = nullptr; uint64_t sai_cap = 0;
+    uint4 *d_wq = nullptr; uint32_t *d_wq_cnt = nullptr; uint32_t walk_blocks = 2048;      // k_seed's walk queues (sized with the seed arrays), k_seed_walk's grid
     uint32_t *d_pm = nullptr, *d_tb = nullptr; uint64_t pm_cap = 0, tb_cap = 0;     // k_pack's records (words)
     uint8_t *d_heads = nullptr, *h_heads = nullptr;          // first 128 bytes of every result row: dense device copy + pinned host staging
     unsigned long long *d_ctr = nullptr;
@@ -312,6 +313,9 @@ extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint
         uint32_t gap_per_cu = 16;
         if (const char *e2 = getenv("SALT_GPU_GAP_PER_CU")) { int v = atoi(e2); if (v > 0 && v <= 16) gap_per_cu = (uint32_t)v; }
         ws->gap_blocks = (uint32_t)prop.multiProcessorCount * gap_per_cu;
+        ws->walk_blocks = (uint32_t)prop.multiProcessorCount * 8u;            // k_seed_walk: 8 waves per SIMD in blocks of four waves
+        if (const char *e2 = getenv("SALT_GPU_WALK_PER_CU")) { int v = atoi(e2); if (v > 0 && v <= 16) ws->walk_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)v; }
+        CHKW(hipMalloc((void **)&ws->d_wq_cnt, (size_t)seed_wq_cnt_words() * 4));
         CHKW(hipMalloc(&ws->d_lvtab, (uint64_t)ws->heavy_blocks * lv_table_bytes()));
         const char *e = getenv("SALT_GPU_ALL_HEAVY");
         ws->all_heavy = e && atoi(e) != 0;
@@ -328,7 +332,7 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
 {
     if (!ws) return;
     hipSetDevice(ws->ix->device);
-    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_heads); if (ws->h_heads) hipHostFree(ws->h_heads); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qsub); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gap);
+    hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_wq); hipFree(ws->d_wq_cnt); hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_heads); if (ws->h_heads) hipHostFree(ws->h_heads); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qsub); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gap);
     hipFree(ws->d_raw); hipFree(ws->d_tile); hipFree(ws->d_lines); hipFree(ws->d_rec); hipFree(ws->d_tctl); hipFree(ws->d_samoff); hipFree(ws->d_scan); hipFree(ws->d_sam); hipFree(ws->d_rg);
     if (ws->h_sam && ws->h_sam_owned) hipHostFree(ws->h_sam);
     hipFree(ws->d_pe_scr); hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres); hipFree(ws->d_pctl); hipFree(ws->d_sw_scr); hipFree(ws->d_pcq);
@@ -373,9 +377,10 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     uint64_t items = (uint64_t)n_reads * 2u * spr;
     if (items > ws->sai_cap) {                     // grows rarely; not on the steady-state path
         HIPCHK(hipStreamSynchronize(st));
-        hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); ws->d_sai_c = ws->d_sai_r = nullptr; ws->sai_cap = 0;
+        hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_wq); ws->d_sai_c = ws->d_sai_r = ws->d_wq = nullptr; ws->sai_cap = 0;
         HIPCHK(hipMalloc((void **)&ws->d_sai_c, items * sizeof(uint4)));
         HIPCHK(hipMalloc((void **)&ws->d_sai_r, items * sizeof(uint4)));
+        HIPCHK(hipMalloc((void **)&ws->d_wq, seed_wq_words(items) * 4));
         ws->sai_cap = items;
     }
     const PackGeom pg = PackGeom::make(max_read_len);
@@ -405,7 +410,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     if (timed) HIPCHK(hipEventRecord(ev[0], st));
     launch_pack(pg, n_reads, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_pm, ws->d_tb, st);
     if (timed) HIPCHK(hipEventRecord(ev[1], st));
-    launch_seed(ws->ix->view, sp, ws->d_tb, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r, ctr, st);
+    launch_seed(ws->ix->view, sp, ws->d_tb, ws->d_sai_c, ws->d_sai_r, ws->d_wq, ws->d_wq_cnt, ws->walk_blocks, ctr, st);
     if (timed) HIPCHK(hipEventRecord(ev[2], st));
     if (!ap.all_heavy)
         launch_light(ws->ix->view, ap, ws->d_pm, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
@@ -544,9 +549,10 @@ extern "C" int salt_gpu_ws_reserve_text(salt_gpu_ws_t *ws, const salt_aln_opt_t 
     if (!ws->d_samoff) HIPCHK(hipMalloc((void **)&ws->d_samoff, ((uint64_t)ws->max_reads + 2) * 4));
     const uint64_t items = (uint64_t)est_reads * 2u * spr;
     if (items > ws->sai_cap) {
-        hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); ws->d_sai_c = ws->d_sai_r = nullptr; ws->sai_cap = 0;
+        hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_wq); ws->d_sai_c = ws->d_sai_r = ws->d_wq = nullptr; ws->sai_cap = 0;
         HIPCHK(hipMalloc((void **)&ws->d_sai_c, items * sizeof(uint4)));
         HIPCHK(hipMalloc((void **)&ws->d_sai_r, items * sizeof(uint4)));
+        HIPCHK(hipMalloc((void **)&ws->d_wq, seed_wq_words(items) * 4));
         ws->sai_cap = items;
     }
     const PackGeom pg = PackGeom::make(max_read_len);

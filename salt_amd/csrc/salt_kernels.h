@@ -56,8 +56,12 @@ struct AlignParams {
 static const uint32_t PE_LOCI_CAP = 0x40000;    // loci per strand a PE mate may enumerate = MAX_LOC_POS (alnse.c:42,533); global scratch
 
 void launch_pack(const PackGeom &pg, uint32_t n_reads, const uint8_t *seqs, const uint32_t *offs, uint32_t *pm, uint32_t *tb, hipStream_t st);
-void launch_seed(const IndexView &ix, const SeedParams &sp, const uint32_t *tb, const uint8_t *seqs, const uint32_t *offs, uint4 *sai_c,
-                 uint4 *sai_r, unsigned long long *ctr, hipStream_t st);
+// k_seed (W-mer gather, in-register resolves, walks queued) + k_seed_walk (the queued walks, one per lane).  wq: seed_wq_words(items) words,
+// wq_cnt: seed_wq_cnt_words() words (zeroed inside); walk_blocks: 256-lane blocks of the walk kernel (what fills the device: CUs x 8)
+void launch_seed(const IndexView &ix, const SeedParams &sp, const uint32_t *tb, uint4 *sai_c, uint4 *sai_r, uint4 *wq, uint32_t *wq_cnt,
+                 uint32_t walk_blocks, unsigned long long *ctr, hipStream_t st);
+size_t seed_wq_words(uint64_t items);
+uint32_t seed_wq_cnt_words();
 void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, uint32_t *qseg, uint32_t *qsub, unsigned long long *ctr, hipStream_t st);
 size_t queue_words(uint32_t max_reads);                      // d_queue: the flat queue, k_heavy's overflow queue, k_light's segments
