@@ -403,18 +403,25 @@ def main():
     aln.close()
     if idx is not None:
         idx.destroy()
+    # N > 1: every rank lets go of its device memory, because the end-to-end legs below are ONE `salt --gpus N` process that puts its own
+    # replica of the index on every GPU of the node (in-process RCCL broadcast, salt_gpu_index_replicate)
+    if rank != 0:
+        del d_ress, batches, timed_rows, genome, site, pos, mask
+        torch.cuda.empty_cache()
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         del d_ress, batches, timed_rows
         torch.cuda.empty_cache()
         # ---- end to end: the drop-in binary, FASTQ text -> SAM text, wall clock (SURVEY 8d's metric; never `value`) ----
         if args.e2e_reads > 0:
             try:
-                out["e2e"] = e2e_leg(args, cfg, w, genome, site, workload, torch, np, log)
+                out["e2e"] = e2e_leg(args, cfg, w, genome, site, workload, torch, np, log, 1 if os.environ.get("SALT_BENCH_SAME_GPU") else world)
             except Exception as ex:                                    # the leg is a report, not a gate
                 out["e2e"] = {"error": str(ex)[:300]}
         if args.e2e_pairs > 0 and args.e2e_reads > 0:
             try:
-                out["e2e_pe"] = e2e_pe_leg(args, w, genome, site, workload, torch, np, log)
+                out["e2e_pe"] = e2e_pe_leg(args, w, genome, site, workload, torch, np, log, 1 if os.environ.get("SALT_BENCH_SAME_GPU") else world)
             except Exception as ex:
                 out["e2e_pe"] = {"error": str(ex)[:300]}
         print(json.dumps(out), flush=True)
@@ -551,7 +558,7 @@ def pe_leg(args, cfg, idx, alns, streams, genome, site, ora, oracle_py, dev, tor
     return out
 
 
-def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log):
+def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log, n_gpus=1):
     """`salt -d -c` on a FASTQ file of the same workload: the binary's own clock (starts when the index is loaded and attached, like the
     reference's; ends with the last SAM byte written), plus the whole process."""
     L = cfg["read_len"]
@@ -572,7 +579,7 @@ def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log):
     sam = os.path.join(d, "e2e.sam")
     t0 = time.time()
     with open(sam, "wb") as fo:
-        p = subprocess.run([salt, "-d", "-c", "-t", str(threads), w["prefix"], fq], stdout=fo, stderr=subprocess.PIPE, timeout=900)
+        p = subprocess.run([salt, "-d", "-c", "-t", str(threads), "--gpus", str(n_gpus), w["prefix"], fq], stdout=fo, stderr=subprocess.PIPE, timeout=900)
     wall = time.time() - t0
     err = p.stderr.decode(errors="replace")
     if p.returncode != 0:
@@ -585,14 +592,14 @@ def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log):
             detail = line[7:]
     sam_bytes = os.path.getsize(sam)
     os.unlink(sam); os.unlink(fq)
-    return {"value": round(n / align_s / 1e6, 3) if align_s else None, "unit": "Mreads/s", "reads": n, "threads": threads,
-            "what": "salt -d -c -t %d <idx> reads.fq > out.sam: FASTQ text in, SAM text out (%.2f GB), PCIe and host I/O included; clock = the binary's "
+    return {"value": round(n / align_s / 1e6, 3) if align_s else None, "unit": "Mreads/s", "reads": n, "threads": threads, "n_gpus": n_gpus,
+            "what": "salt -d -c -t %d --gpus N <idx> reads.fq > out.sam (one process, reads dealt to the GPUs' workers in chunks, one ordered SAM stream): FASTQ text in, SAM text out (%.2f GB), PCIe and host I/O included; clock = the binary's "
                     "[alnse_core] total (restarted where the reference restarts its own, behind the index reload, alnse.c:1366; workspace set-up included; ends with the "
                     "last SAM byte written; index load + attach excluded, as SURVEY 8d defines it)" % (threads, sam_bytes / 1e9),
             "align_wall_s": align_s, "process_wall_s": round(wall, 2), "fastq_write_s": round(t_write, 2), "pipeline": detail}
 
 
-def e2e_pe_leg(args, w, genome, site, workload, torch, np, log):
+def e2e_pe_leg(args, w, genome, site, workload, torch, np, log, n_gpus=1):
     """`salt -d -c -p -a 250 -b 550` on two FASTQ files of 2 x 150-base pairs of the same genome (BASELINE's paired-end configuration): the
     binary's own clock as in e2e_leg."""
     L, n, d = 150, args.e2e_pairs, w["dir"]
@@ -610,7 +617,7 @@ def e2e_pe_leg(args, w, genome, site, workload, torch, np, log):
     sam = os.path.join(d, "e2e_pe.sam")
     t0 = time.time()
     with open(sam, "wb") as fo:
-        p = subprocess.run([os.path.join(ROOT, "salt_amd", "bin", "salt"), "-d", "-c", "-p", "-a", "250", "-b", "550", "-t", str(threads), w["prefix"]] + fq,
+        p = subprocess.run([os.path.join(ROOT, "salt_amd", "bin", "salt"), "-d", "-c", "-p", "-a", "250", "-b", "550", "-t", str(threads), "--gpus", str(n_gpus), w["prefix"]] + fq,
                            stdout=fo, stderr=subprocess.PIPE, timeout=900)
     wall = time.time() - t0
     err = p.stderr.decode(errors="replace")
@@ -625,7 +632,7 @@ def e2e_pe_leg(args, w, genome, site, workload, torch, np, log):
     sam_bytes = os.path.getsize(sam)
     for f in fq + [sam]:
         os.unlink(f)
-    return {"value": round(2 * n / align_s / 1e6, 3) if align_s else None, "unit": "M mates/s", "pairs": n, "read_len": L, "threads": threads,
+    return {"value": round(2 * n / align_s / 1e6, 3) if align_s else None, "unit": "M mates/s", "pairs": n, "read_len": L, "threads": threads, "n_gpus": n_gpus,
             "what": "salt -d -c -p -a 250 -b 550 -t %d <idx> r1.fq r2.fq > out.sam (%.2f GB of SAM); the binary's clock as in e2e" % (threads, sam_bytes / 1e9),
             "align_wall_s": align_s, "process_wall_s": round(wall, 2), "pipeline": detail}
 

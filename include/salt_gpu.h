@@ -198,6 +198,10 @@ int  salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, const 
                             const char **sam, uint64_t *sam_bytes, uint32_t *n_reads);
 int  salt_gpu_host_alloc(uint64_t bytes, void **ptr);      /* page-locked host memory for the text buffers */
 void salt_gpu_host_free(void *ptr);
+/* Multi-GPU drivers (`salt --gpus N`, which stands where alnse_core's pthread fan-out is, alnse.c:1419-1429): the host NUMA node of a device
+ * (-1 = unknown), so that a device's worker threads and their page-locked buffers can be kept on the socket it is attached to. */
+int  salt_gpu_device_numa_node(int device, int *node);
+int  salt_gpu_device_count(int *n);
 
 /* Same work on device-resident buffers; only enqueues on `hip_stream` (a hipStream_t, NULL = default). */
 int  salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, uint32_t n_reads,

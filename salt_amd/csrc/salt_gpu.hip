@@ -7,6 +7,7 @@
 #include <string.h>
 #include <time.h>
 #include <cstddef>
+#include <cctype>
 #include <string>
 #include <thread>
 #include <vector>
@@ -521,6 +522,27 @@ extern "C" int salt_gpu_host_alloc(uint64_t bytes, void **ptr)
     return SALT_OK;
 }
 extern "C" void salt_gpu_host_free(void *ptr) { if (ptr) hipHostFree(ptr); }
+
+// The host NUMA node a device hangs off (its PCI function's numa_node in sysfs); -1 when the platform does not say.  A multi-GPU driver pins
+// each device's worker threads -- and allocates their page-locked buffers from them -- on that node: the reads' and the SAM text's DMA then
+// stays on the socket the GPU is attached to.
+extern "C" int salt_gpu_device_numa_node(int device, int *node)
+{
+    if (!node) return fail(SALT_E_INVAL, "null argument");
+    *node = -1;
+    char bus[64] = { 0 };
+    HIPCHK(hipDeviceGetPCIBusId(bus, (int)sizeof bus, device));
+    for (char *c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    if (FILE *f = fopen(path.c_str(), "r")) { int v = -1; if (fscanf(f, "%d", &v) == 1) *node = v; fclose(f); }
+    return SALT_OK;
+}
+extern "C" int salt_gpu_device_count(int *n)
+{
+    if (!n) return fail(SALT_E_INVAL, "null argument");
+    HIPCHK(hipGetDeviceCount(n));
+    return SALT_OK;
+}
 
 #define REGROW(ptr, cap, need, type) do { if ((need) > (cap)) { HIPCHK(hipStreamSynchronize(st)); hipFree(ptr); (ptr) = nullptr; (cap) = 0; \
     const uint64_t want_ = (need) + (need) / 4; HIPCHK(hipMalloc((void **)&(ptr), want_ * sizeof(type))); (cap) = want_; } } while (0)

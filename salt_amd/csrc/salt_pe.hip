@@ -324,6 +324,62 @@ __device__ __forceinline__ int tb_band_pass(int32_t *__restrict__ hb, int32_t *_
     return dpp_max8(mx);
 }
 
+// The same pass for bands of at most eight cells (half-width <= 3: an alignment whose ends differ by up to two bases, before any doubling
+// -- nearly every mate rescue), with the band arrays in REGISTERS: lane t IS array index t + 1 of h_b / e_b (index 0 is the constant 0), the
+// upper row's cells come over DPP row shifts (rows shift by one index once i > w), and a row is ~35 VALU instructions with no LDS round
+// trip in its dependency chain (the LDS version waits ~6 of them per row).  The arrays' contents are tracked exactly, including what the
+// reference leaves behind in indices a row does not write and the index it zeroes at the band's edge.
+template <int N> __device__ __forceinline__ int dpp_row_shl(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x100 + N, 0xF, 0xF, true); }
+__device__ __forceinline__ int tb_band_pass_small(uint8_t *__restrict__ dir, const uint8_t *rd, const uint8_t *rf, const int aware,
+                                                  const int refLen, const int readLen, const int bw)
+{
+    const int lane = (int)(threadIdx.x & 7u);
+    const int go = 3, ge = 1;
+    const int width = 2 * bw + 3, width_d = 2 * bw + 1;                          // width - 1 <= 8: indices 1 .. 8 live in lanes 0 .. 7
+    int Hp = 0, Ep = 0, mx = 0;                                                  // h_b[lane + 1], e_b[lane + 1]
+    for (int i = 0; i < readLen; ++i) {
+        const int x = i - bw > 0 ? i - bw : 0, xp = i - 1 - bw > 0 ? i - 1 - bw : 0, d = x - xp;
+        const int end = refLen - 1 < i + bw ? refLen - 1 : i + bw, n = end - x + 1;
+        const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
+        if (lane + 1 == edge) { Hp = 0; Ep = 0; }                                // h_b[edge] = e_b[edge] = 0 (ssw.c:593)
+        const bool act = lane < n;
+        const int j = x + lane;
+        const uint32_t rc = rd[i], sym = act ? (uint32_t)rf[j] : 0u;
+        // h_b[e], e_b[e], h_b[e - 1] with e = lane + d + 1: this lane's or a neighbour's register
+        const int Hn = dpp_row_shl<1>(Hp), En = dpp_row_shl<1>(Ep);
+        int Hl = dpp_row_shr<1>(Hp);
+        if (lane == 0) Hl = 0;                                                   // h_b[0]
+        const int hb_e = d ? (lane == 7 ? 0 : Hn) : Hp, eb_e = d ? (lane == 7 ? 0 : En) : Ep, hb_d = d ? Hp : Hl;
+        const int t1 = i == 0 ? -go : hb_e - go, t2 = i == 0 ? -ge : eb_e - ge;
+        const int E = t1 > t2 ? t1 : t2, e_open = t1 > t2 ? 1 : 0;
+        const int e1 = E > 0 ? E : 0;
+        const int diag = hb_d + sw_score(aware, sym, rc);
+        const int A = e1 > diag ? e1 : diag;
+        int inc = act ? A - go + j * ge : TB_NEG;
+        { const int t = dpp_row_shr<1>(inc); if (lane >= 1) inc = inc > t ? inc : t; }
+        { const int t = dpp_row_shr<2>(inc); if (lane >= 2) inc = inc > t ? inc : t; }
+        { const int t = dpp_row_shr<4>(inc); if (lane >= 4) inc = inc > t ? inc : t; }
+        int exc = dpp_row_shr<1>(inc);
+        if (lane == 0) exc = TB_NEG;
+        const int f_init = -(lane + 1) * ge, f_open = exc - (j - 1) * ge;
+        const int f = f_init > f_open ? f_init : f_open;
+        const int f1 = f > 0 ? f : 0;
+        const int tt = e1 > f1 ? e1 : f1;
+        const int H = tt > diag ? tt : diag;
+        int Hleft = dpp_row_shr<1>(H), fleft = dpp_row_shr<1>(f);
+        if (lane == 0) { Hleft = 0; fleft = 0; }
+        const int f_opened = (Hleft - go > fleft - ge) ? 1 : 0;
+        const int hsel = tt <= diag ? 0 : (e1 > f1 ? 1 : 2);
+        if (act) {
+            Ep = E; Hp = H;
+            dir[(size_t)i * (size_t)width_d + (size_t)lane] = (uint8_t)(hsel | (e_open << 2) | (f_opened << 3));
+            mx = mx > H ? mx : H;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    return dpp_max8(mx);
+}
+
 // the walk back (ssw.c:650-713) by the group's first lane: (len << 4 | op) runs into cig[], first operation first.
 // Returns their number, 0 on a walk that leaves the direction bytes (the reference's "Trace back error": no CIGAR), -1 when more than cap.
 __device__ __forceinline__ int tb_walk(const uint8_t *dir, const int64_t n_dir, const int refLen, const int readLen, const int bw, uint16_t *stack, uint16_t *cig, const int cap)
@@ -478,16 +534,36 @@ k_swtb(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict_
         const int rfl = ref_end - ref_begin + 1, rdl = read_end - read_begin + 1, aware = rq.aware;
         const uint32_t off = offs[rq.mate], L = offs[rq.mate + 1] - off;
         int n_cig = 0;
+        if (aware != 2 && rdl < 20) { if (lane == 0) { o->n_cigar = 0; o->ok = 0; } continue; }      // alnpe.c:297 turns it down whatever its CIGAR (polish keeps every CIGAR)
         if (rfl > 0 && rdl > 0 && (uint32_t)rdl <= tg.read_b) {
             const uint32_t ref0 = rq.start + (uint32_t)ref_begin;
-            for (int t = (int)lane; t < rdl; t += 8) {               // the aligned part of the mate on the requested strand
-                const uint32_t q = (uint32_t)(read_begin + t);
-                uint32_t c = rq.strand ? seqs[off + (L - 1 - q)] : seqs[off + q];
-                if (rq.strand && c < 4) c = 3 - c;
-                rd[t] = (uint8_t)(c > 4 ? 4 : c);
+            // the aligned part of the mate on the requested strand and the alignment's reference symbols: 64 per trip and group (eight loads
+            // of a lane in flight together; one after the other they were most of this kernel's time)
+            for (int t0 = 0; t0 < rdl; t0 += 64) {
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int t = t0 + 8 * k + (int)lane;
+                    const uint32_t q = (uint32_t)(read_begin + (t < rdl ? t : 0));
+                    v[k] = rq.strand ? seqs[off + (L - 1 - q)] : seqs[off + q];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int t = t0 + 8 * k + (int)lane;
+                    uint32_t c = v[k];
+                    if (rq.strand && c < 4) c = 3 - c;
+                    if (t < rdl) rd[t] = (uint8_t)(c > 4 ? 4 : c);
+                }
             }
             const bool ref_in_lds = (uint32_t)rfl <= tg.ref_b;
-            if (ref_in_lds) for (int t = (int)lane; t < rfl; t += 8) rf[t] = (uint8_t)ref_symbol(ix, pac, aware, ref0 + (uint32_t)t);
+            if (ref_in_lds)
+                for (int t0 = 0; t0 < rfl; t0 += 64) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const int t = t0 + 8 * k + (int)lane; v[k] = ref_symbol(ix, pac, aware, ref0 + (uint32_t)(t < rfl ? t : 0)); }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const int t = t0 + 8 * k + (int)lane; if (t < rfl) rf[t] = (uint8_t)v[k]; }
+                }
             int bw = rfl - rdl; bw = (bw < 0 ? -bw : bw) + 1;
             int mx = 0;
             bool fits = true, dir_lds = true;
@@ -498,7 +574,8 @@ k_swtb(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict_
                 if (width > (int)SW_BAND_W || (!dir_lds && (uint64_t)width_d * (uint64_t)rdl > gdir_cap) || (dbg_max_bw && bw > dbg_max_bw)) { fits = false; break; }
                 int m;
                 const uint8_t *rfp = ref_in_lds ? rf : nullptr;
-                if (rows_lds && dir_lds) m = tb_band_pass<true, true>(lrows, lrows + tg.row_w, lrows + 2 * tg.row_w, ldir, rd, rfp, ix, pac, aware, ref0, rfl, rdl, bw);
+                if (width - 1 <= 8 && dir_lds && ref_in_lds) m = tb_band_pass_small(ldir, rd, rf, aware, rfl, rdl, bw);
+                else if (rows_lds && dir_lds) m = tb_band_pass<true, true>(lrows, lrows + tg.row_w, lrows + 2 * tg.row_w, ldir, rd, rfp, ix, pac, aware, ref0, rfl, rdl, bw);
                 else if (rows_lds) m = tb_band_pass<true, false>(lrows, lrows + tg.row_w, lrows + 2 * tg.row_w, gdir, rd, rfp, ix, pac, aware, ref0, rfl, rdl, bw);
                 else if (dir_lds) m = tb_band_pass<false, true>(grows, grows + SW_BAND_W, grows + 2 * SW_BAND_W, ldir, rd, rfp, ix, pac, aware, ref0, rfl, rdl, bw);
                 else m = tb_band_pass<false, false>(grows, grows + SW_BAND_W, grows + 2 * SW_BAND_W, gdir, rd, rfp, ix, pac, aware, ref0, rfl, rdl, bw);

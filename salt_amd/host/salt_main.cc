@@ -12,6 +12,7 @@
 #include "../../include/salt_host.h"
 #include <fcntl.h>
 #include <getopt.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -297,6 +298,29 @@ void parse_batch(std::vector<char> &raw, Batch &b, Pool &pool)
     });
 }
 
+// The calling thread (and the threads it creates) onto the host NUMA node its GPU is attached to: the chunk a worker preads, the page-locked
+// buffers allocated from it and the SAM text it writes then stay on that socket, and with --gpus N every GPU's workers use their own
+// socket's cores and memory instead of contending for one.  Nothing happens when the platform does not name a node (or SALT_NO_PIN=1).
+void pin_to_device_node(int device)
+{
+    static const bool off = getenv("SALT_NO_PIN") && atoi(getenv("SALT_NO_PIN"));
+    int node = -1;
+    if (off || salt_gpu_device_numa_node(device, &node) || node < 0) return;
+    char path[96]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    cpu_set_t set; CPU_ZERO(&set);
+    int a, b, any = 0; char sep;
+    while (fscanf(f, "%d", &a) == 1) {                        // "0-63,128-191"
+        b = a;
+        if (fscanf(f, "%c", &sep) == 1 && sep == '-') { if (fscanf(f, "%d", &b) != 1) break; if (fscanf(f, "%c", &sep) != 1) sep = 0; }
+        for (int c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET(c, &set); any = 1; }
+        if (sep != ',') break;
+    }
+    fclose(f);
+    if (any) sched_setaffinity(0, sizeof set, &set);
+}
+
 double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + ts.tv_nsec * 1e-9; }
 
 int usage()
@@ -430,8 +454,10 @@ static void text_plan(TextPlan &P, const char *fn_reads, int n_gpus, int n_threa
     P.in_buf.assign((size_t)P.n_workers, nullptr); P.sam_buf.assign((size_t)P.n_workers, nullptr);
     P.alloc = std::thread([&P]() {
         const double t = now();
-        for (int w = 0; w < P.n_workers && P.alloc_ok; ++w)
+        for (int w = 0; w < P.n_workers && P.alloc_ok; ++w) {
+            if (w % P.wpg == 0) pin_to_device_node(w / P.wpg);    // worker w's buffers from its GPU's node
             if (salt_gpu_host_alloc(P.in_cap, (void **)&P.in_buf[(size_t)w]) || salt_gpu_host_alloc(P.sam_cap, (void **)&P.sam_buf[(size_t)w])) P.alloc_ok = false;
+        }
         P.alloc_s = now() - t;
     });
 }
@@ -475,6 +501,7 @@ static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector
     for (int wk = 0; wk < n_workers; ++wk)
         workers.emplace_back([&, wk]() {
             salt_gpu_ws_t *ws = nullptr; char *buf = P.in_buf[(size_t)wk];
+            pin_to_device_node(wk / n_workers_per_gpu);
             const bool trace = getenv("SALT_TEXT_TRACE") != nullptr;      // per-worker timeline on stderr
             const double tw_start = now(); int n_calls = 0; double t_first = 0, t_rest = 0;
             uint32_t ws_reads = max_reads;
@@ -665,6 +692,7 @@ static int run_pe_text(const char *fn1, const char *fn2, salt_index_t *ix, const
     for (int wk = 0; wk < P.n_workers; ++wk)
         workers.emplace_back([&, wk]() {
             salt_gpu_ws_t *ws = nullptr; char *buf = P.in_buf[(size_t)wk];
+            pin_to_device_node(wk / P.wpg);
             if (salt_gpu_ws_create(gix[(size_t)(wk / P.wpg)], P.max_reads + 64, (uint64_t)(P.max_reads + 64) * 160, &ws) ||
                 (P.head_read_len && salt_gpu_ws_reserve_text(ws, &ao, P.in_cap, P.max_reads, P.head_read_len, P.sam_cap - 64, P.sam_buf[(size_t)wk], P.sam_cap))) {
                 fprintf(stderr, "[salt] %s\n", salt_gpu_last_error()); set_failed(); return;
@@ -939,6 +967,7 @@ int main(int argc, char **argv)
     const int fmt_threads = n_threads / (n_gpus * WPG) > 0 ? n_threads / (n_gpus * WPG) : 1;
     for (int g = 0; g < n_gpus * WPG; ++g)
         workers.emplace_back([&, g]() {
+            pin_to_device_node(g / WPG);                      // before the pool: its threads inherit the node
             Pool pool(fmt_threads);
             for (;;) {
                 std::unique_ptr<Batch> b;

@@ -45,6 +45,7 @@ int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint64_t max_ba
 int salt_gpu_ws_reserve_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint64_t b, uint32_t r, uint32_t l, uint64_t sb, void *hs, uint64_t hb)
 { (void)ws; (void)o; (void)b; (void)r; (void)l; (void)sb; (void)hs; (void)hb; return SALT_OK; }
 void salt_gpu_ws_destroy(salt_gpu_ws_t *ws) { if (ws) { free(ws->sam); free(ws); } }
+int salt_gpu_device_numa_node(int device, int *node) { (void)device; *node = -1; return SALT_OK; }
 int salt_gpu_host_alloc(uint64_t bytes, void **ptr) { *ptr = malloc(bytes); return *ptr ? SALT_OK : SALT_E_NOMEM; }
 void salt_gpu_host_free(void *ptr) { free(ptr); }
 /* so_result_t -> salt_result_t: binary CIGARs; the CIGARs of gapped alternative hits (the device delivers them for sam_add_xa, sam.c:216-225)
