@@ -35,7 +35,7 @@ extern "C" {
 
 #define SALT_MAX_READ_LEN   512  /* bases per read handled by the kernels */
 #define SALT_MAX_HITS       5    /* aln.h:133 */
-#define SALT_MAX_LOCATE     1024 /* upper bound accepted for -m (reference default 1000) */
+#define SALT_MAX_LOCATE     1024 /* located rows per strand kept in LDS (reference default -m 1000); -m up to 262144 is accepted, larger lists go to global memory */
 #define SALT_MAX_SEED_SLOTS 512  /* seeds per strand, ceil((L-k+1)/overlap): any stride down to -r 1 on reads of SALT_MAX_READ_LEN bases */
 #define SALT_MAX_CIGAR_OPS  64
 

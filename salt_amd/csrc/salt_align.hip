@@ -661,6 +661,7 @@ struct CandArgs {                      // everything by value: a by-reference In
     uint32_t ref_len, spr, max_locate, r, L; int strand; bool gap_mode; unsigned long long *phase;
     uint32_t *loci; uint32_t loci_cap; int pe;
     bool finish;                   // false: stop after locate (unsorted, duplicates and out-of-range loci still in)
+    const uint4 *r_ctx;                    // non-null (with c_ctx): the R rows' records, used the same way
     const uint4 *c_ctx; uint32_t ctx_k;    // non-null: rows come from the context table and a row whose window has more than 3 mismatches for
                                            // certain (ctx_reject, salt_device.h) is counted against the caps but not stored.  Gap-free pass only.
 };
@@ -693,7 +694,8 @@ __device__ __attribute__((noinline)) CandStats build_candidates(W &w)
     struct { gp_u32 c_sa, r_pos; uint32_t ref_len; } ix = { as_global(a.c_sa), as_global(a.r_pos), a.ref_len };
     struct { uint32_t spr, max_locate; } ap = { a.spr, a.max_locate };
     uint32_t n_sa_c = 0, n_sa_r = 0, n_loci_out = 0;
-    uint32_t *loci = PE ? a.loci : w.loci;                   // PE: decided below, once the number of rows is known
+    const bool glob = a.loci != nullptr;                      // a global list is there (paired end; single end with -m above the LDS list): used when the rows outgrow the LDS
+    uint32_t *loci = glob ? a.loci : w.loci;                 // decided below, once the number of rows is known
     PhaseClock pc(a.phase);
     const uint64_t base_item = ((uint64_t)r * 2u + (uint32_t)strand) * ap.spr;
     uint32_t n_list[2] = { 0, 0 };
@@ -733,7 +735,7 @@ __device__ __attribute__((noinline)) CandStats build_candidates(W &w)
     if (rows > cap_total && lane < 2) { SaiLists sl = sai_ref(w.u.sai); sai_introsort(sl, (int)lane, (int)n_list[lane]); }
     // a PE mate may enumerate 0x40000 loci, which need the global scratch; the usual few hundred stay in LDS like an SE read's (the
     // verify and rule passes then pay one memory round trip per trip instead of two or three)
-    const bool pe_in_lds = PE && rows <= (uint32_t)MAXLOC;
+    const bool pe_in_lds = !glob || rows <= (uint32_t)MAXLOC;
     if (pe_in_lds) loci = w.loci;
     WSYNC();
     pc.stamp(SALT_CTR_T_GATHER);
@@ -781,6 +783,8 @@ __device__ __attribute__((noinline)) CandStats build_candidates(W &w)
         }
     }
     pc.stamp(SALT_CTR_X2);
+    const gp_u32x4 r_ctx = as_global(a.r_ctx);
+    const bool use_rctx = use_ctx && a.r_ctx != nullptr;
     for (uint32_t i = 0; i < n_list[1] && !full; ++i) {
         const uint32_t sp = w.u.sai.sp[1][i], ep = w.u.sai.ep[1][i], off = w.u.sai.off[1][i];
         uint32_t skip = (ep + 1 - sp) / 0x40000u;                                       // alnse.c:707-708
@@ -788,22 +792,33 @@ __device__ __attribute__((noinline)) CandStats build_candidates(W &w)
         // PE: an interval wider than max_locate is subsampled with rand() in the reference (alnse.c:587-595), i.e. its
         // result is not defined; the stand-in keeps the first row of every block of (ep-sp)/max_locate rows
         if (PE) skip = ep - sp > ap.max_locate ? (ep - sp) / ap.max_locate : 1;
+        CtxRead rd = { 0, 0, 0 };
+        if (use_rctx) rd = ctx_read(w.pm[strand], L, off, a.ctx_k);
         for (uint64_t j0 = sp; j0 <= ep && !full; j0 += 64ull * skip) {
             pc.add(SALT_CTR_X1, 1);
             uint64_t j = j0 + (uint64_t)lane * skip;
-            bool in = j <= ep, keep = false;
+            bool in = j <= ep, keep = false, rej = false;
             uint32_t pos = 0;
-            if (in) { pos = ix.r_pos[j] - off; keep = !(pos > ix.ref_len || pos + L > ix.ref_len); }   // alnse.c:715-717
+            if (in) {
+                uint32_t rp;
+                if (use_rctx) { const u32x4_t rc = r_ctx[j]; rp = rc.x; rej = ctx_reject(make_uint4(rc.x, rc.y, rc.z, rc.w), rd, 3u); }
+                else rp = ix.r_pos[j];
+                pos = rp - off; keep = !(pos > ix.ref_len || pos + L > ix.ref_len);      // alnse.c:715-717
+            }
             uint64_t m = __ballot(keep);
             uint32_t rank = (uint32_t)__popcll(m & lt);
-            if (keep && n + rank < cap_total) loci[ns + rank] = pos;
+            const bool st = keep && !rej && n + rank < cap_total;                       // inside the cap and not ruled out by its context
+            const uint64_t ms = __ballot(st);
+            if (st) loci[ns + (uint32_t)__popcll(ms & lt)] = pos;
+            ns += (uint32_t)__popcll(ms);
             uint32_t tot = (uint32_t)__popcll(m);
             if (n + tot >= cap_total) {
                 uint64_t last = m; uint32_t need = cap_total - n;
                 for (uint32_t q = 1; q < need; ++q) last &= last - 1;
-                n_sa_r += (uint32_t)__ffsll((long long)last);
-                ns += need; n = cap_total; full = true;
-            } else { n += tot; ns += tot; n_sa_r += (uint32_t)__popcll(__ballot(in)); }
+                const uint32_t looked = (uint32_t)__ffsll((long long)last);
+                n_sa_r += looked; if (use_rctx) n_ctx_rows += looked;
+                n = cap_total; full = true;
+            } else { n += tot; const uint32_t looked = (uint32_t)__popcll(__ballot(in)); n_sa_r += looked; if (use_rctx) n_ctx_rows += looked; }
         }
     }
     const uint32_t n_ctx_rej = n - ns;
@@ -811,7 +826,7 @@ __device__ __attribute__((noinline)) CandStats build_candidates(W &w)
     n = ns;                                                   // what the passes below see
     WSYNC();
     bool in_lds = pe_in_lds;
-    if (PE && !in_lds && n <= (uint32_t)MAXLOC) {
+    if (glob && !in_lds && n <= (uint32_t)MAXLOC) {
         // the rows that were ENUMERATED outgrew the LDS list, the rows the context table let through do not: bring them in (one trip now
         // instead of two or three per verify / rule pass)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1388,8 +1403,9 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_lv = 0, c_loci = 0, c_ctx_rej = 0, c_ctx_rows = 0;
     PhaseClock pc(phase);
     const uint64_t rt0 = phase ? __builtin_amdgcn_s_memrealtime() : 0;
-    uint32_t *loci = PE ? pe_loci : w.loci;                   // candidate loci: LDS; for PE mates the global scratch when a list outgrows it
-    uint8_t *cand_e = PE ? pe_cand : w.cand_e;                // (set after every build_candidates call from what it reports)
+    const bool glob = pe_loci != nullptr;                     // paired end (0x40000 loci per strand, alnse.c:42) or single end with -m above the LDS list
+    uint32_t *loci = glob ? pe_loci : w.loci;                 // candidate loci: LDS, or the block's global scratch when a list outgrows it
+    uint8_t *cand_e = glob ? pe_cand : w.cand_e;              // (set after every build_candidates call from what it reports)
     const uint32_t loci_cap = PE ? PE_LOCI_CAP : (uint32_t)MAXLOC;
 
     // ---- the read: one-hot masks of both strands, 8 bases per word, LSB first like the mixRef (editdistance.c:40) ----
@@ -1428,8 +1444,8 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         // Located rows first, unsorted: only loci that can pass (<= 3 mismatches, inside the reference) matter to the
         // sequential rule, so the sort (alnse.c:726-729), the duplicate filter (alnse.c:758-762) and the rule run on
         // those few; the result is the one the full sorted list gives.
-        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, false, ix.c_ctx, ix.ctx_k }, w);
-        if (PE) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
+        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, pe_loci, loci_cap, ap.pe, false, ix.r_ctx, ix.c_ctx, ix.ctx_k }, w);
+        if (glob) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
         pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
         const uint32_t n_loc = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci; c_ctx_rej += cs.n_ctx_rej; c_ctx_rows += cs.n_ctx_rows;
         uint32_t call_best_n = INF, call_best_pos = 0;
@@ -1480,8 +1496,8 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                     uint32_t n = n_loc_s[1];
                     if (strand == 0 || ix.c_ctx != nullptr) {
                         WSYNC();
-                        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, false, nullptr, 0 }, w);
-                        if (PE) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
+                        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, pe_loci, loci_cap, ap.pe, false, nullptr, nullptr, 0 }, w);
+                        if (glob) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
                         c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
                         n = cs.n_cand;
                     }
@@ -1533,8 +1549,8 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         }
         for (int strand = 0; strand < 2; ++strand) {
             pc.stamp(SALT_CTR_T_GAP);
-            const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, PE ? pe_loci : w.loci, loci_cap, ap.pe, true, nullptr, 0 }, w);
-            if (PE) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
+            const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, pe_loci, loci_cap, ap.pe, true, nullptr, nullptr, 0 }, w);
+            if (glob) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
             pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
             const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
             bool any = false;

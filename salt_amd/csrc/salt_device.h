@@ -60,6 +60,7 @@ struct IndexView {
     const COcc *c_occ; const uint32_t *c_sa; const uint32_t *lkt;
     const ROcc *r_occ; const uint32_t *r_pos; const uint4 *wlkt; const uint32_t *ref; const uint32_t *text;
     const uint4 *c_ctx; uint32_t ctx_k;                            // nullptr: absent
+    const uint4 *r_ctx;                                            // the same records for the R rows (.x = r_pos of the row); outside the image, built with the paired-end genome (set_pac); nullptr: absent
     uint32_t c_primary, c_L2[5], c_seq_len;
     uint32_t r_text_len, r_inv_sa0, r_cum[6];
     uint32_t ref_len, lkt_len, r_lkt_len;

@@ -31,6 +31,7 @@ struct salt_gpu_index {
     ImageHeader hdr;               // host copy
     IndexView view;
     uint8_t *d_pac = nullptr; uint64_t l_pac = 0;      // 2-bit genome for the PE singleton rescue (not part of the image)
+    uint4 *d_rctx = nullptr;                            // context records of the R rows (paired end; not part of the image)
     int64_t *d_c_off = nullptr; uint32_t *d_c_name_off = nullptr; char *d_c_names = nullptr; int32_t n_contigs = 0;     // contig table for the SAM kernels
 };
 
@@ -84,6 +85,7 @@ static void make_view(salt_gpu_index *ix)
     v.ref = reinterpret_cast<const uint32_t *>(b + h.off_ref);
     v.text = reinterpret_cast<const uint32_t *>(b + h.off_text);
     v.c_ctx = h.off_ctx ? reinterpret_cast<const uint4 *>(b + h.off_ctx) : nullptr; v.ctx_k = h.ctx_k;
+    v.r_ctx = ix->d_rctx;
     v.c_primary = h.c_primary; memcpy(v.c_L2, h.c_L2, sizeof v.c_L2); v.c_seq_len = h.c_seq_len;
     v.r_text_len = h.r_text_len; v.r_inv_sa0 = h.r_inv_sa0; memcpy(v.r_cum, h.r_cum, sizeof v.r_cum);
     v.ref_len = h.ref_len; v.lkt_len = h.lkt_len; v.r_lkt_len = h.r_lkt_len;
@@ -213,6 +215,7 @@ extern "C" void salt_gpu_index_detach(salt_gpu_index_t *ix)
     if (!ix) return;
     if (ix->owns && ix->image) { hipSetDevice(ix->device); hipFree(ix->image); }
     if (ix->d_pac) { hipSetDevice(ix->device); hipFree(ix->d_pac); }
+    if (ix->d_rctx) { hipSetDevice(ix->device); hipFree(ix->d_rctx); }
     if (ix->d_c_off) { hipSetDevice(ix->device); hipFree(ix->d_c_off); hipFree(ix->d_c_name_off); hipFree(ix->d_c_names); }
     delete ix;
 }
@@ -346,7 +349,7 @@ static int check_opt(const salt_gpu_index *ix, const salt_aln_opt_t *o, uint32_t
 {
     if (o->l_seed < (int32_t)ix->hdr.r_lkt_len) return fail(SALT_E_INVAL, "l_seed shorter than the device k-mer table (set SALT_GPU_LKT_LEN or pass l_seed at attach)");
     if (o->l_overlap <= 0) return fail(SALT_E_INVAL, "l_overlap must be positive (aln.c:223 sets it to l_seed when -r is absent)");
-    if (o->max_locate == 0 || o->max_locate > SALT_MAX_LOCATE) return fail(SALT_E_INVAL, "max_locate (-m) must be in 1..1024");
+    if (o->max_locate == 0 || o->max_locate > PE_LOCI_CAP) return fail(SALT_E_INVAL, "max_locate (-m) must be in 1..262144");
     if (o->max_hits != SALT_MAX_HITS) return fail(SALT_E_INVAL, "max_hits is fixed at 5 (aln.h:133)");
     if (max_len > SALT_MAX_READ_LEN) return fail(SALT_E_INVAL, "read longer than SALT_MAX_READ_LEN (512)");
     uint32_t spr = 1;
@@ -403,7 +406,10 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
 #ifdef SALT_DIAG
     { const char *e = getenv("SALT_GPU_LIGHT_STOP"); ap.dbg_stop = e ? atoi(e) : 0; } { static const int hs = getenv("SALT_GPU_HEAVY_STOP") ? atoi(getenv("SALT_GPU_HEAVY_STOP")) : 0; ap.heavy_stop = hs; }
 #endif
-    if (pe && !ws->d_pe_scr) HIPCHK(hipMalloc((void **)&ws->d_pe_scr, (uint64_t)ws->heavy_blocks * PE_LOCI_CAP * 5));
+    // located rows beyond the LDS list (SALT_MAX_LOCATE) live in a global list per persistent block: paired end always may need it (0x40000
+    // loci per strand, alnse.c:42,533), single end when -m is above the LDS list (the reference grows its vector, alnse.c:678, kvec.h)
+    const bool glob_loci = pe || o->max_locate > SALT_MAX_LOCATE;
+    if (glob_loci && !ws->d_pe_scr) HIPCHK(hipMalloc((void **)&ws->d_pe_scr, (uint64_t)ws->heavy_blocks * PE_LOCI_CAP * 5));
     unsigned long long *ctr = o->collect_counters ? ws->d_ctr : nullptr;
     const bool timed = ws->timing && ws->n_timed < MAX_TIMED;
     hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * EV_PER_CALL] : nullptr;
@@ -419,7 +425,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     if (timed) HIPCHK(hipEventRecord(ev[3], st));
     launch_heavy(ws->ix->view, ap, ws->d_pm, ws->d_sai_c, ws->d_sai_r,
                  static_cast<salt_result_t *>(d_results), ws->d_queue, ctr, ws->heavy_blocks, ws->gap_blocks, ws->d_lvtab,
-                 gap_bufs_layout(ws->d_gap, ws->gcap, ws->d_qctl, nullptr), ws->d_queue + ws->max_reads, pe ? ws->d_pe_scr : nullptr, timed ? ev + 4 : nullptr, st);
+                 gap_bufs_layout(ws->d_gap, ws->gcap, ws->d_qctl, nullptr), ws->d_queue + ws->max_reads, glob_loci ? ws->d_pe_scr : nullptr, timed ? ev + 4 : nullptr, st);
     if (timed) { HIPCHK(hipEventRecord(ev[7], st)); ws->ev_pe[ws->n_timed] = 0; ++ws->n_timed; }
     HIPCHK(hipGetLastError());
     return SALT_OK;
@@ -560,7 +566,7 @@ extern "C" int salt_gpu_ws_reserve_text(salt_gpu_ws_t *ws, const salt_aln_opt_t 
     HIPCHK(hipSetDevice(ws->ix->device));
     hipStream_t st = ws->stream;
     REGROW(ws->d_raw, ws->raw_cap, max_block_bytes + 64, uint8_t);
-    if (!ws->d_tctl) HIPCHK(hipMalloc((void **)&ws->d_tctl, 16));
+    if (!ws->d_tctl) HIPCHK(hipMalloc((void **)&ws->d_tctl, 32));      // parse ctl[4] | the SAM block's byte count in 64 bits
     REGROW(ws->d_tile, ws->tile_cap, ws->raw_cap / FQ_TILE + 4, uint32_t);
     {
         const size_t need = text_scan_bytes(std::max<uint64_t>(ws->tile_cap, (uint64_t)ws->max_reads + 2));
@@ -614,7 +620,7 @@ extern "C" int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
     // ---- the raw block and its lines ----
     REGROW(ws->d_raw, ws->raw_cap, n_bytes + 64, uint8_t);
     const uint64_t n_tiles = (n_bytes + FQ_TILE - 1) / FQ_TILE;
-    if (!ws->d_tctl) HIPCHK(hipMalloc((void **)&ws->d_tctl, 16));
+    if (!ws->d_tctl) HIPCHK(hipMalloc((void **)&ws->d_tctl, 32));      // parse ctl[4] | the SAM block's byte count in 64 bits
     {   // tile counters + scan scratch follow the raw capacity
         const uint64_t tiles_cap = ws->raw_cap / FQ_TILE + 4;
         REGROW(ws->d_tile, ws->tile_cap, tiles_cap, uint32_t);
@@ -675,10 +681,12 @@ extern "C" int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
     d.rg = ws->d_rg; d.rg_len = to->rg_id ? (int32_t)rg.size() : 0;
     d.pe = 0; d.min_tlen = d.max_tlen = 0;
     if (to->rg_id && rg.empty()) return fail(SALT_E_INVAL, "empty read group id");
-    HIPCHK(launch_sam_len(d, n_rec, ws->d_samoff, ws->d_scan, ws->scan_bytes, st));
-    uint32_t total = 0;
+    HIPCHK(launch_sam_len(d, n_rec, ws->d_samoff, reinterpret_cast<unsigned long long *>(ws->d_tctl + 4), ws->d_scan, ws->scan_bytes, st));
+    uint32_t total = 0; unsigned long long total64 = 0;
     HIPCHK(hipMemcpyAsync(&total, ws->d_samoff + n_rec, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&total64, ws->d_tctl + 4, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (total64 >> 32) return fail(SALT_E_CAPACITY, "the SAM text of this block passes 4 GiB (its offsets are 32-bit): hand over smaller blocks (SALT_CHUNK_MB)");
     mark();
     if ((uint64_t)total + 64 > ws->sam_cap) {
         hipFree(ws->d_sam); ws->d_sam = nullptr; if (ws->h_sam && ws->h_sam_owned) hipHostFree(ws->h_sam); ws->h_sam = nullptr; ws->sam_cap = 0; ws->h_sam_owned = true;
@@ -723,7 +731,7 @@ extern "C" int salt_gpu_align_pe_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
     const uint64_t b2 = (n1 + 3) & ~3ull;                      // block 2 behind block 1, on a word boundary
     REGROW(ws->d_raw, ws->raw_cap, b2 + n2 + 64, uint8_t);
     const uint64_t t1 = (n1 + FQ_TILE - 1) / FQ_TILE, t2 = (n2 + FQ_TILE - 1) / FQ_TILE;
-    if (!ws->d_tctl) HIPCHK(hipMalloc((void **)&ws->d_tctl, 16));
+    if (!ws->d_tctl) HIPCHK(hipMalloc((void **)&ws->d_tctl, 32));      // parse ctl[4] | the SAM block's byte count in 64 bits
     {
         REGROW(ws->d_tile, ws->tile_cap, ws->raw_cap / FQ_TILE + 16, uint32_t);
         const size_t need = text_scan_bytes(std::max<uint64_t>(ws->tile_cap, (uint64_t)ws->max_reads + 2));
@@ -785,13 +793,15 @@ extern "C" int salt_gpu_align_pe_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
     d.text = ix->view.text; d.ref = ix->view.ref; d.xa_cigar = to->print_xa_cigar; d.nm_md = to->print_nm_md;
     d.rg = ws->d_rg; d.rg_len = to->rg_id ? (int32_t)rg.size() : 0;
     d.pe = 1; d.min_tlen = pe->min_tlen; d.max_tlen = pe->max_tlen;
-    HIPCHK(launch_sam_len(d, n_rec, ws->d_samoff, ws->d_scan, ws->scan_bytes, st));
-    uint32_t total = 0, n_over = 0;
+    HIPCHK(launch_sam_len(d, n_rec, ws->d_samoff, reinterpret_cast<unsigned long long *>(ws->d_tctl + 4), ws->d_scan, ws->scan_bytes, st));
+    uint32_t total = 0, n_over = 0; unsigned long long total64 = 0;
     HIPCHK(hipMemcpyAsync(&total, ws->d_samoff + n_rec, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&total64, ws->d_tctl + 4, 8, hipMemcpyDeviceToHost, st));
     if (ws->d_pctl) HIPCHK(hipMemcpyAsync(&n_over, ws->d_pctl + 4, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (n_over) return fail(SALT_E_CAPACITY, std::to_string(n_over) + " mate rescue(s) need a Smith-Waterman band wider than this build holds (SW_BAND_W): "
                                              "the rows of this batch would differ from the reference's");
+    if (total64 >> 32) return fail(SALT_E_CAPACITY, "the SAM text of this block passes 4 GiB (its offsets are 32-bit): hand over smaller blocks (SALT_CHUNK_MB)");
     if ((uint64_t)total + 64 > ws->sam_cap) {
         hipFree(ws->d_sam); ws->d_sam = nullptr; if (ws->h_sam && ws->h_sam_owned) hipHostFree(ws->h_sam); ws->h_sam = nullptr; ws->sam_cap = 0; ws->h_sam_owned = true;
         const uint64_t want = (uint64_t)total + total / 4 + 64;
@@ -1231,6 +1241,17 @@ extern "C" int salt_gpu_index_set_pac(salt_gpu_index_t *ix, const uint8_t *pac, 
     HIPCHK(hipMemset(ix->d_pac, 0, bytes + 16));
     HIPCHK(hipMemcpy(ix->d_pac, pac, bytes, hipMemcpyHostToDevice));
     ix->l_pac = l_pac;
+    // Paired end: context records for the R rows as well (16 B per row of the R index, 20 GiB at GRCh38 scale), when the C rows have theirs
+    // and the device has the room; SALT_GPU_NO_RCTX=1 leaves them out.  Results do not depend on it (ctx_reject is a lower bound).
+    if (ix->view.c_ctx && !ix->d_rctx && !(getenv("SALT_GPU_NO_RCTX") && atoi(getenv("SALT_GPU_NO_RCTX")))) {
+        const uint64_t rbytes = ((uint64_t)ix->hdr.r_text_len + 1) * 16;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= rbytes + (32ull << 30) && hipMalloc((void **)&ix->d_rctx, rbytes) == hipSuccess) {
+            launch_build_r_ctx(ix->view, ix->hdr.ctx_k, ix->d_rctx, nullptr);
+            if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { hipFree(ix->d_rctx); ix->d_rctx = nullptr; return fail(SALT_E_HIP, "building the R context records failed"); }
+            ix->view.r_ctx = ix->d_rctx;
+        } else ix->d_rctx = nullptr;
+    }
     return SALT_OK;
 }
 

@@ -159,6 +159,41 @@ k_build_c_ctx(IndexView ix, uint32_t ctx_k, uint4 *__restrict__ out)
     }
 }
 
+// r_ctx: the same record for every row of the R index -- the genome around the position r_pos gives the row (the seed's first base): a
+// paired-end mate of a repeat enumerates up to max_locate rows of every R interval too (alnse.c:538-595), and two thirds of the candidate
+// windows k_heavy_pe looked at came from there
+__global__ void __launch_bounds__(256)
+k_build_r_ctx(IndexView ix, uint32_t ctx_k, uint4 *__restrict__ out)
+{
+    const uint64_t n = (uint64_t)ix.r_text_len + 1, stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t len = ix.c_seq_len < ix.ref_len ? ix.c_seq_len : ix.ref_len;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const uint32_t rp = ix.r_pos[j];
+        const uint64_t s = rp;
+        uint64_t lo = 0, hi = 0;
+        uint32_t ns[2] = { 0, 0 };
+        bool whole[2] = { s + ctx_k + CTX_N <= len, s >= CTX_N && s <= len };
+        for (int side = 0; side < 2; ++side) {
+            if (!whole[side]) { ns[side] = 3; continue; }
+            for (uint32_t t = 0; t < CTX_N; ++t) {
+                const uint64_t p = side == 0 ? s + ctx_k + t : s - 1 - t;
+                const uint32_t b = (ix.text[p >> 4] >> (30 - 2 * (uint32_t)(p & 15u))) & 3u;
+                const uint32_t mask = (ix.ref[p >> 3] >> (4 * (uint32_t)(p & 7u))) & 15u;
+                const uint32_t bit = side * CTX_N + t;
+                lo |= (uint64_t)(b & 1u) << bit; hi |= (uint64_t)(b >> 1) << bit;
+                ns[side] += mask != (1u << b);
+            }
+            if (ns[side] > 3) ns[side] = 3;
+        }
+        out[j] = ctx_pack(rp, lo, hi, ns[0], ns[1]);
+    }
+}
+void launch_build_r_ctx(const IndexView &ix, uint32_t ctx_k, uint4 *out, hipStream_t st)
+{
+    const uint64_t n = (uint64_t)ix.r_text_len + 1;
+    hipLaunchKernelGGL(k_build_r_ctx, dim3(stride_grid(n)), dim3(256), 0, st, ix, ctx_k, out);
+}
+
 void launch_build_c_ctx(const IndexView &ix, uint32_t ctx_k, uint4 *out, hipStream_t st)
 {
     const uint64_t n = (uint64_t)ix.c_seq_len + 1;

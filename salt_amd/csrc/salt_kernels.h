@@ -99,7 +99,7 @@ SwGeom sw_geom(uint32_t max_len, uint64_t max_window, uint32_t cus);
 void sw_geom_limit(SwGeom &g, uint32_t blocks);            // small batches: no more blocks than that (and their scratch)
 uint64_t sw_scratch_bytes(const SwGeom &g);
 struct PeSwReq { uint32_t start, end, mate; uint8_t strand, aware; uint16_t pad; };          // mate: index of the rescued mate (2p or 2p+1);
-                                                                                            // aware: 0 plain, 1 SNP-aware, 2 polish matrix; pad bit 0: score only
+                                                                                            // aware: 0 plain, 1 SNP-aware, 2 polish matrix; pad bit 0: score only, bit 1: mate rescue (no CIGAR for spans under 20 bases)
 struct PeSwRes { int32_t score1, score2, ref_begin, ref_end, read_begin, read_end; uint32_t start, strand; uint16_t n_cigar, ok; uint16_t cigar[SALT_MAX_CIGAR_OPS]; };
 struct PePair { uint32_t req0; uint8_t n_req; uint8_t rescued[2]; uint8_t pad; };             // requests req0 .. req0+n_req-1, in the order tried
 void launch_pair(uint32_t n_pairs, uint32_t min_tlen, uint32_t max_tlen, uint32_t l_pac, const uint32_t *offs, salt_result_t *res,
@@ -149,7 +149,7 @@ hipError_t launch_fq_parse_mate(const uint8_t *raw, uint32_t base, const uint32_
                                 uint32_t *ctl, hipStream_t st);
 hipError_t launch_text_scan(uint32_t *v, uint32_t n_plus_1, void *tmp, size_t tmp_bytes, hipStream_t st);       // exclusive scan in place
 hipError_t launch_fq_codes(const uint8_t *raw, const FqRec *rec, const uint32_t *offs, uint32_t n_rec, uint8_t *seqs, hipStream_t st);
-hipError_t launch_sam_len(const SamDev &d, uint32_t n, uint32_t *off, void *tmp, size_t tmp_bytes, hipStream_t st);
+hipError_t launch_sam_len(const SamDev &d, uint32_t n, uint32_t *off, unsigned long long *total64, void *tmp, size_t tmp_bytes, hipStream_t st);   // *total64: all bytes, 64-bit
 hipError_t launch_sam_write(const SamDev &d, uint32_t n, const uint32_t *off, char *out, hipStream_t st);
 static const uint32_t FQ_TILE = 1024;                                          // bytes per newline-count tile (k_fq_count)
 
@@ -158,6 +158,7 @@ void launch_pack_c_occ(const uint32_t *bwt, uint64_t bwt_words, uint32_t seq_len
 void launch_pack_r_occ(const uint32_t *code, uint64_t code_words, const uint32_t *minor, uint64_t minor_words, const uint32_t *major, uint64_t major_words,
                        uint32_t text_len, uint64_t n_blocks, ROcc *out, uint32_t *err, hipStream_t st);
 void launch_build_c_ctx(const IndexView &ix, uint32_t ctx_k, uint4 *out, hipStream_t st);
+void launch_build_r_ctx(const IndexView &ix, uint32_t ctx_k, uint4 *out, hipStream_t st);
 void launch_build_c_sa(const IndexView &ix, const uint32_t *sa_sampled, uint32_t sa_intv, uint32_t *out, hipStream_t st);
 void launch_build_r_pos(const IndexView &ix, const uint32_t *r_sa, uint32_t *out, hipStream_t st);
 void launch_build_text(const IndexView &ix, uint32_t *out, hipStream_t st);

@@ -534,7 +534,7 @@ k_swtb(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict_
         const int rfl = ref_end - ref_begin + 1, rdl = read_end - read_begin + 1, aware = rq.aware;
         const uint32_t off = offs[rq.mate], L = offs[rq.mate + 1] - off;
         int n_cig = 0;
-        if (aware != 2 && rdl < 20) { if (lane == 0) { o->n_cigar = 0; o->ok = 0; } continue; }      // alnpe.c:297 turns it down whatever its CIGAR (polish keeps every CIGAR)
+        if ((rq.pad & 2u) && rdl < 20) { if (lane == 0) { o->n_cigar = 0; o->ok = 0; } continue; }    // a mate rescue (pad bit 1): alnpe.c:297 turns it down whatever its CIGAR
         if (rfl > 0 && rdl > 0 && (uint32_t)rdl <= tg.read_b) {
             const uint32_t ref0 = rq.start + (uint32_t)ref_begin;
             // the aligned part of the mate on the requested strand and the alignment's reference symbols: 64 per trip and group (eight loads
@@ -663,7 +663,7 @@ k_pair(uint32_t n_pairs, uint32_t min_tlen, uint32_t max_tlen, uint32_t l_pac, c
     if (nr) {
         const uint32_t base = atomicAdd(&pctl[0], (uint32_t)nr);
         pr.n_req = (uint8_t)nr; pr.req0 = base;
-        for (int k = 0; k < nr; ++k) { PeSwReq r; r.start = st[k]; r.end = en[k]; r.mate = 2 * p + who[k]; r.strand = str[k]; r.aware = aw[k]; r.pad = 0; req[base + k] = r; pr.rescued[k] = who[k]; }
+        for (int k = 0; k < nr; ++k) { PeSwReq r; r.start = st[k]; r.end = en[k]; r.mate = 2 * p + who[k]; r.strand = str[k]; r.aware = aw[k]; r.pad = 2; req[base + k] = r; pr.rescued[k] = who[k]; }
     }
     pairs[p] = pr;
 }

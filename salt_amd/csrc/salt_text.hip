@@ -307,10 +307,14 @@ __device__ uint32_t sam_record_pe(const SamDev &d, uint32_t i, char *dst)
     return o.n;
 }
 
-__global__ void __launch_bounds__(256) k_sam_len(SamDev d, uint32_t n, uint32_t *__restrict__ len)
+// total64: the block's byte count in 64 bits next to the 32-bit offsets of the scan (a block whose SAM text passes 4 GiB is refused)
+__global__ void __launch_bounds__(256) k_sam_len(SamDev d, uint32_t n, uint32_t *__restrict__ len, unsigned long long *__restrict__ total64)
 {
-    if (d.pe) { TSTRIDE(i, n) len[i] = sam_record_pe<false>(d, (uint32_t)i, nullptr) + 2u; }       // + the record's newline and the driver's (alnpe.c:640-648)
-    else { TSTRIDE(i, n) len[i] = sam_record<false>(d, (uint32_t)i, nullptr) + 1u; }               // + the newline
+    unsigned long long mine = 0;
+    if (d.pe) { TSTRIDE(i, n) { const uint32_t l = sam_record_pe<false>(d, (uint32_t)i, nullptr) + 2u; len[i] = l; mine += l; } }   // + the record's newline and the driver's (alnpe.c:640-648)
+    else { TSTRIDE(i, n) { const uint32_t l = sam_record<false>(d, (uint32_t)i, nullptr) + 1u; len[i] = l; mine += l; } }          // + the newline
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(total64, mine);
 }
 // One wave per 64 consecutive records.  A thread that formats its record straight into the output writes single bytes at its own
 // address: 64 different cache lines per store instruction.  The records of a wave are contiguous in the output (off[] is a scan), so
@@ -400,11 +404,13 @@ hipError_t launch_fq_codes(const uint8_t *raw, const FqRec *rec, const uint32_t 
     hipLaunchKernelGGL(k_fq_codes, dim3(tgrid((uint64_t)n_rec * 64)), dim3(256), 0, st, raw, rec, offs, n_rec, seqs);
     return hipGetLastError();
 }
-hipError_t launch_sam_len(const SamDev &d, uint32_t n, uint32_t *off, void *tmp, size_t tmp_bytes, hipStream_t st)
+hipError_t launch_sam_len(const SamDev &d, uint32_t n, uint32_t *off, unsigned long long *total64, void *tmp, size_t tmp_bytes, hipStream_t st)
 {
     hipError_t e = hipMemsetAsync(off + n, 0, 4, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sam_len, dim3(tgrid(n)), dim3(256), 0, st, d, n, off);
+    e = hipMemsetAsync(total64, 0, 8, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_sam_len, dim3(tgrid(n)), dim3(256), 0, st, d, n, off, total64);
     return rocprim::exclusive_scan(tmp, tmp_bytes, off, off, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st);                        // off[n] = all bytes
 }
 hipError_t launch_sam_write(const SamDev &d, uint32_t n, const uint32_t *off, char *out, hipStream_t st)

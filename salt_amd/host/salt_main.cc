@@ -335,7 +335,7 @@ int usage()
             "           -r, --overlap       <int>    seed stride [seed length]\n"
             "           -v, --ref                    only seed on the primary reference\n"
             "           -s, --max_seed      <int>    max seed occ [50]\n"
-            "           -m, --max_locate    <int>    max loci per strand [1000]\n"
+            "           -m, --max_locate    <int>    max loci per strand [1000] (up to 262144)\n"
             "           -p, --pe                     paired end mode (two read files)\n"
             "           -a, --min_tlen      <int>    min template length [250]\n"
             "           -b, --max_tlen      <int>    max template length [550]\n"

@@ -323,15 +323,18 @@ def test_gpu_verifiers_never_dereference_a_wrapped_locate(mode):
 
 
 def test_gpu_rejects_what_it_cannot_do():
-    """Loud errors instead of silent fallbacks: -m above 1024, reads above 512 bp."""
+    """Loud errors instead of silent fallbacks: reads above SALT_MAX_READ_LEN = 512 bases (the kernels' LDS records; the reference's
+    Landau-Vishkin caps k at 30, LandauVishkin.c:13, so it aligns nothing meaningful beyond ~300 bases), -m above 262 144 (the located rows
+    of a strand: 1 024 in LDS, up to MAX_LOC_POS = 0x40000 in global memory).  The message names the limit."""
     import salt_amd
     idx = salt_amd.Index.reload(os.path.join(LAMBDA, "idx"))
     aln = salt_amd.GpuAligner(idx, device=0, max_reads=8, max_bases=8192)
     seq = np.zeros(600, dtype=np.uint8)
-    with pytest.raises(salt_amd.SaltError):
+    with pytest.raises(salt_amd.SaltError, match="SALT_MAX_READ_LEN"):
         aln.alnse_core1(salt_amd.AlnOpt(l_seed=idx.l_seed), seq, np.array([0, 600], dtype=np.uint32))
-    with pytest.raises(salt_amd.SaltError):
-        aln.alnse_core1(salt_amd.AlnOpt(l_seed=idx.l_seed, max_locate=5000), seq[:100], np.array([0, 100], dtype=np.uint32))
+    with pytest.raises(salt_amd.SaltError, match="262144"):
+        aln.alnse_core1(salt_amd.AlnOpt(l_seed=idx.l_seed, max_locate=300000), seq[:100], np.array([0, 100], dtype=np.uint32))
+    aln.alnse_core1(salt_amd.AlnOpt(l_seed=idx.l_seed, max_locate=5000), seq[:100], np.array([0, 100], dtype=np.uint32))     # fine since round 3
     aln.close()
     idx.destroy()
 
@@ -505,7 +508,10 @@ def test_cli_option_matrix_equals_the_oracle(oracle_cli, tmp_path):
 
 
 TANDEM_ROWS = ["-d -c", "-d -c -r 2", "-d -c -s 100000", "-d -c -m 50", "-d -c -r 2 -s 100000", "-d -c -r 1 -s 3 -m 200", "-d -c -v -s 100000",
-               "-p -d -c -r 2 -s 100000", "-p -d -c -m 200"]       # PE with -m below ~60 here subsamples R intervals with rand(): undefined
+               "-p -d -c -r 2 -s 100000", "-p -d -c -m 200",       # PE with -m below ~60 here subsamples R intervals with rand(): undefined
+               # -m above the 1 024 rows a strand keeps in LDS: the lists move to global memory (the reference's vector grows, alnse.c:678);
+               # the oracle equals the real reference on these four rows too (checked in the build container)
+               "-d -c -m 1025", "-d -c -m 5000 -s 100000", "-d -c -m 30000 -r 2 -s 100000", "-p -d -c -m 3000 -s 100000"]
 
 
 def test_cli_on_a_tandem_repeat_equals_the_oracle(oracle_cli, tmp_path):
