@@ -1290,7 +1290,7 @@ static int pe_prepare(salt_gpu_ws_t *ws, uint32_t n_pairs, hipStream_t st)
         ws->pe_pairs_cap = n_pairs;
     }
     if (!ws->d_pctl) {
-        HIPCHK(hipMalloc((void **)&ws->d_pctl, 8 * 4));
+        HIPCHK(hipMalloc((void **)&ws->d_pctl, 16 * 4));         // [0..7] see pe_resident_impl; [8..11] k_swtb's phase clocks (diagnostics build)
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ws->ix->device));
         ws->sw_blocks = (uint32_t)prop.multiProcessorCount;             // CUs: k_sw runs up to SW_MAX_BLOCKS_PER_CU blocks on each
@@ -1308,7 +1308,7 @@ static int pe_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const sa
     rc = align_resident_impl(ws, o, 2 * n_pairs, max_len, d_seqs, d_offs, d_results, st, 1);
     if (rc) return rc;
     hipEvent_t *ev = ws->n_timed == ti + 1 ? &ws->ev[(size_t)ti * EV_PER_CALL] : nullptr;      // the call above was timed: three more events
-    HIPCHK(hipMemsetAsync(ws->d_pctl, 0, 32, st));
+    HIPCHK(hipMemsetAsync(ws->d_pctl, 0, 64, st));
     launch_pair(n_pairs, pe->min_tlen, pe->max_tlen, (uint32_t)ws->ix->l_pac, static_cast<const uint32_t *>(d_offs), static_cast<salt_result_t *>(d_results),
                 ws->d_pairs, ws->d_req, ws->d_pctl, st);
     if (ev) HIPCHK(hipEventRecord(ev[8], st));
@@ -1333,6 +1333,13 @@ static int pe_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const sa
     launch_pe_final(ws->ix->view, PackGeom::make(max_len), n_pairs, ws->d_pm, static_cast<salt_result_t *>(d_results), ws->d_pairs, ws->d_swres, ws->d_lvtab,
                     ws->d_pcq, ws->d_pctl + 2, ws->heavy_blocks, st);
     if (ev) { HIPCHK(hipEventRecord(ev[10], st)); ws->ev_pe[ti] = 1; }
+#ifdef SALT_DIAG
+    if (getenv("SALT_GPU_TB_CLOCKS")) {
+        uint32_t c[16]; HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipMemcpy(c, ws->d_pctl, 64, hipMemcpyDeviceToHost));
+        if (c[11]) fprintf(stderr, "[k_swtb] %u tracebacks: operands %.1f us, band passes %.1f us, walk + write %.1f us each (s_memtime, 10 ns ticks)\n", c[11],
+                           c[8] / 100.0 / c[11], c[9] / 100.0 / c[11], c[10] / 100.0 / c[11]);
+    }
+#endif
     HIPCHK(hipGetLastError());
     return SALT_OK;
 }

@@ -30,6 +30,17 @@ __device__ __forceinline__ int sw_score(int aware, uint32_t ref, uint32_t code)
     return ref == code ? 1 : -3;
 }
 
+// the same value without a branch (the traceback calls it once per cell of a row, eight alignments side by side in one wave: the
+// short-circuit form above compiles to a dozen divergent branches per row)
+__device__ __forceinline__ int sw_score_flat(int aware, uint32_t ref, uint32_t code)
+{
+    const bool eq = ref == code, bases = (ref | code) < 4u;
+    const int s0 = bases ? (eq ? 1 : -3) : -1, s2 = bases ? (eq ? 2 : -2) : 0;
+    const bool one_allele = __popc(ref) == 1, listed = ((ref >> (code & 3u)) & 1u) != 0;
+    const int s1 = ((code < 4u) & one_allele & listed) ? 1 : -3;
+    return aware == 2 ? s2 : aware ? s1 : s0;
+}
+
 __device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
 __device__ __forceinline__ int subu16(int a, int b) { unsigned x = (unsigned)a & 0xFFFFu; return (int)(short)(x > (unsigned)b ? x - (unsigned)b : 0u); }
 
@@ -283,7 +294,7 @@ __device__ __forceinline__ int tb_band_pass(int32_t *__restrict__ hb, int32_t *_
             const int t1 = i == 0 ? -go : hb_e - go, t2 = i == 0 ? -ge : eb_e - ge;
             const int E = t1 > t2 ? t1 : t2, e_open = t1 > t2 ? 1 : 0;
             const int e1 = E > 0 ? E : 0;
-            const int diag = hb_d + sw_score(aware, sym, rc);
+            const int diag = hb_d + sw_score_flat(aware, sym, rc);
             const int A = e1 > diag ? e1 : diag;
             // max-plus scan: inclusive prefix maximum of g = A - go + j ge over the group's lanes, then one lane down, then the chunks before
             int inc = act ? A - go + j * ge : TB_NEG;
@@ -337,6 +348,8 @@ __device__ __forceinline__ int tb_band_pass_small(uint8_t *__restrict__ dir, con
     const int go = 3, ge = 1;
     const int width = 2 * bw + 3, width_d = 2 * bw + 1;                          // width - 1 <= 8: indices 1 .. 8 live in lanes 0 .. 7
     int Hp = 0, Ep = 0, mx = 0;                                                  // h_b[lane + 1], e_b[lane + 1]
+    // the read base and the lane's reference symbol of a row are fetched from LDS one row ahead (nothing else in a row touches memory)
+    uint32_t rc_n = rd[0], sym_n = lane < refLen && lane <= bw ? (uint32_t)rf[lane] : 0u;
     for (int i = 0; i < readLen; ++i) {
         const int x = i - bw > 0 ? i - bw : 0, xp = i - 1 - bw > 0 ? i - 1 - bw : 0, d = x - xp;
         const int end = refLen - 1 < i + bw ? refLen - 1 : i + bw, n = end - x + 1;
@@ -344,7 +357,12 @@ __device__ __forceinline__ int tb_band_pass_small(uint8_t *__restrict__ dir, con
         if (lane + 1 == edge) { Hp = 0; Ep = 0; }                                // h_b[edge] = e_b[edge] = 0 (ssw.c:593)
         const bool act = lane < n;
         const int j = x + lane;
-        const uint32_t rc = rd[i], sym = act ? (uint32_t)rf[j] : 0u;
+        const uint32_t rc = rc_n, sym = sym_n;
+        if (i + 1 < readLen) {
+            const int xn = i + 1 - bw > 0 ? i + 1 - bw : 0, endn = refLen - 1 < i + 1 + bw ? refLen - 1 : i + 1 + bw;
+            rc_n = rd[i + 1];
+            sym_n = lane < endn - xn + 1 ? (uint32_t)rf[xn + lane] : 0u;
+        }
         // h_b[e], e_b[e], h_b[e - 1] with e = lane + d + 1: this lane's or a neighbour's register
         const int Hn = dpp_row_shl<1>(Hp), En = dpp_row_shl<1>(Ep);
         int Hl = dpp_row_shr<1>(Hp);
@@ -353,7 +371,7 @@ __device__ __forceinline__ int tb_band_pass_small(uint8_t *__restrict__ dir, con
         const int t1 = i == 0 ? -go : hb_e - go, t2 = i == 0 ? -ge : eb_e - ge;
         const int E = t1 > t2 ? t1 : t2, e_open = t1 > t2 ? 1 : 0;
         const int e1 = E > 0 ? E : 0;
-        const int diag = hb_d + sw_score(aware, sym, rc);
+        const int diag = hb_d + sw_score_flat(aware, sym, rc);
         const int A = e1 > diag ? e1 : diag;
         int inc = act ? A - go + j * ge : TB_NEG;
         { const int t = dpp_row_shr<1>(inc); if (lane >= 1) inc = inc > t ? inc : t; }
@@ -509,7 +527,7 @@ k_swtb(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict_
        const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
        uint32_t *__restrict__ overflow, uint8_t *__restrict__ scratch, uint32_t group_bytes, TbGeom tg, int dbg_arg)
 {
-    const int dbg_max_bw = SALT_DIAG_VAL(dbg_arg);               // diagnostics build only: bands wider than this count as overflow
+    const int dbg_max_bw = SALT_DIAG_VAL(dbg_arg);               // diagnostics build only: bands wider than (low 16 bits) count as overflow; bit 16: phase clocks
     extern __shared__ __attribute__((aligned(16))) uint8_t tb_lds[];
     const uint32_t grp = threadIdx.x >> 3, lane = threadIdx.x & 7u;
     uint8_t *const rd = tb_lds + (size_t)grp * tg.group_b, *const rf = rd + tg.read_b;
@@ -534,6 +552,9 @@ k_swtb(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict_
         const int rfl = ref_end - ref_begin + 1, rdl = read_end - read_begin + 1, aware = rq.aware;
         const uint32_t off = offs[rq.mate], L = offs[rq.mate + 1] - off;
         int n_cig = 0;
+        const bool clk = (dbg_max_bw & 0x10000) != 0;                 // diagnostics build: s_memtime ticks per phase into overflow[4..7]
+        const unsigned long long c0 = clk ? __builtin_amdgcn_s_memtime() : 0ull;
+        unsigned long long c1 = c0, c2 = c0;
         if ((rq.pad & 2u) && rdl < 20) { if (lane == 0) { o->n_cigar = 0; o->ok = 0; } continue; }    // a mate rescue (pad bit 1): alnpe.c:297 turns it down whatever its CIGAR
         if (rfl > 0 && rdl > 0 && (uint32_t)rdl <= tg.read_b) {
             const uint32_t ref0 = rq.start + (uint32_t)ref_begin;
@@ -567,11 +588,13 @@ k_swtb(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict_
             int bw = rfl - rdl; bw = (bw < 0 ? -bw : bw) + 1;
             int mx = 0;
             bool fits = true, dir_lds = true;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (clk) c1 = __builtin_amdgcn_s_memtime();
             for (;;) {                                               // band doubling (ssw.c:570-631): until the band holds the alignment's score
                 const int width = 2 * bw + 3, width_d = 2 * bw + 1;
                 const bool rows_lds = (uint32_t)width <= tg.row_w;
                 dir_lds = (uint64_t)width_d * (uint64_t)rdl <= tg.dir_b;
-                if (width > (int)SW_BAND_W || (!dir_lds && (uint64_t)width_d * (uint64_t)rdl > gdir_cap) || (dbg_max_bw && bw > dbg_max_bw)) { fits = false; break; }
+                if (width > (int)SW_BAND_W || (!dir_lds && (uint64_t)width_d * (uint64_t)rdl > gdir_cap) || ((dbg_max_bw & 0xFFFF) && bw > (dbg_max_bw & 0xFFFF))) { fits = false; break; }
                 int m;
                 const uint8_t *rfp = ref_in_lds ? rf : nullptr;
                 if (width - 1 <= 8 && dir_lds && ref_in_lds) m = tb_band_pass_small(ldir, rd, rf, aware, rfl, rdl, bw);
@@ -583,6 +606,7 @@ k_swtb(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict_
                 if (mx >= score) break;
                 bw *= 2;
             }
+            if (clk) c2 = __builtin_amdgcn_s_memtime();
             if (!fits) n_cig = -1;
             else if (lane == 0) n_cig = tb_walk(dir_lds ? ldir : gdir, (int64_t)(2 * bw + 1) * rdl, rfl, rdl, bw, reinterpret_cast<uint16_t *>(lrows), o->cigar, SALT_MAX_CIGAR_OPS);
             n_cig = __shfl(n_cig, 0, 8);
@@ -592,6 +616,10 @@ k_swtb(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict_
             if (n_cig < 0) { atomicAdd(overflow, 1u); n_cig = 0; }
             o->n_cigar = (uint16_t)n_cig;
             o->ok = (uint16_t)((n_cig > 0 && rdl >= 20) ? 1 : 0);      // alnpe.c:297 (filters = 0, filterd = 20)
+            if (clk) {
+                const unsigned long long c3 = __builtin_amdgcn_s_memtime();
+                atomicAdd(overflow + 4, (uint32_t)(c1 - c0)); atomicAdd(overflow + 5, (uint32_t)(c2 - c1)); atomicAdd(overflow + 6, (uint32_t)(c3 - c2)); atomicAdd(overflow + 7, 1u);
+            }
         }
     }
 }
@@ -754,6 +782,7 @@ void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, con
 #ifdef SALT_DIAG
     if (getenv("SALT_GPU_NO_TB")) return;                                                       // diagnostics: no traceback (no CIGARs)
     if (getenv("SALT_GPU_TB_MAXBW")) tb_dbg = atoi(getenv("SALT_GPU_TB_MAXBW"));
+    if (getenv("SALT_GPU_TB_CLOCKS")) tb_dbg |= 0x10000;
 #endif
     hipLaunchKernelGGL(k_swtb, dim3(g.tb_blocks), dim3(64), 8u * tg.group_b, st, ix, pac, seqs, offs, req, pctl, res, tb_head, overflow,
                        scratch + (uint64_t)g.n_blocks * 8 * g.maxcol_bytes, g.tb_group_bytes, tg, tb_dbg);
