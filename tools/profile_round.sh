@@ -29,6 +29,8 @@ for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum 
   name=${pass%%:*}; ctrs=${pass#*:}
   rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pmc_$name" -o pmc -- python3 "$ROOT/bench.py" $Q --streams 1 --steps 4 --warmup 2 --batches 4 --pe-steps 4 --pe-batches 2 > /dev/null 2>> "$OUT/bench.log" || echo "[profile] pmc pass $name FAILED"
   find "$OUT/pmc_$name" -name '*counter_collection.csv' -exec cp {} "$OUT/${PRE}pmc_${name}_${WL}.csv" \;
+  # keep the product's kernels only (the generator's torch kernels are nine tenths of the rows)
+  if [ -f "$OUT/${PRE}pmc_${name}_${WL}.csv" ]; then (head -1 "$OUT/${PRE}pmc_${name}_${WL}.csv"; grep "salt::" "$OUT/${PRE}pmc_${name}_${WL}.csv") > "$OUT/.f.csv" && mv "$OUT/.f.csv" "$OUT/${PRE}pmc_${name}_${WL}.csv"; fi
   rm -rf "$OUT/pmc_$name"
   echo "[profile] pmc pass $name done"
 done
