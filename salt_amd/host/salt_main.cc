@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -355,7 +356,73 @@ int usage()
 //   blocks behind the one being written are read and aligned meanwhile.  Output order = input order, as the reference's puts loop
 //   gives it (alnse.c:1433-1439).
 // ---------------------------------------------------------------------------------------------
+// ---- BGZF input (blocked gzip: every block is a gzip member of at most 64 KiB with its compressed size in a 'BC' extra field -- what
+// bgzip and most sequencing pipelines write).  The reference reads any .gz through gzopen (query.c:103-112), one stream, one thread; a
+// blocked file can be cut anywhere: the block table (compressed offset, uncompressed offset) is read from the headers and trailers
+// without inflating, and the text path treats the UNCOMPRESSED byte range as its file -- a worker inflates the blocks its chunk touches
+// into its page-locked buffer, a few at a time on helper threads.  Plain single-member gzip stays on the host pipeline.
+struct Bgzf {
+    std::vector<uint64_t> coff, uoff;                        // per block: offset in the file, offset in the uncompressed text; one entry past the end
+    bool ok = false;
+};
+static bool bgzf_index(const char *fn, Bgzf &B)
+{
+    const int fd = open(fn, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { close(fd); return false; }
+    const uint64_t size = (uint64_t)sb.st_size;
+    uint64_t at = 0, u = 0;
+    bool good = true;
+    while (at < size) {
+        unsigned char h[18 + 256];
+        const ssize_t got = pread(fd, h, sizeof h, (off_t)at);
+        if (got < 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { good = false; break; }
+        const uint32_t xlen = h[10] | (h[11] << 8);
+        uint32_t bsize = 0;
+        for (uint32_t p = 12; p + 4 <= 12 + xlen && p + 4 <= (uint32_t)got; ) {       // extra subfields: SI1 SI2 SLEN data
+            const uint32_t slen = h[p + 2] | (h[p + 3] << 8);
+            if (h[p] == 'B' && h[p + 1] == 'C' && slen == 2 && p + 6 <= (uint32_t)got) { bsize = (h[p + 4] | (h[p + 5] << 8)) + 1u; break; }
+            p += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || at + bsize > size) { good = false; break; }
+        unsigned char t[4];
+        if (pread(fd, t, 4, (off_t)(at + bsize - 4)) != 4) { good = false; break; }
+        const uint32_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (isize > 65536) { good = false; break; }
+        B.coff.push_back(at); B.uoff.push_back(u);
+        at += bsize; u += isize;
+    }
+    close(fd);
+    if (!good || B.coff.empty()) { B.coff.clear(); B.uoff.clear(); return false; }
+    B.coff.push_back(at); B.uoff.push_back(u);
+    B.ok = true;
+    return true;
+}
+// inflates block b (bytes cbuf[0 .. csize) of the file) to exactly usize bytes at dst; false on a damaged block
+static bool bgzf_inflate(const unsigned char *cbuf, size_t csize, char *dst, size_t usize)
+{
+    if (csize < 26) return false;
+    const uint32_t xlen = cbuf[10] | (cbuf[11] << 8);
+    const size_t hdr = 12 + (size_t)xlen;
+    if (hdr + 8 > csize) return false;
+    z_stream z; memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, -15) != Z_OK) return false;
+    z.next_in = const_cast<unsigned char *>(cbuf + hdr); z.avail_in = (uInt)(csize - hdr - 8);
+    z.next_out = reinterpret_cast<unsigned char *>(dst); z.avail_out = (uInt)usize;
+    const int rc = inflate(&z, Z_FINISH);
+    bool ok = (rc == Z_STREAM_END || (usize == 0 && rc == Z_BUF_ERROR)) && z.total_out == usize;
+    inflateEnd(&z);
+    if (ok) {                                                // the member's CRC-32, as gzread checks it
+        const unsigned char *t = cbuf + csize - 8;
+        const uint32_t want = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+        ok = (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef *>(dst), (uInt)usize) == want;
+    }
+    return ok;
+}
+
 struct TextRun {
+    const Bgzf *bgzf = nullptr;                              // non-null: `file_size` and every offset below are in the uncompressed text
     int fd = -1; uint64_t file_size = 0, chunk = 0;
     std::atomic<uint64_t> next_chunk{ 0 };
     // output sequencing: block k is written once block k - 1 has been
@@ -404,6 +471,7 @@ struct TextPlan {
     std::vector<char *> in_buf, sam_buf;
     std::thread alloc; bool alloc_ok = true; double alloc_s = 0;
     bool pe = false; uint64_t pairs_per_chunk = 0;          // paired end: chunks are cut by record count (both files the same), about `chunk` bytes per file
+    Bgzf bgzf;                                               // single end, blocked gzip input: its block table
     ~TextPlan();
 };
 
@@ -423,7 +491,13 @@ static void text_plan(TextPlan &P, const char *fn_reads, int n_gpus, int n_threa
     double sam_per_fq_byte = 1.5;                            // SAM bytes a FASTQ byte turns into, for the first sizing of the SAM buffers
     char head[65536];
     ssize_t got = -1;
-    { const int fd = open(fn_reads, O_RDONLY); if (fd >= 0) { got = pread(fd, head, sizeof head, 0); close(fd); } }
+    if (P.bgzf.ok) {                                         // the head of the TEXT: the first block, inflated
+        const int fd = open(fn_reads, O_RDONLY);
+        std::vector<unsigned char> cb((size_t)(P.bgzf.coff[1] - P.bgzf.coff[0]));
+        const size_t us = (size_t)(P.bgzf.uoff[1] - P.bgzf.uoff[0]);
+        if (fd >= 0 && pread(fd, cb.data(), cb.size(), 0) == (ssize_t)cb.size() && us <= sizeof head && bgzf_inflate(cb.data(), cb.size(), head, us)) got = (ssize_t)us;
+        if (fd >= 0) close(fd);
+    } else { const int fd = open(fn_reads, O_RDONLY); if (fd >= 0) { got = pread(fd, head, sizeof head, 0); close(fd); } }
     uint64_t lines = 0, last_rec_end = 0, line_start = 0, name_bytes = 0;
     for (ssize_t i = 0; i < got; ++i)
         if (head[i] == '\n') {
@@ -441,7 +515,7 @@ static void text_plan(TextPlan &P, const char *fn_reads, int n_gpus, int n_threa
         sam_per_fq_byte = (name_bytes / n_rec + 2.0 * P.head_read_len + 160.0) / rec_bytes;
     }
     if (P.head_read_len > SALT_MAX_READ_LEN) P.head_read_len = 0;      // the call itself reports it
-    P.in_cap = P.chunk + 2 * TEXT_SLACK + 64;
+    P.in_cap = P.chunk + 2 * TEXT_SLACK + 64 + (P.bgzf.ok ? (3u << 16) : 0u);      // blocked input: whole 64 KiB blocks at both ends
     P.sam_cap = (uint64_t)((double)(P.chunk + TEXT_SLACK) * sam_per_fq_byte) + 4096;
     if (pe) {                                                // a chunk = pairs_per_chunk records of EACH file; both blocks share the input buffer
         const double rec_bytes = lines >= 4 && last_rec_end ? (double)last_rec_end / (double)(lines / 4) : 250.0;
@@ -479,6 +553,7 @@ static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector
     struct stat sb;
     if (fstat(R.fd, &sb) != 0) { fprintf(stderr, "[salt] cannot stat %s\n", fn_reads); return 1; }
     R.file_size = (uint64_t)sb.st_size;
+    if (P.bgzf.ok) { R.bgzf = &P.bgzf; R.file_size = P.bgzf.uoff.back(); }
     R.chunk = P.chunk;
     fflush(stdout);
     // contig table for RNAME / POS on the device
@@ -495,6 +570,10 @@ static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector
     const uint32_t worst_reads = P.worst_reads, max_reads = P.max_reads, head_read_len = P.head_read_len;
     const salt_text_opt_t to = { so.print_xa_cigar, so.print_nm_md, so.rg_id };
     const uint64_t n_chunks = (R.file_size + R.chunk - 1) / R.chunk;
+    // blocked gzip input: every worker inflates with a few helper threads (a block inflates at ~0.3 GB/s on one core; a worker's chunk must
+    // not take longer to inflate than the device takes for the chunks of the other workers)
+    int inflate_helpers = 0;
+    if (R.bgzf) { inflate_helpers = 5; if (const char *e = getenv("SALT_INFLATE_HELPERS")) { const int v = atoi(e); if (v >= 0 && v <= 64) inflate_helpers = v; } }
     std::vector<std::thread> workers;
     std::atomic<double> t_read{ 0 }, t_gpu{ 0 }, t_write{ 0 }, t_last{ t0 };     // t_last: when the last SAM byte so far was written
     auto set_failed = [&]() { { std::lock_guard<std::mutex> lk(R.mu); R.failed = true; } R.cv.notify_all(); };
@@ -502,6 +581,7 @@ static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector
         workers.emplace_back([&, wk]() {
             salt_gpu_ws_t *ws = nullptr; char *buf = P.in_buf[(size_t)wk];
             pin_to_device_node(wk / n_workers_per_gpu);
+            std::vector<unsigned char> cbuf;                              // blocked gzip input: the compressed bytes of a chunk's blocks
             const bool trace = getenv("SALT_TEXT_TRACE") != nullptr;      // per-worker timeline on stderr
             const double tw_start = now(); int n_calls = 0; double t_first = 0, t_rest = 0;
             uint32_t ws_reads = max_reads;
@@ -518,12 +598,47 @@ static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector
                 const uint64_t rd_lo = lo ? lo - 1 : 0, rd_hi = std::min(R.file_size, hi + TEXT_SLACK);
                 double tr0 = now();
                 uint64_t got = 0;
-                while (got < rd_hi - rd_lo) {
-                    ssize_t r = pread(R.fd, buf + got, rd_hi - rd_lo - got, (off_t)(rd_lo + got));
-                    if (r <= 0) break;
-                    got += (uint64_t)r;
+                char *const buf0 = buf;                               // (blocked input inflates whole blocks: the chunk's bytes then start inside the buffer)
+                if (R.bgzf) {
+                    // the blocks that hold text bytes [rd_lo, rd_hi): read as one piece, inflated side by side by this worker and its helpers
+                    const Bgzf &B = *R.bgzf;
+                    const size_t b0 = (size_t)(std::upper_bound(B.uoff.begin(), B.uoff.end(), rd_lo) - B.uoff.begin()) - 1;
+                    size_t b1 = (size_t)(std::lower_bound(B.uoff.begin(), B.uoff.end(), rd_hi) - B.uoff.begin());
+                    if (b1 >= B.uoff.size()) b1 = B.uoff.size() - 1;
+                    const uint64_t c0 = B.coff[b0], c1 = B.coff[b1], u0 = B.uoff[b0];
+                    bool ok = B.uoff[b1] - u0 <= P.in_cap - 64;
+                    if (ok) {
+                        cbuf.resize((size_t)(c1 - c0));
+                        uint64_t cg = 0;
+                        while (cg < c1 - c0) { const ssize_t r = pread(R.fd, cbuf.data() + cg, c1 - c0 - cg, (off_t)(c0 + cg)); if (r <= 0) break; cg += (uint64_t)r; }
+                        ok = cg == c1 - c0;
+                    }
+                    if (ok) {
+                        std::atomic<size_t> nb{ b0 }; std::atomic<bool> bad{ false };
+                        auto work = [&]() {
+                            for (;;) {
+                                const size_t b = nb.fetch_add(1);
+                                if (b >= b1 || bad) break;
+                                if (!bgzf_inflate(cbuf.data() + (B.coff[b] - c0), (size_t)(B.coff[b + 1] - B.coff[b]), buf0 + (B.uoff[b] - u0), (size_t)(B.uoff[b + 1] - B.uoff[b]))) bad = true;
+                            }
+                        };
+                        std::vector<std::thread> helpers;
+                        for (int h = 0; h < inflate_helpers; ++h) helpers.emplace_back(work);
+                        work();
+                        for (auto &h : helpers) h.join();
+                        ok = !bad;
+                    }
+                    if (!ok) { fprintf(stderr, "[salt] %s: damaged or oversized gzip block near text offset %llu\n", fn_reads, (unsigned long long)rd_lo); set_failed(); break; }
+                    buf = buf0 + (rd_lo - u0);
+                    got = rd_hi - rd_lo;
+                } else {
+                    while (got < rd_hi - rd_lo) {
+                        ssize_t r = pread(R.fd, buf + got, rd_hi - rd_lo - got, (off_t)(rd_lo + got));
+                        if (r <= 0) break;
+                        got += (uint64_t)r;
+                    }
+                    if (got != rd_hi - rd_lo) { fprintf(stderr, "[salt] short read on %s\n", fn_reads); set_failed(); break; }
                 }
-                if (got != rd_hi - rd_lo) { fprintf(stderr, "[salt] short read on %s\n", fn_reads); set_failed(); break; }
                 t_read = t_read + (now() - tr0);
                 uint64_t n = got;
                 if (rd_hi == R.file_size && n && buf[n - 1] != '\n') buf[n++] = '\n';          // a last record without its newline
@@ -578,6 +693,7 @@ static int run_se_text(const char *fn_reads, salt_index_t *ix, const std::vector
                     fprintf(stderr, "%ld reads have been aligned!\n", R.reads_done);
                 }
                 R.cv.notify_all();
+                buf = buf0;
             }
             if (trace) fprintf(stderr, "[salt] worker %d: started %.3f s after the clock, setup %.3f s, first device call %.3f s, %d later calls %.4f s each, done at %.3f s\n", wk,
                                tw_start - t0, t_setup, t_first, n_calls - 1, n_calls > 1 ? t_rest / (n_calls - 1) : 0.0, now() - t0);
@@ -823,6 +939,9 @@ int main(int argc, char **argv)
             return plain && sniff_four_line(fn);
         };
         text_path = plain4(fn_reads) && (!pe || plain4(fn_mates));
+        // single end, blocked gzip (BGZF) whose text starts as strict 4-line FASTQ: the text path over the uncompressed byte range
+        if (!text_path && !pe && bgzf_index(fn_reads, plan.bgzf) && sniff_four_line(fn_reads)) text_path = true;
+        else if (!text_path) plan.bgzf = Bgzf();
         if (text_path) text_plan(plan, fn_reads, n_gpus, n_threads, pe != 0);
     }
     double t0 = now();

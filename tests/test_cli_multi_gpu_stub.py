@@ -152,3 +152,53 @@ def test_salt_pe_text_path_neither_hangs_nor_shifts_pairs_on_odd_files(stub_tree
         assert res.returncode == 1 and b"different numbers of reads" in res.stderr, res.stderr[-600:]
         got = _strip(res.stdout)
         assert want.startswith(got[:len(got) - len(got) % 1])   # whatever came out is a prefix of the right answer: no shifted pairs
+
+
+def _bgzf(data, block=65280):
+    """Blocked gzip as bgzip writes it: every block a gzip member with the 'BC' extra field (its compressed size - 1), an empty block last."""
+    import struct
+    import zlib
+    out = bytearray()
+    for o in list(range(0, len(data), block)) + [None]:
+        raw = b"" if o is None else data[o:o + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(raw) + c.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += body + struct.pack("<II", zlib.crc32(raw) & 0xFFFFFFFF, len(raw))
+    return bytes(out)
+
+
+@pytest.mark.parametrize("gpus,block", [(1, 65280), (3, 700)])
+def test_salt_reads_blocked_gzip_through_the_text_path(gpus, block, stub_tree, tmp_path):
+    """BGZF input: the text path runs over the uncompressed byte range -- workers inflate the blocks their chunks touch
+    (blocks of 700 bytes here: dozens per chunk, chunk ends inside blocks) -- and the SAM is the reference's.  A plain single-member .gz of
+    the same reads goes through the host pipeline, as before."""
+    import gzip
+    d, prefix = stub_tree
+    want = open(os.path.join(LAMBDA, "expect_se_default.sam"), "rb").read()
+    raw = open(os.path.join(LAMBDA, "reads_se.fq"), "rb").read()
+    bg = tmp_path / "reads.bgzf.fq.gz"
+    bg.write_bytes(_bgzf(raw, block))
+    import gzip as _g
+    assert _g.decompress(bg.read_bytes()) == raw                  # a valid multi-member gzip file to everyone else
+    log = str(tmp_path / "stub.log")
+    env = dict(os.environ, SALT_STUB_PREFIX=prefix, SALT_STUB_LOG=log, SALT_CHUNK_BYTES="9000", LD_LIBRARY_PATH=str(d / "lib"))
+    res = subprocess.run([str(d / "bin" / "salt")] + read_cases()["se_default"] + ["-t", "8", "--gpus", str(gpus), prefix, str(bg)],
+                         capture_output=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stderr[-600:]
+    assert b"text path:" in res.stderr and b"the host parser takes over" not in res.stderr
+    assert _strip(res.stdout) == want
+    rows = [l.split() for l in open(log).read().splitlines()]
+    assert sum(int(r[1]) for r in rows) == 2000 and len(rows) > 10
+    plain = tmp_path / "reads.plain.fq.gz"
+    with gzip.open(plain, "wb") as f:
+        f.write(raw)
+    res = subprocess.run([str(d / "bin" / "salt")] + read_cases()["se_default"] + ["-t", "8", prefix, str(plain)], capture_output=True, env=env, timeout=300)
+    assert res.returncode == 0 and b"host phases" in res.stderr and _strip(res.stdout) == want, res.stderr[-600:]
+    # a damaged block is an error, not silence
+    dmg = bytearray(bg.read_bytes()); dmg[len(dmg) // 2] ^= 0x55
+    bad = tmp_path / "damaged.fq.gz"
+    bad.write_bytes(bytes(dmg))
+    res = subprocess.run([str(d / "bin" / "salt")] + read_cases()["se_default"] + ["-t", "8", prefix, str(bad)], capture_output=True, env=env, timeout=300)
+    assert res.returncode != 0

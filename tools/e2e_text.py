@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end experiments with the `salt` binary on the GRCh38-scale workload (GPU box): builds the index once, writes one FASTQ file,
 then runs `salt -d -c` for every settings string given on the command line ("ENV=VAL,ENV=VAL"; "" = defaults).
+A setting IN=bgzf / IN=gz runs on a blocked-gzip / plain-gzip copy of the FASTQ (written once, 32 processes).
 usage: tools/e2e_text.py <n_reads> [settings ...]"""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,6 +26,35 @@ with open(fq, "wb") as f:
         done += k
 del g, site
 torch.cuda.empty_cache()
+
+
+def _bgzf_piece(args):
+    import struct, zlib
+    path, lo, hi = args
+    data = open(path, "rb").read()[lo:hi] if False else None
+    with open(path, "rb") as f:
+        f.seek(lo); data = f.read(hi - lo)
+    out = bytearray()
+    for o in range(0, len(data), 65280):
+        raw = data[o:o + 65280]
+        c = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = c.compress(raw) + c.flush()
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1)
+        out += body + struct.pack("<II", zlib.crc32(raw) & 0xFFFFFFFF, len(raw))
+    return bytes(out)
+
+
+def make_bgzf(src, dst):
+    import multiprocessing as mp
+    size = os.path.getsize(src)
+    step = 65280 * 256
+    with mp.Pool(32) as pool, open(dst, "wb") as f:
+        for piece in pool.imap(_bgzf_piece, [(src, lo, min(size, lo + step)) for lo in range(0, size, step)]):
+            f.write(piece)
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+
+
+made = {}
 salt = os.path.join(ROOT, "salt_amd", "bin", "salt")
 for s in settings:
     env = dict(os.environ)
@@ -33,9 +63,21 @@ for s in settings:
         env[a] = b
     sam = os.path.join(w["dir"], "e2e.sam")
     to_null = env.pop("OUT", "") == "null"
+    kind = env.pop("IN", "")
+    src = fq
+    if kind:
+        src = fq + (".bgzf.gz" if kind == "bgzf" else ".plain.gz")
+        if kind not in made:
+            tz = time.time()
+            if kind == "bgzf":
+                make_bgzf(fq, src)
+            else:
+                subprocess.run("gzip -1 -c %s > %s" % (fq, src), shell=True, check=True)
+            made[kind] = 1
+            print("   (%s written in %.1f s, %.2f GB)" % (src, time.time() - tz, os.path.getsize(src) / 1e9))
     t0 = time.time()
     with open("/dev/null" if to_null else sam, "wb") as fo:
-        r = subprocess.run([salt, "-d", "-c", "-t", env.pop("T", "64"), w["prefix"], fq], stdout=fo, stderr=subprocess.PIPE, env=env)
+        r = subprocess.run([salt, "-d", "-c", "-t", env.pop("T", "64"), w["prefix"], src], stdout=fo, stderr=subprocess.PIPE, env=env)
     tail = [l for l in r.stderr.decode().splitlines() if l.startswith("[salt") or l.startswith("[alnse_core]: total")]
     print("== %s  (rc %d, process %.1f s)" % (s or "defaults", r.returncode, time.time() - t0))
     for l in tail:
