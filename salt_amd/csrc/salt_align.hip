@@ -683,8 +683,8 @@ __device__ __forceinline__ CtxRead ctx_read(const uint32_t *pm, uint32_t L, uint
 // Not inlined (three call sites, ~1 400 instructions).  Its arguments are the same for all 64 lanes: passed by value they would be
 // written to and read back from scratch memory once per lane and call (~6 KB per call, measured as 430 MB of writes per launch), so the
 // caller leaves ONE copy in the wave's LDS.
-template <bool PE, class W>
-__device__ __attribute__((noinline)) CandStats build_candidates(W &w)
+template <bool PE, bool GL, class W>       // GL: the block has a global list for located rows beyond the LDS list (paired end; single end with -m above it).
+__device__ __attribute__((noinline)) CandStats build_candidates(W &w)      // A template parameter, not a run-time flag: a list that may live in either memory is reached through flat loads
 {
     const CandArgs a = *reinterpret_cast<const CandArgs *>(w.cargs);
     const uint32_t lane = lane_id();
@@ -694,7 +694,7 @@ __device__ __attribute__((noinline)) CandStats build_candidates(W &w)
     struct { gp_u32 c_sa, r_pos; uint32_t ref_len; } ix = { as_global(a.c_sa), as_global(a.r_pos), a.ref_len };
     struct { uint32_t spr, max_locate; } ap = { a.spr, a.max_locate };
     uint32_t n_sa_c = 0, n_sa_r = 0, n_loci_out = 0;
-    const bool glob = a.loci != nullptr;                      // a global list is there (paired end; single end with -m above the LDS list): used when the rows outgrow the LDS
+    constexpr bool glob = GL;                                 // a global list is there: used when the rows outgrow the LDS
     uint32_t *loci = glob ? a.loci : w.loci;                 // decided below, once the number of rows is known
     PhaseClock pc(a.phase);
     const uint64_t base_item = ((uint64_t)r * 2u + (uint32_t)strand) * ap.spr;
@@ -844,14 +844,14 @@ __device__ __attribute__((noinline)) CandStats build_candidates(W &w)
     return CandStats{ n_out, n_sa_c, n_sa_r, n_loci_out, in_lds ? 1u : 0u, n_ctx_rej, n_ctx_rows };
 }
 
-template <bool PE, class W>
+template <bool PE, bool GL, class W>
 __device__ __forceinline__ CandStats build_candidates_call(const CandArgs a, W &w)
 {
     static_assert(sizeof(CandArgs) <= sizeof(w.cargs), "CandArgs outgrew its LDS slot");
     WSYNC();
     if (lane_id() == 0) *reinterpret_cast<CandArgs *>(w.cargs) = a;
     WSYNC();
-    return build_candidates<PE, W>(w);
+    return build_candidates<PE, GL, W>(w);
 }
 
 // ---- masked Hamming distance, capped: returns 0..3 or INF (ed_mismatch, editdistance.c:88-163) ----
@@ -1388,7 +1388,7 @@ __device__ __forceinline__ uint32_t store_gap_list(const uint32_t *loci, uint32_
     return n_out;
 }
 
-template <bool PE, class W>
+template <bool PE, bool GL, class W>
 __device__ __forceinline__ void align_general(const IndexView ix, const AlignParams ap, W &w, const uint32_t r,
                               const uint32_t *__restrict__ pm,
                               const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r,
@@ -1403,7 +1403,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
     uint32_t c_sa_c = 0, c_sa_r = 0, c_verify = 0, c_vwords = 0, c_lv = 0, c_loci = 0, c_ctx_rej = 0, c_ctx_rows = 0;
     PhaseClock pc(phase);
     const uint64_t rt0 = phase ? __builtin_amdgcn_s_memrealtime() : 0;
-    const bool glob = pe_loci != nullptr;                     // paired end (0x40000 loci per strand, alnse.c:42) or single end with -m above the LDS list
+    constexpr bool glob = GL;                                 // paired end (0x40000 loci per strand, alnse.c:42) or single end with -m above the LDS list
     uint32_t *loci = glob ? pe_loci : w.loci;                 // candidate loci: LDS, or the block's global scratch when a list outgrows it
     uint8_t *cand_e = glob ? pe_cand : w.cand_e;              // (set after every build_candidates call from what it reports)
     const uint32_t loci_cap = PE ? PE_LOCI_CAP : (uint32_t)MAXLOC;
@@ -1444,7 +1444,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         // Located rows first, unsorted: only loci that can pass (<= 3 mismatches, inside the reference) matter to the
         // sequential rule, so the sort (alnse.c:726-729), the duplicate filter (alnse.c:758-762) and the rule run on
         // those few; the result is the one the full sorted list gives.
-        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, pe_loci, loci_cap, ap.pe, false, ix.r_ctx, ix.c_ctx, ix.ctx_k }, w);
+        const CandStats cs = build_candidates_call<PE, GL>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, false, phase, pe_loci, loci_cap, ap.pe, false, ix.r_ctx, ix.c_ctx, ix.ctx_k }, w);
         if (glob) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
         pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
         const uint32_t n_loc = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci; c_ctx_rej += cs.n_ctx_rej; c_ctx_rows += cs.n_ctx_rows;
@@ -1496,7 +1496,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                     uint32_t n = n_loc_s[1];
                     if (strand == 0 || ix.c_ctx != nullptr) {
                         WSYNC();
-                        const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, pe_loci, loci_cap, ap.pe, false, nullptr, nullptr, 0 }, w);
+                        const CandStats cs = build_candidates_call<PE, GL>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, pe_loci, loci_cap, ap.pe, false, nullptr, nullptr, 0 }, w);
                         if (glob) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
                         c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
                         n = cs.n_cand;
@@ -1549,7 +1549,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
         }
         for (int strand = 0; strand < 2; ++strand) {
             pc.stamp(SALT_CTR_T_GAP);
-            const CandStats cs = build_candidates_call<PE>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, pe_loci, loci_cap, ap.pe, true, nullptr, nullptr, 0 }, w);
+            const CandStats cs = build_candidates_call<PE, GL>(CandArgs{ ix.c_sa, ix.r_pos, sai_c, sai_r, ix.ref_len, ap.spr, ap.max_locate, r, L, strand, true, phase, pe_loci, loci_cap, ap.pe, true, nullptr, nullptr, 0 }, w);
             if (glob) { loci = cs.in_lds ? w.loci : pe_loci; cand_e = cs.in_lds ? w.cand_e : pe_cand; }
             pc.t = phase ? __builtin_amdgcn_s_memtime() : 0;
             const uint32_t n_cand = cs.n_cand; c_sa_c += cs.n_sa_c; c_sa_r += cs.n_sa_r; c_loci += cs.n_loci;
@@ -1683,7 +1683,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
 //   qctl[2] gapped reads (slots)       qctl[3] k_gap head        qctl[4] k_gapfin head
 //   qctl[5] k_gap items                qctl[6] CIGAR items       qctl[7] k_cigar head      qctl[8] pool entries used
 // ---------------------------------------------------------------------------------------------
-template <bool PE, class W>
+template <bool PE, bool GL, class W>
 __device__ __forceinline__ void heavy_body(const IndexView &ix, const AlignParams &ap, const uint32_t *__restrict__ pm,
                                            const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r,
                                            salt_result_t *__restrict__ results, const uint32_t *__restrict__ queue,
@@ -1705,7 +1705,7 @@ __device__ __forceinline__ void heavy_body(const IndexView &ix, const AlignParam
         WSYNC();
         if (it >= n_items) break;
         const uint32_t r = overflow_pass ? g.ovq[it] : ap.all_heavy ? it : queue[it];
-        align_general<PE>(ix, ap, w, r, pm, sai_c, sai_r, results, ctr, phase, lvtab + blockIdx.x, g,
+        align_general<PE, GL>(ix, ap, w, r, pm, sai_c, sai_r, results, ctr, phase, lvtab + blockIdx.x, g,
                           pe_scr ? reinterpret_cast<uint32_t *>(pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5) : nullptr,
                           pe_scr ? pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5 + (size_t)PE_LOCI_CAP * 4 : nullptr);
         if (phase && threadIdx.x == 0) s_phase[SALT_CTR_HEAVY_READS] += 1;
@@ -1722,17 +1722,19 @@ __device__ __forceinline__ void heavy_body(const IndexView &ix, const AlignParam
 #else
 #define HEAVY_OCC
 #endif
-#define HEAVY_KERNEL(NAME, PE, LDS)                                                                                     \
+#define HEAVY_KERNEL(NAME, PE, GL, LDS)                                                                                    \
 __global__ void __launch_bounds__(64) HEAVY_OCC                                                                         \
 NAME(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,                                                     \
      const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,             \
      const uint32_t *__restrict__ queue, unsigned long long *__restrict__ ctr,                                          \
      LvTables *__restrict__ lvtab, GapBufs g, uint8_t *__restrict__ pe_scr, int overflow_pass)                          \
-{ heavy_body<PE, LDS>(ix, ap, pm, sai_c, sai_r, results, queue, ctr, lvtab, g, pe_scr, overflow_pass); }
-HEAVY_KERNEL(k_heavy, false, WaveLdsSmall)      // the usual shape: <= 32 seed slots per strand, gapped reads handed to k_gap
-HEAVY_KERNEL(k_heavy_pe, true, WaveLdsSmall)    // paired-end mates: PE locate rule, loci in global scratch, gap bound 3
-HEAVY_KERNEL(k_heavy_big, false, WaveLds)       // any read the ABI admits, everything finished inside the block: batches with more seed
-HEAVY_KERNEL(k_heavy_pe_big, true, WaveLds)     // slots, runs without the k_gap buffers, and the overflow pass behind the usual shape
+{ heavy_body<PE, GL, LDS>(ix, ap, pm, sai_c, sai_r, results, queue, ctr, lvtab, g, pe_scr, overflow_pass); }
+HEAVY_KERNEL(k_heavy, false, false, WaveLdsSmall)      // the usual shape: <= 32 seed slots per strand, gapped reads handed to k_gap
+HEAVY_KERNEL(k_heavy_pe, true, true, WaveLdsSmall)    // paired-end mates: PE locate rule, loci in global scratch, gap bound 3
+HEAVY_KERNEL(k_heavy_big, false, false, WaveLds)      // any read the ABI admits, everything finished inside the block: batches with more seed
+HEAVY_KERNEL(k_heavy_pe_big, true, true, WaveLds)
+HEAVY_KERNEL(k_heavy_glob, false, true, WaveLds)    // single end with -m above the LDS list (SALT_MAX_LOCATE): located rows in the block's global list, everything in this one shape
+//    // slots, runs without the k_gap buffers, and the overflow pass behind the usual shape
 
 // k_gap: one item = 32 candidates of one strand of one queued read: their Landau-Vishkin distances at the bound L/10
 // (ed_diff -> computeEditDistance, editdistance.c:174-232, LandauVishkin.c:19-122), one candidate per lane
@@ -2776,14 +2778,19 @@ void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm
     // reads to; the few reads it cannot finish (no k_gap slot left) wait in the overflow queue for the pass right behind it, which runs
     // the all-in-one shape (18.6 KB) and leaves at once when the queue is empty.  SALT_GPU_HEAVY_BIG=1: the all-in-one shape for everything.
     static const bool force_big = getenv("SALT_GPU_HEAVY_BIG") && atoi(getenv("SALT_GPU_HEAVY_BIG"));
-    const bool small = !force_big && g.cap > 0 && ovq != nullptr && ap.spr <= (uint32_t)WaveLdsSmall::N_SLOTS;
+    const bool se_glob = !ap.pe && pe_scr != nullptr;                  // single end, -m above the LDS list
+    if (se_glob) {
+        hipLaunchKernelGGL(k_heavy_glob, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr, 0);
+    }
+    const bool small = !se_glob && !force_big && g.cap > 0 && ovq != nullptr && ap.spr <= (uint32_t)WaveLdsSmall::N_SLOTS;
     if (small) {
         if (ap.pe) hipLaunchKernelGGL(k_heavy_pe, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr, 0);
         else     hipLaunchKernelGGL(k_heavy, dim3(blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr, 0);
     }
     // (the overflow pass on a small grid: it is empty nearly always, and 1 536 blocks of 18.6 KB each that only look at a counter cost 70 us)
     const uint32_t big_blocks = small && blocks > 256u ? 256u : blocks;
-    if (ap.pe) hipLaunchKernelGGL(k_heavy_pe_big, dim3(big_blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr, small ? 1 : 0);
+    if (se_glob) { }                                                    // (done above)
+    else if (ap.pe) hipLaunchKernelGGL(k_heavy_pe_big, dim3(big_blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr, small ? 1 : 0);
     else     hipLaunchKernelGGL(k_heavy_big, dim3(big_blocks), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, queue, ctr, tab, g, pe_scr, small ? 1 : 0);
     if (ev3) hipEventRecord(ev3[0], st);
     if (!g.cap) { if (ev3) { hipEventRecord(ev3[1], st); hipEventRecord(ev3[2], st); } return; }

@@ -138,7 +138,7 @@ __device__ __forceinline__ int dpp_max8(int x)
 // right before the new one overwrites it.  Same operations in the same order as above, so the same lazy-F behaviour.
 template <int SEG, class ReadAt>
 __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint8_t *pac, int aware, uint32_t ref0, int ref_dir, int refLen,
-                                                 int readLen, ReadAt rd, int terminate, uint16_t *maxColumn, uint16_t *maxColumnLds,
+                                                 int readLen, ReadAt rd, int terminate, uint16_t *maxColumn, uint16_t *maxColumnLds, short *hm,
                                                  int &out_max, int &out_end_ref, int &out_end_read, uint32_t *dbg_cols = nullptr)
 {
     uint32_t n_cols = 0, n_lazy = 0;
@@ -148,13 +148,18 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
     // Every H, E and F here lies in [0, 32767] (scores are at most the read length), where the SSE2 operations reduce to plain
     // integer ones: adds_epi16(vH, profile) = vH + profile, subs_epu16(x, g) = max(x - g, 0).  The profile of a column is six
     // 4-bit fields (value + 3 per read code 0..3, N, "past the read"), so a cell's lookup is one bit-field extract.
-    int H[SEG], E[SEG], Hm[SEG]; uint32_t sh[SEG];
+    // H at the best column so far (what the end point is read from, ssw.c:504-512) is written a few dozen times per pass and read once:
+    // it lives in the group's LDS (hm[j * 8 + lane]), and the profile shifts of six stripes share a register -- 34 VGPRs fewer, which is
+    // the difference between two and three waves per SIMD for this kernel
+    int H[SEG], E[SEG]; uint32_t shp[(SEG + 5) / 6];
+#pragma unroll
+    for (int k = 0; k < (SEG + 5) / 6; ++k) shp[k] = 0;
 #pragma unroll
     for (int j = 0; j < SEG; ++j) {
-        H[j] = 0; E[j] = 0; Hm[j] = 0;
+        H[j] = 0; E[j] = 0; hm[j * 8 + lane] = 0;
         const int q = j + lane * segLen;
         const uint32_t code = (j < segLen && q < readLen) ? rd(q) : 5u;      // 5: past the read (profile 0)
-        sh[j] = 4u * (code > 5u ? 4u : code);
+        shp[j / 6] |= (4u * (code > 5u ? 4u : code)) << (5 * (j % 6));
     }
     int max = 0, end_ref = 0, vMaxScore = 0, vMaxMark = 0;
     const int begin = ref_dir ? refLen - 1 : 0, end = ref_dir ? -1 : refLen, step = ref_dir ? -1 : 1;
@@ -185,7 +190,7 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
 #pragma unroll
         for (int j = 0; j < SEG; ++j) {
             if (j < segLen) {
-                int h = vH + (int)((prof4 >> sh[j]) & 15u) - bias;
+                int h = vH + (int)((prof4 >> ((shp[j / 6] >> (5 * (j % 6))) & 31u)) & 15u) - bias;
                 int e = E[j];
                 h = h > e ? h : e; h = h > vF ? h : vF;
                 vMaxColumn = vMaxColumn > h ? vMaxColumn : h;
@@ -224,7 +229,7 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
             if (temp > max) {
                 max = temp; end_ref = i;
 #pragma unroll
-                for (int j = 0; j < SEG; ++j) Hm[j] = H[j];
+                for (int j = 0; j < SEG; ++j) hm[j * 8 + lane] = (short)H[j];
             }
         }
         const int mc = dpp_max8(vMaxColumn);
@@ -233,7 +238,7 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
     }
     int end_read = readLen - 1;
 #pragma unroll
-    for (int j = 0; j < SEG; ++j) if (j < segLen && Hm[j] == max) { int t = j + lane * segLen; if (t < end_read) end_read = t; }
+    for (int j = 0; j < SEG; ++j) if (j < segLen && (int)hm[j * 8 + lane] == max) { int t = j + lane * segLen; if (t < end_read) end_read = t; }
     for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(end_read, o, 8); end_read = end_read < t ? end_read : t; }
     out_max = max; out_end_ref = end_ref; out_end_read = end_read;
     if (dbg_cols && lane == 0) { atomicAdd(dbg_cols, n_cols); atomicAdd(dbg_cols + 1, n_lazy); }
@@ -431,8 +436,10 @@ __device__ __forceinline__ int tb_walk(const uint8_t *dir, const int64_t n_dir, 
 // k_sw: persistent groups of 8 lanes pull rescue requests -- the two striped passes of ssw_align (scores, end and begin points, second
 // best).  A request that needs its CIGAR leaves with ok = 2 and is finished by k_swtb.
 // ---------------------------------------------------------------------------------------------
+// The register variants for reads up to 152 bases are capped at 128 VGPRs (four waves per SIMD; the compiler spills ~90 registers of the
+// fully unrolled column loop, and the kernel is still 13 % faster than at 203 registers and two waves: profiles/r03/ab_sw_waves.log)
 template <int SEG>                     // 0: stripe rows in LDS (any read length); > 0: in registers, segLen <= SEG
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((SEG == 13 || SEG == 19) ? 4 : 1, (SEG == 13 || SEG == 19) ? 4 : 8)))
 k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
      const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
      uint32_t *__restrict__ overflow, uint8_t *__restrict__ scratch, uint32_t maxcol_bytes, uint32_t seg, int dbg_arg)
@@ -446,8 +453,9 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
         s.H[0] = reinterpret_cast<short *>(base); s.H[1] = s.H[0] + seg * 8; s.E = s.H[1] + seg * 8; s.Hmax = s.E + seg * 8;
         s.read = reinterpret_cast<uint8_t *>(s.Hmax + seg * 8);
     } else {
-        s.H[0] = s.H[1] = s.E = s.Hmax = nullptr;
+        s.H[0] = s.H[1] = s.E = nullptr;
         s.read = sw_lds + (size_t)grp * ((8u * seg + 15u) & ~15u);
+        s.Hmax = reinterpret_cast<short *>(sw_lds + 8u * ((8u * seg + 15u) & ~15u)) + (size_t)grp * (SEG ? SEG : 1) * 8;      // [SEG][8] per group, behind the reads
     }
     const uint32_t n_req = pctl[0];
     uint16_t *maxColumn = reinterpret_cast<uint16_t *>(scratch + ((size_t)blockIdx.x * 8 + grp) * maxcol_bytes);
@@ -481,7 +489,7 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
             int max1, end_ref1, end_read1;
             auto fwd = [&](int q) -> uint32_t { return s.read[q]; };
             if (SEG == 0) sw_word_pass(ix, pac, aware, s, rq.start, 0, refLen, (int)L, fwd, 0xFFFF, maxColumn, max1, end_ref1, end_read1);
-            else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, aware, rq.start, 0, refLen, (int)L, fwd, 0xFFFF, maxColumn, (uint16_t *)nullptr,
+            else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, aware, rq.start, 0, refLen, (int)L, fwd, 0xFFFF, maxColumn, (uint16_t *)nullptr, s.Hmax,
                                                    max1, end_ref1, end_read1, (dbg & 4) ? overflow + 1 : nullptr);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
             // second best outside +-maskLen around the end column (ssw.c:529-542), maskLen = L/2 >= 15 or none
@@ -501,7 +509,7 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
                 int max2, beg_ref, beg_read_rev;
                 auto rev = [&](int q) -> uint32_t { return s.read[end_read1 - q]; };
                 if (SEG == 0) sw_word_pass(ix, pac, aware, s, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, max2, beg_ref, beg_read_rev);
-                else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, aware, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, (uint16_t *)nullptr,
+                else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, aware, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, (uint16_t *)nullptr, s.Hmax,
                                                        max2, beg_ref, beg_read_rev, (dbg & 8) ? overflow + 1 : nullptr);
                 out.ref_begin = beg_ref; out.read_begin = end_read1 - beg_read_rev;
                 out.ok = 2;                                          // the banded traceback is k_swtb's
@@ -712,7 +720,8 @@ static int sw_seg_variant(uint32_t max_len)
 uint32_t sw_lds_bytes(uint32_t max_len)
 {
     const uint32_t seg = (max_len + 7) / 8, rd = (8u * seg + 15u) & ~15u;
-    return sw_seg_variant(max_len) ? 8u * rd : 8u * (4u * seg * 16u + rd);
+    const uint32_t v = (uint32_t)sw_seg_variant(max_len);
+    return v ? 8u * rd + 8u * v * 8u * 2u : 8u * (4u * seg * 16u + rd);          // register variants: the reads + H-at-best [SEG][8] shorts per group
 }
 // one-wave blocks per CU: what registers (the register variants) or LDS (the LDS variant) admit
 uint32_t sw_blocks_per_cu(uint32_t max_len)
