@@ -515,8 +515,24 @@ def pe_leg(args, cfg, idx, alns, streams, genome, site, ora, oracle_py, dev, tor
         db = {}
     # a rescue reads its window once forward and (to the end point) once backward as 4-bit masks or 2-bit bases, the mate, and writes a 160-byte row
     db["k_sw"] = int(pc[0]) * (2 * (550 + L) // 2 + L + 160)
-    cand = {k: v for k, v in skm.items() if k in db and v > 0}
+    # the roofline block is for the dominant MEMORY-bound kernel; k_sw (+ k_swtb, timed together) is integer DP in registers: its block
+    # (`valu`) gives the share of the chip's vector issue slots it used, from the committed PMC passes
+    cand = {k: v for k, v in skm.items() if k in db and v > 0 and k != "k_sw"}
     dom = max(cand, key=lambda k: cand[k]) if cand else None
+    pf = os.path.join(ROOT, "profiles", "r03", "pmc_summary_pe_%s.json" % args.workload)
+    prof = {}
+    if os.path.exists(pf):
+        try:
+            prof = json.load(open(pf))
+        except Exception:
+            prof = {}
+    if skm.get("k_sw"):
+        isw, itb = prof.get("issue", {}).get("k_sw", {}), prof.get("issue", {}).get("k_swtb", {})
+        out["valu"] = {"kernel": "k_sw + k_swtb (striped Smith-Waterman passes + banded traceback of the mate rescues)", "ms": round(skm["k_sw"], 3),
+                       "requests": int(pc[0]), "bound": "valu (integer DP in registers; no HBM or MFMA roofline applies)",
+                       "valu_issue_frac_k_sw": isw.get("valu_issue_frac"), "valu_issue_frac_k_swtb": itb.get("valu_issue_frac"),
+                       "valu_wave_insts_k_sw": isw.get("valu_wave_insts"), "ms_rocprof": {"k_sw": isw.get("kernel_ms_rocprof"), "k_swtb": itb.get("kernel_ms_rocprof")},
+                       "source": "profiles/r03/pmc_summary_pe_%s.json (SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x duration x 2.4 GHz))" % args.workload}
     if dom:
         ach = db[dom] / (skm[dom] / 1e3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom + (" (k_heavy_pe)" if dom == "k_heavy" else ""), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -525,16 +541,14 @@ def pe_leg(args, cfg, idx, alns, streams, genome, site, ora, oracle_py, dev, tor
                                                "GBps": round(v / (skm[k] / 1e3) / 1e9, 1) if skm.get(k) else None} for k, v in db.items()},
                            "timing": "HIP events on the launch stream over %d serialized steps (kernel_ms_serialized)" % n_serial,
                            "counters": {k: int(v) for k, v in ctr.items() if k.startswith("d_")},
-                           "note": "k_sw is integer DP in registers (VALU-bound): its byte fraction is small by construction; profiles/r03 holds its issue rate"}
-        pf = os.path.join(ROOT, "profiles", "r03", "pmc_summary_pe_%s.json" % args.workload)
-        if os.path.exists(pf):
-            try:
-                prof = json.load(open(pf))
-                key = "k_heavy_pe" if dom == "k_heavy" else dom
-                out["roofline"]["traffic"] = prof.get("hbm_bytes_per_launch", {}).get(key)
-                out["roofline"]["issue_bound"] = prof.get("issue", {}).get(key)
-            except Exception:
-                pass
+                           "note": "the dominant memory-bound kernel of the paired-end step; k_sw has its own block (`valu`)"}
+        key = "k_heavy_pe" if dom == "k_heavy" else dom
+        out["roofline"]["traffic"] = prof.get("hbm_bytes_per_launch", {}).get(key)
+        out["roofline"]["issue_bound"] = prof.get("issue", {}).get(key)
+        rq = prof.get("per_kernel_mean", {}).get(key, {}).get("TCC_EA0_RDREQ_sum")
+        if rq:
+            out["roofline"]["random_requests"] = {"per_launch": int(rq), "G_per_s": round(rq / (skm[dom] / 1e3) / 1e9, 1), "ceiling_G_per_s": RANDOM_REQ_GPS,
+                                                  "frac_of_ceiling": round(rq / (skm[dom] / 1e3) / 1e9 / RANDOM_REQ_GPS, 3)}
     # ---- parity + CPU baseline on the first pe_check pairs of the last timed step's batch ----
     nchk = min(args.pe_check, n_pairs)
     if nchk > 0 and ora is not None:
