@@ -49,6 +49,12 @@ struct SwLds {                       // per 8-lane group: views into the block's
     uint8_t *read;                   // [8 * seg]
 };
 __device__ __forceinline__ uint32_t sw_group_bytes(uint32_t seg) { return 4u * seg * 16u + ((8u * seg + 15u) & ~15u); }
+// where the groups' window words begin in k_swf's / k_swr's LDS: behind the rows (LDS variant, variant 0) or the reads and H-at-best rows
+__host__ __device__ __forceinline__ uint32_t sw_lds_words_at(uint32_t seg, uint32_t variant, bool fwd)
+{
+    const uint32_t rd = (8u * seg + 15u) & ~15u;
+    return variant ? (fwd ? 2u : 1u) * (8u * rd + 8u * variant * 8u * 2u) : 8u * (4u * seg * 16u + rd);
+}
 
 
 __device__ __forceinline__ uint32_t ref_symbol(const IndexView &ix, const uint8_t *pac, int aware, uint32_t p)
@@ -134,14 +140,66 @@ __device__ __forceinline__ int dpp_max8(int x)
 
 // The same pass with the stripe rows in REGISTERS (SEG = compile-time bound on segLen, every loop fully unrolled): the LDS
 // version spends a column in ~5 dependent LDS round trips per stripe with two waves per SIMD to hide them; here a column is
-// ~25 VALU instructions per stripe and nothing else.  One buffer suffices for H: the old H[j] is read (it feeds stripe j+1)
+// ~12 VALU instructions per stripe and nothing else.  One buffer suffices for H: the old H[j] is read (it feeds stripe j+1)
 // right before the new one overwrites it.  Same operations in the same order as above, so the same lazy-F behaviour.
+//
+// The window's symbols reach the lanes without a memory wait per column: the eight lanes of a group hold the eight 32-bit words of the
+// window's current block (8 allele masks of the mixRef or 16 bases of the 2-bit genome per word; a block = 7 words' worth of columns, so
+// that an unaligned block still touches at most 8 words) and drop them into the group's LDS, from where a column's word is read a column
+// ahead of its use: one exposed load per block of 56 or 112 columns and no memory wait inside a column (a register that a load MAY have
+// written this iteration costs a wait for every store in flight at its first use, each column).  (Loading "the next word" into a register
+// rotation, as this pass first did, compiled into a memory wait at the top of every column: the copies of the rotation need the load.)
+// The column maxima leave the same way: lane c % 8 keeps column c's and the group stores eight at a time.
+__device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) { return __builtin_elementwise_add_sat(a, b); }
+__device__ __forceinline__ uint32_t sat_sub_u32(uint32_t a, uint32_t b) { return __builtin_elementwise_sub_sat(a, b); }
+struct RefStream {
+    uint32_t *lw;                      // the current block's eight words (the group's LDS)
+    uint32_t wb;                       // word index of lw[0]
+    int cnext;                         // pass column at which the next block begins
+};
+// the block that begins at pass column c0 (forward: lw[0] is the lowest word, reverse: the highest); a block beyond the window (the
+// shorter window of a pair) loads some valid word and is never used
+__device__ __forceinline__ void ref_stream_turn(RefStream &r, const uint32_t *words, uint32_t ref_len, uint32_t ws, uint32_t ref0, int n, int dir, int c0, int lane)
+{
+    const uint32_t last = ref_len - 1u;
+    uint32_t w;
+    if (dir) { r.wb = sat_sub_u32(ref0 + (uint32_t)(n - 1), (uint32_t)c0) >> ws; w = sat_sub_u32(r.wb, (uint32_t)lane); }
+    else { const uint32_t p = sat_add_u32(ref0, (uint32_t)c0); r.wb = (p < last ? p : last) >> ws; w = r.wb + (uint32_t)lane; w = w < (last >> ws) ? w : (last >> ws); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();      // the word asked for a column ahead has been read
+    r.lw[lane] = words[w];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    r.cnext = c0 + (int)(7u << ws);
+}
+// the word holding the symbol of pass column c (window position ref0 + c forward, ref0 + n - 1 - c reverse), out of the current block;
+// asked for one column ahead of its use
+__device__ __forceinline__ uint32_t ref_stream_word(const RefStream &r, uint32_t ws, uint32_t ref0, int n, int dir, int c)
+{
+    const uint32_t p = dir ? ref0 + (uint32_t)(n - 1 - c) : ref0 + (uint32_t)c;
+    const uint32_t k = dir ? r.wb - (p >> ws) : (p >> ws) - r.wb;
+    return r.lw[k & 7u];
+}
+__device__ __forceinline__ uint32_t ref_word_symbol(uint32_t w, bool masks, uint32_t ref0, int n, int dir, int c)
+{
+    const uint32_t p = dir ? ref0 + (uint32_t)(n - 1 - c) : ref0 + (uint32_t)c;
+    // masks: 8 per word, LSB first (metaref.c:54-56); 2-bit genome: 4 bases per byte, the first in the byte's top bits (bntseq.c:88-139)
+    const uint32_t sh = masks ? 4u * (p & 7u) : 8u * ((p >> 2) & 3u) + ((~p & 3u) << 1);
+    return (w >> sh) & (masks ? 15u : 3u);
+}
+// the six 4-bit profile fields of a column: sw_score for read codes 0..3, N and "past the read", + bias (3, polish's matrix 2)
+__device__ __forceinline__ uint32_t sw_prof_fields(bool masks, bool polish, uint32_t sym)
+{
+    const bool single = sym != 0u && (sym & (sym - 1u)) == 0u;                    // SNP-aware: exactly one allele (alnpe.c:58-73 as SSW indexes it)
+    const uint32_t idx = masks ? (uint32_t)__ffs((int)sym) - 1u : sym;
+    const uint32_t hit = (masks ? single : true) ? 4u << ((4u * idx) & 31u) : 0u;
+    return ((polish ? 2u : 3u) << 20) | (masks ? 0u : 2u << 16) | hit;
+}
+
 template <int SEG, class ReadAt>
 __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint8_t *pac, int aware, uint32_t ref0, int ref_dir, int refLen,
-                                                 int readLen, ReadAt rd, int terminate, uint16_t *maxColumn, uint16_t *maxColumnLds, short *hm,
+                                                 int readLen, ReadAt rd, int terminate, uint16_t *maxColumn, short *hm, uint32_t *lw,
                                                  int &out_max, int &out_end_ref, int &out_end_read, uint32_t *dbg_cols = nullptr)
 {
-    uint32_t n_cols = 0, n_lazy = 0;
+    uint32_t n_cols = 0;
     const int lane = (int)(threadIdx.x & 7u);
     const uint64_t gmask = 0xFFull << (threadIdx.x & 56u);
     const int segLen = (readLen + 7) / 8, go = 3, ge = 1;      // aln.h:137-138
@@ -149,8 +207,7 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
     // integer ones: adds_epi16(vH, profile) = vH + profile, subs_epu16(x, g) = max(x - g, 0).  The profile of a column is six
     // 4-bit fields (value + 3 per read code 0..3, N, "past the read"), so a cell's lookup is one bit-field extract.
     // H at the best column so far (what the end point is read from, ssw.c:504-512) is written a few dozen times per pass and read once:
-    // it lives in the group's LDS (hm[j * 8 + lane]), and the profile shifts of six stripes share a register -- 34 VGPRs fewer, which is
-    // the difference between two and three waves per SIMD for this kernel
+    // it lives in the group's LDS (hm[j * 8 + lane]), and the profile shifts of six stripes share a register
     int H[SEG], E[SEG]; uint32_t shp[(SEG + 5) / 6];
 #pragma unroll
     for (int k = 0; k < (SEG + 5) / 6; ++k) shp[k] = 0;
@@ -162,31 +219,27 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
         shp[j / 6] |= (4u * (code > 5u ? 4u : code)) << (5 * (j % 6));
     }
     int max = 0, end_ref = 0, vMaxScore = 0, vMaxMark = 0;
-    const int begin = ref_dir ? refLen - 1 : 0, end = ref_dir ? -1 : refLen, step = ref_dir ? -1 : 1;
-    // the window's symbols come from 32-bit words (8 masks of the mixRef, or 16 bases of the 2-bit genome); the word after the
-    // one in use is already on its way, so a column never waits for memory
-    const bool masks = aware == 1;                               // 4-bit allele masks (mixRef) or the 2-bit genome
+    const bool masks = aware == 1, polish = aware == 2;          // 4-bit allele masks (mixRef) or the 2-bit genome
     const uint32_t *words = masks ? ix.ref : reinterpret_cast<const uint32_t *>(pac);
-    const uint32_t wshift = masks ? 3u : 4u;
-    const int bias = aware == 2 ? 2 : 3;                         // the smallest score of the matrix in use, negated
-    uint32_t w_idx = (ref0 + (uint32_t)begin) >> wshift;
-    uint32_t w_cur = words[w_idx], w_next = words[(int64_t)w_idx + step < 0 ? 0 : w_idx + step];
-    for (int i = begin; i != end; i += step) {
-        const uint32_t p = ref0 + (uint32_t)i;
-        if ((p >> wshift) != w_idx) { w_idx = p >> wshift; w_cur = w_next; w_next = words[(int64_t)w_idx + step < 0 ? 0 : w_idx + step]; }
-        const uint32_t sym = masks ? (w_cur >> (4u * (p & 7u))) & 15u
-                                   : (((w_cur >> (8u * ((p >> 2) & 3u))) & 0xFFu) >> ((~p & 3u) << 1)) & 3u;
-        // profile fields of this column (sw_score for the six codes, + bias)
-        uint32_t prof4 = (uint32_t)bias << 20;
-        if (aware == 2) prof4 |= (2u << 16) | (4u << (4u * sym));
-        else if (masks) { if (sym == 1u || sym == 2u || sym == 4u || sym == 8u) prof4 |= 4u << (4u * (uint32_t)(__ffs((int)sym) - 1)); }
-        else prof4 |= sym > 3u ? 0x22222u : ((2u << 16) | (4u << (4u * sym)));
+    const uint32_t ws = masks ? 3u : 4u;
+    const int bias = polish ? 2 : 3;                             // the smallest score of the matrix in use, negated
+    RefStream rs; rs.lw = lw;
+    ref_stream_turn(rs, words, ix.ref_len, ws, ref0, refLen, ref_dir, 0, lane);
+    uint32_t w_ahead = ref_stream_word(rs, ws, ref0, refLen, ref_dir, 0);
+    int last = 0;                                                // H of the last stripe, as the column before left it
+    int mc_keep = 0, c = 0;                                      // lane c % 8 keeps column c's maximum until the group stores eight
+    for (; c < refLen; ++c) {
+        const int i = ref_dir ? refLen - 1 - c : c;
+        const uint32_t prof4 = sw_prof_fields(masks, polish, ref_word_symbol(w_ahead, masks, ref0, refLen, ref_dir, c));
+        if (c + 1 == rs.cnext) ref_stream_turn(rs, words, ix.ref_len, ws, ref0, refLen, ref_dir, c + 1, lane);
+        w_ahead = ref_stream_word(rs, ws, ref0, refLen, ref_dir, c + 1);
         int vF = 0, vMaxColumn = 0;
-        int last = 0;
-#pragma unroll
-        for (int j = 0; j < SEG; ++j) if (j == segLen - 1) last = H[j];
         int vH = dpp_row_shr<1>(last);
         if (lane == 0) vH = 0;
+        // (keeps the stripes' shifts packed: left alone, the compiler extracts all of them ahead of the loop into registers it does
+        // not have and reloads them from scratch memory stripe by stripe)
+#pragma unroll
+        for (int k = 0; k < (SEG + 5) / 6; ++k) asm volatile("" : "+v"(shp[k]));
 #pragma unroll
         for (int j = 0; j < SEG; ++j) {
             if (j < segLen) {
@@ -210,17 +263,16 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
         // over the 8 lanes and one pass over the stripes replace the sweeps (which the 8 requests of a wave would each stretch to
         // the longest of them).  E and the column maximum are not touched by the lazy pass there either.
         {
-            int c = dpp_row_shr<1>(vF);
-            if (lane == 0) c = 0;
+            int cf = dpp_row_shr<1>(vF);
+            if (lane == 0) cf = 0;
             const int seg_ge = segLen * ge;
-            { int t = dpp_row_shr<1>(c); t = lane >= 1 ? t - seg_ge : 0; t = t > 0 ? t : 0; c = c > t ? c : t; }
-            { int t = dpp_row_shr<2>(c); t = lane >= 2 ? t - 2 * seg_ge : 0; t = t > 0 ? t : 0; c = c > t ? c : t; }
-            { int t = dpp_row_shr<4>(c); t = lane >= 4 ? t - 4 * seg_ge : 0; t = t > 0 ? t : 0; c = c > t ? c : t; }
+            { int t = dpp_row_shr<1>(cf); t = lane >= 1 ? t - seg_ge : 0; t = t > 0 ? t : 0; cf = cf > t ? cf : t; }
+            { int t = dpp_row_shr<2>(cf); t = lane >= 2 ? t - 2 * seg_ge : 0; t = t > 0 ? t : 0; cf = cf > t ? cf : t; }
+            { int t = dpp_row_shr<4>(cf); t = lane >= 4 ? t - 4 * seg_ge : 0; t = t > 0 ? t : 0; cf = cf > t ? cf : t; }
 #pragma unroll
             for (int j = 0; j < SEG; ++j) {
-                if (j < segLen) { int f = c - j * ge; f = f > 0 ? f : 0; H[j] = H[j] > f ? H[j] : f; }
+                if (j < segLen) { int f = cf - j * ge; f = f > 0 ? f : 0; H[j] = H[j] > f ? H[j] : f; last = H[j]; }
             }
-            n_lazy += (uint32_t)segLen;
         }
         vMaxScore = vMaxScore > vMaxColumn ? vMaxScore : vMaxColumn;
         if (__ballot(vMaxMark != vMaxScore) & gmask) {
@@ -233,15 +285,152 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
             }
         }
         const int mc = dpp_max8(vMaxColumn);
-        if (lane == 0) { if (maxColumnLds) maxColumnLds[i] = (uint16_t)mc; else if (maxColumn) maxColumn[i] = (uint16_t)mc; }
-        if (mc == terminate) break;
+        if (maxColumn) {                                         // (forward passes only: column c is window position c)
+            if (lane == (c & 7)) mc_keep = mc;
+            if ((c & 7) == 7) maxColumn[c - 7 + lane] = (uint16_t)mc_keep;
+        }
+        if (mc == terminate) { ++c; break; }
     }
+    if (maxColumn && (c & 7) && lane < (c & 7)) maxColumn[(c & ~7) + lane] = (uint16_t)mc_keep;
     int end_read = readLen - 1;
 #pragma unroll
     for (int j = 0; j < SEG; ++j) if (j < segLen && (int)hm[j * 8 + lane] == max) { int t = j + lane * segLen; if (t < end_read) end_read = t; }
     for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(end_read, o, 8); end_read = end_read < t ? end_read : t; }
     out_max = max; out_end_ref = end_ref; out_end_read = end_read;
-    if (dbg_cols && lane == 0) { atomicAdd(dbg_cols, n_cols); atomicAdd(dbg_cols + 1, n_lazy); }
+    if (dbg_cols && lane == 0) { atomicAdd(dbg_cols, n_cols); atomicAdd(dbg_cols + 1, n_cols * (uint32_t)segLen); }
+}
+
+// The forward pass of TWO requests in one group: each lane's H, E, F hold request A in the low and request B in the high 16 bits of a
+// register and the column's operations are the packed 16-bit ones (v_pk_add_u16, v_pk_max_i16, v_pk_sub_u16 clamp = subs_epu16), so a
+// column of both costs what a column of one did, apart from the two profile look-ups.  The requests of the whole WAVE must have the same
+// read length and scoring (the stripes then line up and their count is a scalar; paired-end mates do); their windows may differ in
+// length -- the shorter one's half keeps running with its maximum, end point and column maxima frozen.  Same operations per half in the
+// same order as sw_word_pass_reg, so the same values.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+__device__ __forceinline__ uint32_t dpp_pk_max8(uint32_t x)
+{
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true); x = pk_max(x, t);
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true); x = pk_max(x, t);
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true); return pk_max(x, t);
+}
+template <int SEG>
+__device__ __forceinline__ void sw_fwd2_reg(const IndexView &ix, const uint8_t *pac, int aware, uint32_t ref0A, uint32_t ref0B, int refLenA, int refLenB,
+                                            int readLen, const uint8_t *rdA, const uint8_t *rdB, uint16_t *mcA, uint16_t *mcB, short *hmA, short *hmB,
+                                            uint32_t *lw, int &maxA_out, int &maxB_out, int &endRefA, int &endRefB, int &endReadA, int &endReadB)
+{
+    const int lane = (int)(threadIdx.x & 7u);
+    const uint64_t gmask = 0xFFull << (threadIdx.x & 56u);
+    readLen = __builtin_amdgcn_readfirstlane(readLen); aware = __builtin_amdgcn_readfirstlane(aware);     // the same in every group (the caller checked)
+    const int segLen = (readLen + 7) / 8;
+    const uint32_t go2 = 0x00030003u, ge2 = 0x00010001u;         // aln.h:137-138, both halves
+    uint32_t H[SEG], E[SEG], shp[(SEG + 2) / 3];                 // per stripe: the 5-bit profile shifts of A and of B, three stripes per register
+#pragma unroll
+    for (int k = 0; k < (SEG + 2) / 3; ++k) shp[k] = 0;
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+        H[j] = 0; E[j] = 0; hmA[j * 8 + lane] = 0; hmB[j * 8 + lane] = 0;
+        const int q = j + lane * segLen;
+        const bool in = j < segLen && q < readLen;
+        const uint32_t ca = in ? rdA[q] : 5u, cb = in ? rdB[q] : 5u;
+        shp[j / 3] |= ((4u * (ca > 5u ? 4u : ca)) | (4u * (cb > 5u ? 4u : cb)) << 5) << (10 * (j % 3));
+    }
+    const bool masks = aware == 1, polish = aware == 2;
+    const uint32_t *words = masks ? ix.ref : reinterpret_cast<const uint32_t *>(pac);
+    const uint32_t ws = masks ? 3u : 4u;
+    const uint32_t negb2 = (uint32_t)(-(polish ? 2 : 3) & 0xFFFF) * 0x00010001u;
+    const int nCols = refLenA > refLenB ? refLenA : refLenB;
+    RefStream rsA, rsB; rsA.lw = lw; rsB.lw = lw + 8;            // (both streams turn their blocks at the same columns)
+    ref_stream_turn(rsA, words, ix.ref_len, ws, ref0A, nCols, 0, 0, lane); ref_stream_turn(rsB, words, ix.ref_len, ws, ref0B, nCols, 0, 0, lane);
+    uint32_t wA = ref_stream_word(rsA, ws, ref0A, nCols, 0, 0), wB = ref_stream_word(rsB, ws, ref0B, nCols, 0, 0);
+    uint32_t last = 0, mc_keep = 0;
+    int maxA = 0, maxB = 0, erA = 0, erB = 0;
+    uint32_t vMaxScore = 0, vMaxMark = 0;
+    const uint32_t seg_ge = (uint32_t)segLen * 0x00010001u;
+    for (int i = 0; i < nCols; ++i) {
+        // (past the end of the shorter window its half sees whatever follows in the genome: nothing of it is kept)
+        const uint32_t profA = sw_prof_fields(masks, polish, ref_word_symbol(wA, masks, ref0A, nCols, 0, i));
+        const uint32_t profB = sw_prof_fields(masks, polish, ref_word_symbol(wB, masks, ref0B, nCols, 0, i));
+        if (i + 1 == rsA.cnext) {
+            ref_stream_turn(rsA, words, ix.ref_len, ws, ref0A, nCols, 0, i + 1, lane); ref_stream_turn(rsB, words, ix.ref_len, ws, ref0B, nCols, 0, i + 1, lane);
+        }
+        wA = ref_stream_word(rsA, ws, ref0A, nCols, 0, i + 1); wB = ref_stream_word(rsB, ws, ref0B, nCols, 0, i + 1);
+        uint32_t vF = 0, vMaxColumn = 0;
+        uint32_t vH = (uint32_t)dpp_row_shr<1>((int)last);
+        if (lane == 0) vH = 0;
+#pragma unroll
+        for (int k = 0; k < (SEG + 2) / 3; ++k) asm volatile("" : "+v"(shp[k]));          // (as in sw_word_pass_reg)
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) {
+            if (j < segLen) {
+                const uint32_t t = shp[j / 3] >> (10 * (j % 3));
+                const uint32_t p = __builtin_amdgcn_ubfe(profA, t, 4u) | (__builtin_amdgcn_ubfe(profB, t >> 5, 4u) << 16);
+                uint32_t h = pk_add(pk_add(vH, p), negb2);
+                uint32_t e = E[j];
+                h = pk_max(h, e); h = pk_max(h, vF);
+                vMaxColumn = pk_max(vMaxColumn, h);
+                vH = H[j];
+                H[j] = h;
+                h = pk_subs(h, go2);
+                e = pk_subs(e, ge2); e = pk_max(e, h); E[j] = e;
+                vF = pk_subs(vF, ge2); vF = pk_max(vF, h);
+            }
+        }
+        {                                                        // lazy F in closed form (see sw_word_pass_reg), both halves
+            uint32_t cf = (uint32_t)dpp_row_shr<1>((int)vF);
+            if (lane == 0) cf = 0;
+            { uint32_t t = (uint32_t)dpp_row_shr<1>((int)cf); t = lane >= 1 ? pk_subs(t, seg_ge) : 0u; cf = pk_max(cf, t); }
+            { uint32_t t = (uint32_t)dpp_row_shr<2>((int)cf); t = lane >= 2 ? pk_subs(t, 2u * seg_ge) : 0u; cf = pk_max(cf, t); }
+            { uint32_t t = (uint32_t)dpp_row_shr<4>((int)cf); t = lane >= 4 ? pk_subs(t, 4u * seg_ge) : 0u; cf = pk_max(cf, t); }
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) {
+                if (j < segLen) { H[j] = pk_max(H[j], pk_subs(cf, (uint32_t)j * 0x00010001u)); last = H[j]; }
+            }
+        }
+        vMaxScore = pk_max(vMaxScore, vMaxColumn);
+        if (__ballot(vMaxMark != vMaxScore) & gmask) {
+            vMaxMark = vMaxScore;
+            const uint32_t temp = dpp_pk_max8(vMaxScore);
+            const int tA = (int)(temp & 0xFFFFu), tB = (int)(temp >> 16);
+            if (tA > maxA && i < refLenA) {
+                maxA = tA; erA = i;
+#pragma unroll
+                for (int j = 0; j < SEG; ++j) hmA[j * 8 + lane] = (short)(H[j] & 0xFFFFu);
+            }
+            if (tB > maxB && i < refLenB) {
+                maxB = tB; erB = i;
+#pragma unroll
+                for (int j = 0; j < SEG; ++j) hmB[j * 8 + lane] = (short)(H[j] >> 16);
+            }
+        }
+        const uint32_t mc = dpp_pk_max8(vMaxColumn);
+        if (lane == (i & 7)) mc_keep = mc;
+        if ((i & 7) == 7) {
+            const int t = i - 7 + lane;
+            if (t < refLenA) mcA[t] = (uint16_t)(mc_keep & 0xFFFFu);
+            if (t < refLenB) mcB[t] = (uint16_t)(mc_keep >> 16);
+        }
+    }
+    if ((nCols & 7) && lane < (nCols & 7)) {
+        const int t = (nCols & ~7) + lane;
+        if (t < refLenA) mcA[t] = (uint16_t)(mc_keep & 0xFFFFu);
+        if (t < refLenB) mcB[t] = (uint16_t)(mc_keep >> 16);
+    }
+    int erdA = readLen - 1, erdB = readLen - 1;
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) if (j < segLen) {
+        const int t = j + lane * segLen;
+        if ((int)hmA[j * 8 + lane] == maxA && t < erdA) erdA = t;
+        if ((int)hmB[j * 8 + lane] == maxB && t < erdB) erdB = t;
+    }
+    for (int o = 1; o < 8; o <<= 1) {
+        int t = __shfl_xor(erdA, o, 8); erdA = erdA < t ? erdA : t;
+        t = __shfl_xor(erdB, o, 8); erdB = erdB < t ? erdB : t;
+    }
+    maxA_out = maxA; maxB_out = maxB; endRefA = erA; endRefB = erB; endReadA = erdA; endReadB = erdB;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -433,18 +622,136 @@ __device__ __forceinline__ int tb_walk(const uint8_t *dir, const int64_t n_dir, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_sw: persistent groups of 8 lanes pull rescue requests -- the two striped passes of ssw_align (scores, end and begin points, second
-// best).  A request that needs its CIGAR leaves with ok = 2 and is finished by k_swtb.
+// k_swf / k_swr: persistent groups of 8 lanes pull rescue requests -- the two striped passes of ssw_align.  k_swf runs the forward pass
+// (best score, its end point, second best: ssw.c:771-816) and leaves the requests that need their begin point with ok = 1; k_swr runs
+// the reverse pass from the end point for those (ssw.c:817-830) and leaves them with ok = 2 for k_swtb, the banded traceback.  Two
+// kernels rather than one: each column loop then has the registers to itself (as one kernel the loops reloaded spilled registers
+// at the top of every column, a memory round trip per column), and k_swf packs two requests per group (sw_fwd2_reg).
 // ---------------------------------------------------------------------------------------------
-// The register variants for reads up to 152 bases are capped at 128 VGPRs (four waves per SIMD; the compiler spills ~90 registers of the
-// fully unrolled column loop, and the kernel is still 13 % faster than at 203 registers and two waves: profiles/r03/ab_sw_waves.log)
-template <int SEG>                     // 0: stripe rows in LDS (any read length); > 0: in registers, segLen <= SEG
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((SEG == 13 || SEG == 19) ? 4 : 1, (SEG == 13 || SEG == 19) ? 4 : 8)))
-k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
-     const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
-     uint32_t *__restrict__ overflow, uint8_t *__restrict__ scratch, uint32_t maxcol_bytes, uint32_t seg, int dbg_arg)
+// The register variants for reads up to 152 bases are capped at 128 VGPRs (four waves per SIMD)
+#define SALT_SW_WAVES(SEG) __attribute__((amdgpu_waves_per_eu(((SEG) == 13 || (SEG) == 19) ? 4 : 1, ((SEG) == 13 || (SEG) == 19) ? 4 : 8)))
+
+// the mate's bases on the requested strand into the group's LDS
+__device__ __forceinline__ void sw_load_read(const uint8_t *__restrict__ seqs, uint32_t off, uint32_t L, uint32_t strand, uint8_t *dst, uint32_t lane)
 {
-    const int dbg = SALT_DIAG_VAL(dbg_arg);                      // diagnostics build only: 2 = phase clocks, 4 / 8 = column counts of the forward / reverse pass
+    for (uint32_t i = lane; i < L; i += 8) {
+        uint32_t c = strand ? seqs[off + (L - 1 - i)] : seqs[off + i];
+        if (strand && c < 4) c = 3 - c;
+        dst[i] = (uint8_t)(c > 4 ? 4 : c);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+}
+// what follows the forward pass: the second best score outside +-maskLen around the end column (ssw.c:529-542; maskLen = L/2 >= 15 or
+// none) and the result row, without begin point and CIGAR
+__device__ __forceinline__ void sw_fwd_row(PeSwRes *o, const PeSwReq &rq, bool fits, int refLen, uint32_t L, const uint16_t *maxColumn,
+                                           int max1, int end_ref1, int end_read1, uint32_t lane)
+{
+    int score2 = 0;
+    const int maskLen = (int)L / 2;
+    if (fits && maskLen >= 15) {
+        int edge = end_ref1 - maskLen > 0 ? end_ref1 - maskLen : 0;
+        for (int i = (int)lane; i < edge; i += 8) { int v = maxColumn[i]; score2 = score2 > v ? score2 : v; }
+        edge = end_ref1 + maskLen > refLen ? refLen : end_ref1 + maskLen;
+        for (int i = edge + (int)lane; i < refLen; i += 8) { int v = maxColumn[i]; score2 = score2 > v ? score2 : v; }
+        score2 = dpp_max8(score2);
+    }
+    if (lane == 0) {
+        o->score1 = fits ? max1 : 0; o->score2 = score2; o->ref_begin = -1; o->ref_end = fits ? end_ref1 : 0;
+        o->read_begin = -1; o->read_end = fits ? end_read1 : 0; o->start = rq.start; o->strand = rq.strand; o->n_cigar = 0;
+        o->ok = (uint16_t)(fits && !(rq.pad & 1u) ? 1 : 0);          // (pad bit 0: score only -- polish's first pass over every hit: ssw_align flag 0)
+    }
+}
+
+template <int SEG>                     // 0: stripe rows in LDS (any read length); > 0: in registers, segLen <= SEG
+__global__ void __launch_bounds__(64) SALT_SW_WAVES(SEG)
+k_swf(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+      const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
+      uint32_t *__restrict__ overflow, uint8_t *__restrict__ scratch, uint32_t maxcol_bytes, uint32_t seg, int dbg_arg)
+{
+    const int dbg = SALT_DIAG_VAL(dbg_arg);                      // diagnostics build only: 2 = phase clocks, 4 = column counts, 32 = no pass, 128 = no pairs
+    extern __shared__ __attribute__((aligned(16))) uint8_t sw_lds[];
+    const uint32_t grp = threadIdx.x >> 3, lane = threadIdx.x & 7u;
+    SwLds s;
+    uint8_t *read2; short *hm2;                                   // the second request's bases and H-at-best (register variants)
+    if (SEG == 0) {
+        uint8_t *base = sw_lds + (size_t)grp * sw_group_bytes(seg);
+        s.H[0] = reinterpret_cast<short *>(base); s.H[1] = s.H[0] + seg * 8; s.E = s.H[1] + seg * 8; s.Hmax = s.E + seg * 8;
+        s.read = reinterpret_cast<uint8_t *>(s.Hmax + seg * 8);
+        read2 = s.read; hm2 = s.Hmax;
+    } else {
+        const uint32_t rd = (8u * seg + 15u) & ~15u;
+        s.H[0] = s.H[1] = s.E = nullptr;
+        s.read = sw_lds + (size_t)grp * 2u * rd; read2 = s.read + rd;
+        s.Hmax = reinterpret_cast<short *>(sw_lds + 16u * rd) + (size_t)grp * 2u * (SEG ? SEG : 1) * 8;       // 2 x [SEG][8] per group, behind the reads
+        hm2 = s.Hmax + (SEG ? SEG : 1) * 8;
+    }
+    uint32_t *lw = reinterpret_cast<uint32_t *>(sw_lds + sw_lds_words_at(seg, SEG, true)) + grp * 16u;      // 2 x 8 window words per group
+    const uint32_t n_req = pctl[0];
+    uint16_t *maxColumn0 = reinterpret_cast<uint16_t *>(scratch + ((size_t)blockIdx.x * 8 + grp) * 2u * maxcol_bytes);
+    uint16_t *maxColumn1 = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(maxColumn0) + maxcol_bytes);
+    // The wave pulls sixteen requests at a time, two neighbours per group, and leaves as a whole (a uniform exit): groups that drew numbers
+    // past the end sit the round out.  (Groups pulling one request each and leaving one by one is the shape this loop had; with hipcc 7.2 the
+    // kernel then never finished once the traceback had moved out of it -- tools/dbg/sw_hang.hip reproduces that -- so the exit is kept
+    // uniform.)
+    for (;;) {
+        uint32_t base = 0;
+        if (threadIdx.x == 0) base = atomicAdd(head, 16u);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n_req) break;
+        const uint32_t it0 = base + 2u * grp;
+        if (it0 >= n_req) continue;
+        const bool two = it0 + 1 < n_req;
+        const PeSwReq rq0 = req[it0], rq1 = req[two ? it0 + 1 : it0];
+        const uint32_t off0 = offs[rq0.mate], L0 = offs[rq0.mate + 1] - off0, off1 = offs[rq1.mate], L1 = offs[rq1.mate + 1] - off1;
+        const int refLen0 = (int)(rq0.end - rq0.start + 1), refLen1 = (int)(rq1.end - rq1.start + 1);
+        const bool sane0 = rq0.start < ix.ref_len && refLen0 > 0, sane1 = two && rq1.start < ix.ref_len && refLen1 > 0;
+        const bool skip = (dbg & 32) != 0;
+        const bool fits0 = sane0 && (uint64_t)refLen0 * 2u <= maxcol_bytes && L0 <= seg * 8u && !skip;
+        const bool fits1 = sane1 && (uint64_t)refLen1 * 2u <= maxcol_bytes && L1 <= seg * 8u && !skip;
+        if (lane == 0 && !skip && ((sane0 && !fits0) || (sane1 && !fits1))) atomicAdd(overflow, (uint32_t)(sane0 && !fits0) + (uint32_t)(sane1 && !fits1));
+        const unsigned long long t0 = dbg & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
+        int m0 = 0, er0 = 0, ed0 = 0, m1 = 0, er1 = 0, ed1 = 0;
+        const uint32_t uL = (uint32_t)__builtin_amdgcn_readfirstlane((int)L0), uaware = (uint32_t)__builtin_amdgcn_readfirstlane((int)rq0.aware);
+        const bool pack = SEG != 0 && !(dbg & 128) &&
+                          __all(fits0 && fits1 && L0 == uL && L1 == uL && rq0.aware == uaware && rq1.aware == uaware);      // the whole wave or none
+        if (pack) {
+            sw_load_read(seqs, off0, L0, rq0.strand, s.read, lane); sw_load_read(seqs, off1, L1, rq1.strand, read2, lane);
+            sw_fwd2_reg<(SEG ? SEG : 1)>(ix, pac, (int)rq0.aware, rq0.start, rq1.start, refLen0, refLen1, (int)L0, s.read, read2, maxColumn0, maxColumn1,
+                                         s.Hmax, hm2, lw, m0, m1, er0, er1, ed0, ed1);
+            if ((dbg & 4) && lane == 0) atomicAdd(overflow + 1, (uint32_t)(refLen0 > refLen1 ? refLen0 : refLen1));
+        } else {
+            if (fits0) {
+                sw_load_read(seqs, off0, L0, rq0.strand, s.read, lane);
+                const uint8_t *rdp = s.read;
+                auto fwd = [&](int q) -> uint32_t { return rdp[q]; };
+                if (SEG == 0) sw_word_pass(ix, pac, (int)rq0.aware, s, rq0.start, 0, refLen0, (int)L0, fwd, 0xFFFF, maxColumn0, m0, er0, ed0);
+                else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, (int)rq0.aware, rq0.start, 0, refLen0, (int)L0, fwd, 0xFFFF, maxColumn0, s.Hmax, lw, m0, er0, ed0,
+                                                       (dbg & 4) ? overflow + 1 : nullptr);
+            }
+            if (fits1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                sw_load_read(seqs, off1, L1, rq1.strand, read2, lane);
+                const uint8_t *rdp = read2;
+                auto fwd = [&](int q) -> uint32_t { return rdp[q]; };
+                if (SEG == 0) sw_word_pass(ix, pac, (int)rq1.aware, s, rq1.start, 0, refLen1, (int)L1, fwd, 0xFFFF, maxColumn1, m1, er1, ed1);
+                else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, (int)rq1.aware, rq1.start, 0, refLen1, (int)L1, fwd, 0xFFFF, maxColumn1, hm2, lw, m1, er1, ed1,
+                                                       (dbg & 4) ? overflow + 1 : nullptr);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        sw_fwd_row(res + it0, rq0, fits0, refLen0, L0, maxColumn0, m0, er0, ed0, lane);
+        if (two) sw_fwd_row(res + it0 + 1, rq1, fits1, refLen1, L1, maxColumn1, m1, er1, ed1, lane);
+        if ((dbg & 2) && lane == 0) atomicAdd(overflow + 1, (uint32_t)(__builtin_amdgcn_s_memtime() - t0));       // phase clock (10 ns ticks)
+    }
+}
+
+template <int SEG>
+__global__ void __launch_bounds__(64) SALT_SW_WAVES(SEG)
+k_swr(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+      const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
+      uint32_t *__restrict__ overflow, uint32_t seg, int dbg_arg)
+{
+    const int dbg = SALT_DIAG_VAL(dbg_arg);                      // diagnostics build only: 2 = phase clocks, 8 = column counts, 16 = no pass
     extern __shared__ __attribute__((aligned(16))) uint8_t sw_lds[];
     const uint32_t grp = threadIdx.x >> 3, lane = threadIdx.x & 7u;
     SwLds s;
@@ -453,76 +760,37 @@ k_sw(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ 
         s.H[0] = reinterpret_cast<short *>(base); s.H[1] = s.H[0] + seg * 8; s.E = s.H[1] + seg * 8; s.Hmax = s.E + seg * 8;
         s.read = reinterpret_cast<uint8_t *>(s.Hmax + seg * 8);
     } else {
+        const uint32_t rd = (8u * seg + 15u) & ~15u;
         s.H[0] = s.H[1] = s.E = nullptr;
-        s.read = sw_lds + (size_t)grp * ((8u * seg + 15u) & ~15u);
-        s.Hmax = reinterpret_cast<short *>(sw_lds + 8u * ((8u * seg + 15u) & ~15u)) + (size_t)grp * (SEG ? SEG : 1) * 8;      // [SEG][8] per group, behind the reads
+        s.read = sw_lds + (size_t)grp * rd;
+        s.Hmax = reinterpret_cast<short *>(sw_lds + 8u * rd) + (size_t)grp * (SEG ? SEG : 1) * 8;
     }
+    uint32_t *lw = reinterpret_cast<uint32_t *>(sw_lds + sw_lds_words_at(seg, SEG, false)) + grp * 8u;
     const uint32_t n_req = pctl[0];
-    uint16_t *maxColumn = reinterpret_cast<uint16_t *>(scratch + ((size_t)blockIdx.x * 8 + grp) * maxcol_bytes);
-    // The wave pulls eight requests at a time, one per group, and leaves as a whole (a uniform exit): groups that drew a number past the
-    // end sit the round out.  (Groups pulling one request each and leaving one by one is the shape this loop had; with hipcc 7.2 the kernel
-    // then never finished once the traceback had moved out of it -- tools/dbg/sw_hang.hip reproduces that -- so the exit is kept uniform.)
-    for (;;) {
+    for (;;) {                                                       // eight requests per pull, a uniform exit (see k_swf)
         uint32_t base = 0;
         if (threadIdx.x == 0) base = atomicAdd(head, 8u);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= n_req) break;
         const uint32_t it = base + grp;
         if (it >= n_req) continue;
+        PeSwRes *o = res + it;
+        if (o->ok != 1 || (dbg & 16)) continue;
         const PeSwReq rq = req[it];
-        PeSwRes out; out.score1 = 0; out.score2 = 0; out.ref_begin = -1; out.ref_end = 0; out.read_begin = -1; out.read_end = 0; out.n_cigar = 0; out.ok = 0; out.start = rq.start; out.strand = rq.strand;
         const uint32_t off = offs[rq.mate], L = offs[rq.mate + 1] - off;
-        const int refLen = (int)(rq.end - rq.start + 1);
-        const int aware = rq.aware;                                 // 0 plain, 1 SNP-aware, 2 polish matrix
-        const bool sane = rq.start < ix.ref_len && refLen > 0;
-        const bool fits = sane && (uint64_t)refLen * 2u <= maxcol_bytes && L <= seg * 8u;
-        if (sane && !fits && lane == 0) atomicAdd(overflow, 1u);
-        if (fits && !(dbg & 32)) {
-            // the mate's bases on the requested strand
-            for (uint32_t i = lane; i < L; i += 8) {
-                uint32_t c = rq.strand ? seqs[off + (L - 1 - i)] : seqs[off + i];
-                if (rq.strand && c < 4) c = 3 - c;
-                s.read[i] = (uint8_t)(c > 4 ? 4 : c);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-            const unsigned long long t0 = dbg & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
-            int max1, end_ref1, end_read1;
-            auto fwd = [&](int q) -> uint32_t { return s.read[q]; };
-            if (SEG == 0) sw_word_pass(ix, pac, aware, s, rq.start, 0, refLen, (int)L, fwd, 0xFFFF, maxColumn, max1, end_ref1, end_read1);
-            else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, aware, rq.start, 0, refLen, (int)L, fwd, 0xFFFF, maxColumn, (uint16_t *)nullptr, s.Hmax,
-                                                   max1, end_ref1, end_read1, (dbg & 4) ? overflow + 1 : nullptr);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-            // second best outside +-maskLen around the end column (ssw.c:529-542), maskLen = L/2 >= 15 or none
-            int score2 = 0;
-            const int maskLen = (int)L / 2;
-            if (maskLen >= 15 && !(dbg & 64)) {
-                int edge = end_ref1 - maskLen > 0 ? end_ref1 - maskLen : 0;
-                for (int i = (int)lane; i < edge; i += 8) { int v = maxColumn[i]; score2 = score2 > v ? score2 : v; }
-                edge = end_ref1 + maskLen > refLen ? refLen : end_ref1 + maskLen;
-                for (int i = edge + (int)lane; i < refLen; i += 8) { int v = maxColumn[i]; score2 = score2 > v ? score2 : v; }
-                score2 = dpp_max8(score2);
-            }
-            out.score1 = max1; out.score2 = score2; out.ref_end = end_ref1; out.read_end = end_read1;
-            if (!(rq.pad & 1u) && !(dbg & 16)) {                     // (pad bit 0: score only -- polish's first pass over every hit: ssw_align flag 0)
-                const unsigned long long t1 = dbg & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
-                // reverse pass from the end point to find the beginning (ssw.c:817-830)
-                int max2, beg_ref, beg_read_rev;
-                auto rev = [&](int q) -> uint32_t { return s.read[end_read1 - q]; };
-                if (SEG == 0) sw_word_pass(ix, pac, aware, s, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, max2, beg_ref, beg_read_rev);
-                else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, aware, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, (uint16_t *)nullptr, s.Hmax,
-                                                       max2, beg_ref, beg_read_rev, (dbg & 8) ? overflow + 1 : nullptr);
-                out.ref_begin = beg_ref; out.read_begin = end_read1 - beg_read_rev;
-                out.ok = 2;                                          // the banded traceback is k_swtb's
-                if ((dbg & 2) && lane == 0) {                        // phase clocks (10 ns ticks)
-                    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-                    atomicAdd(overflow + 1, (uint32_t)(t1 - t0)); atomicAdd(overflow + 2, (uint32_t)(t2 - t1));
-                }
-            }
-        }
-        if (lane == 0) {                                             // the row without its CIGAR words (k_swtb writes them)
-            PeSwRes *o = res + it;
-            o->score1 = out.score1; o->score2 = out.score2; o->ref_begin = out.ref_begin; o->ref_end = out.ref_end; o->read_begin = out.read_begin; o->read_end = out.read_end;
-            o->start = out.start; o->strand = out.strand; o->n_cigar = 0; o->ok = out.ok;
+        const int max1 = o->score1, end_ref1 = o->ref_end, end_read1 = o->read_end;
+        const unsigned long long t0 = dbg & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
+        sw_load_read(seqs, off, L, rq.strand, s.read, lane);
+        const uint8_t *rdp = s.read;
+        int max2, beg_ref, beg_read_rev;
+        auto rev = [&](int q) -> uint32_t { return rdp[end_read1 - q]; };
+        if (SEG == 0) sw_word_pass(ix, pac, (int)rq.aware, s, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, max2, beg_ref, beg_read_rev);
+        else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, (int)rq.aware, rq.start, 1, end_ref1 + 1, end_read1 + 1, rev, max1, (uint16_t *)nullptr, s.Hmax, lw,
+                                               max2, beg_ref, beg_read_rev, (dbg & 8) ? overflow + 1 : nullptr);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            o->ref_begin = beg_ref; o->read_begin = end_read1 - beg_read_rev; o->ok = 2;      // the banded traceback is k_swtb's
+            if (dbg & 2) atomicAdd(overflow + 2, (uint32_t)(__builtin_amdgcn_s_memtime() - t0));
         }
     }
 }
@@ -717,19 +985,21 @@ static int sw_seg_variant(uint32_t max_len)
     const uint32_t seg = (max_len + 7) / 8;
     return lds_only ? 0 : seg <= 13 ? 13 : seg <= 19 ? 19 : seg <= 32 ? 32 : 0;
 }
-uint32_t sw_lds_bytes(uint32_t max_len)
+uint32_t sw_lds_bytes(uint32_t max_len, bool fwd)
 {
     const uint32_t seg = (max_len + 7) / 8, rd = (8u * seg + 15u) & ~15u;
     const uint32_t v = (uint32_t)sw_seg_variant(max_len);
-    return v ? 8u * rd + 8u * v * 8u * 2u : 8u * (4u * seg * 16u + rd);          // register variants: the reads + H-at-best [SEG][8] shorts per group
+    // register variants: per group the read + H-at-best [SEG][8] shorts of each request in flight (k_swf: a pair, k_swr: one)
+    (void)rd;
+    return sw_lds_words_at(seg, v, fwd) + 8u * (fwd ? 64u : 32u);        // + the groups' window words (RefStream)
 }
 // one-wave blocks per CU: what registers (the register variants) or LDS (the LDS variant) admit
 uint32_t sw_blocks_per_cu(uint32_t max_len)
 {
     int n = 0;
     const int v = sw_seg_variant(max_len);
-    const void *f = v == 13 ? (const void *)k_sw<13> : v == 19 ? (const void *)k_sw<19> : v == 32 ? (const void *)k_sw<32> : (const void *)k_sw<0>;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64, sw_lds_bytes(max_len)) != hipSuccess || n < 1) n = 1;
+    const void *f = v == 13 ? (const void *)k_swf<13> : v == 19 ? (const void *)k_swf<19> : v == 32 ? (const void *)k_swf<32> : (const void *)k_swf<0>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64, sw_lds_bytes(max_len, true)) != hipSuccess || n < 1) n = 1;
     return (uint32_t)(n > (int)SW_MAX_BLOCKS_PER_CU ? (int)SW_MAX_BLOCKS_PER_CU : n);
 }
 // k_swtb's LDS per group: the aligned part of the mate, the reference symbols of alignments up to twice the read length, three band rows
@@ -766,10 +1036,10 @@ SwGeom sw_geom(uint32_t max_len, uint64_t max_window, uint32_t cus)
     return g;
 }
 void sw_geom_limit(SwGeom &g, uint32_t blocks) { if (blocks < 1) blocks = 1; if (g.n_blocks > blocks) g.n_blocks = blocks; if (g.tb_blocks > blocks) g.tb_blocks = blocks; }
-uint64_t sw_scratch_bytes(const SwGeom &g) { return (uint64_t)g.n_blocks * 8 * g.maxcol_bytes + (uint64_t)g.tb_blocks * 8 * g.tb_group_bytes; }
+uint64_t sw_scratch_bytes(const SwGeom &g) { return (uint64_t)g.n_blocks * 16 * g.maxcol_bytes + (uint64_t)g.tb_blocks * 8 * g.tb_group_bytes; }
 
 void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, const uint32_t *offs, const PeSwReq *req, const uint32_t *pctl,
-               PeSwRes *res, uint32_t *head, uint32_t *tb_head, uint32_t *overflow, uint8_t *scratch, SwGeom g, uint32_t max_len, hipStream_t st)
+               PeSwRes *res, uint32_t *head, uint32_t *rev_head, uint32_t *tb_head, uint32_t *overflow, uint8_t *scratch, SwGeom g, uint32_t max_len, hipStream_t st)
 {
     const uint32_t seg = (max_len + 7) / 8;
 #ifdef SALT_DIAG
@@ -777,8 +1047,11 @@ void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, con
 #else
     const int dbg = 0;
 #endif
-#define SALT_LAUNCH_SW(V) hipLaunchKernelGGL(k_sw<V>, dim3(g.n_blocks), dim3(64), sw_lds_bytes(max_len), st, ix, pac, seqs, offs, req, pctl, res, head, \
-                                             overflow, scratch, g.maxcol_bytes, seg, dbg)
+#define SALT_LAUNCH_SW(V) do { \
+        hipLaunchKernelGGL(k_swf<V>, dim3(g.n_blocks), dim3(64), sw_lds_bytes(max_len, true), st, ix, pac, seqs, offs, req, pctl, res, head, \
+                           overflow, scratch, g.maxcol_bytes, seg, dbg); \
+        hipLaunchKernelGGL(k_swr<V>, dim3(g.n_blocks), dim3(64), sw_lds_bytes(max_len, false), st, ix, pac, seqs, offs, req, pctl, res, rev_head, \
+                           overflow, seg, dbg); } while (0)
     switch (sw_seg_variant(max_len)) {
     case 13: SALT_LAUNCH_SW(13); break;
     case 19: SALT_LAUNCH_SW(19); break;
@@ -794,7 +1067,7 @@ void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, con
     if (getenv("SALT_GPU_TB_CLOCKS")) tb_dbg |= 0x10000;
 #endif
     hipLaunchKernelGGL(k_swtb, dim3(g.tb_blocks), dim3(64), 8u * tg.group_b, st, ix, pac, seqs, offs, req, pctl, res, tb_head, overflow,
-                       scratch + (uint64_t)g.n_blocks * 8 * g.maxcol_bytes, g.tb_group_bytes, tg, tb_dbg);
+                       scratch + (uint64_t)g.n_blocks * 16 * g.maxcol_bytes, g.tb_group_bytes, tg, tb_dbg);
 }
 
 } // namespace salt
