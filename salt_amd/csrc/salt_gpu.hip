@@ -906,11 +906,11 @@ extern "C" int salt_gpu_polish_sw(salt_gpu_polish_t *p, const uint8_t *codes, co
     SwGeom geom = sw_geom(max_len, max_len, p->n_blocks / 8u);
     sw_geom_limit(geom, (n_items + 7u) / 8u);
     PCHK(hipMalloc((void **)&d_scr, sw_scratch_bytes(geom)));
-    const uint32_t ctl[5] = { n_items, 0, 0, 0, 0 };         // requests, k_swf's head, overflow count, k_swtb's head, k_swr's head
-    PCHK(hipMalloc((void **)&d_ctl, 20)); PCHK(hipMemcpy(d_ctl, ctl, 20, hipMemcpyHostToDevice));
+    const uint32_t ctl[9] = { n_items, 0, 0, 0, 0, 0, 0, 0, 0 };   // requests, -, overflow count, -, the four kernels' queue heads + pending count
+    PCHK(hipMalloc((void **)&d_ctl, 36)); PCHK(hipMemcpy(d_ctl, ctl, 36, hipMemcpyHostToDevice));
     IndexView v; memset(&v, 0, sizeof v);
     v.ref_len = (uint32_t)p->l_pac;                            // k_sw's range check; mode 2 reads the 2-bit genome only
-    launch_sw(v, p->d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 1, d_ctl + 4, d_ctl + 3, d_ctl + 2, d_scr, geom, max_len, nullptr);
+    launch_sw(v, p->d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 4, d_ctl + 2, d_scr, geom, max_len, nullptr);
     PCHK(hipGetLastError());
     PCHK(hipDeviceSynchronize());
     uint32_t h_ctl[3];
@@ -1097,11 +1097,11 @@ extern "C" int salt_gpu_diag_ssw(uint32_t n_cases, const uint8_t *aware, const u
     SwGeom geom = sw_geom(diag_max_len, diag_max_win, 1);
     geom.n_blocks = blocks; geom.tb_blocks = blocks;
     HIPCHK(hipMalloc((void **)&d_scr, sw_scratch_bytes(geom)));
-    const uint32_t ctl[5] = { n_cases, 0, 0, 0, 0 };          // requests, k_swf's head, overflow count, k_swtb's head, k_swr's head
-    HIPCHK(hipMalloc((void **)&d_ctl, 20)); HIPCHK(hipMemcpy(d_ctl, ctl, 20, hipMemcpyHostToDevice));
+    const uint32_t ctl[9] = { n_cases, 0, 0, 0, 0, 0, 0, 0, 0 };    // requests, -, overflow count, -, the four kernels' queue heads + pending count
+    HIPCHK(hipMalloc((void **)&d_ctl, 36)); HIPCHK(hipMemcpy(d_ctl, ctl, 36, hipMemcpyHostToDevice));
     IndexView v; memset(&v, 0, sizeof v);
     v.ref = d_ref; v.ref_len = (uint32_t)n_sym;
-    launch_sw(v, d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 1, d_ctl + 4, d_ctl + 3, d_ctl + 2, d_scr, geom, diag_max_len, nullptr);
+    launch_sw(v, d_pac, d_codes, d_offs, d_req, d_ctl, d_res, d_ctl + 4, d_ctl + 2, d_scr, geom, diag_max_len, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     std::vector<PeSwRes> h_res(n_cases);
@@ -1290,7 +1290,7 @@ static int pe_prepare(salt_gpu_ws_t *ws, uint32_t n_pairs, hipStream_t st)
         ws->pe_pairs_cap = n_pairs;
     }
     if (!ws->d_pctl) {
-        HIPCHK(hipMalloc((void **)&ws->d_pctl, 16 * 4));         // [0..7] see pe_resident_impl; [8..11] k_swtb's phase clocks (diagnostics build); [12] k_swr's head
+        HIPCHK(hipMalloc((void **)&ws->d_pctl, 20 * 4));         // [0..7] see pe_resident_impl; [8..11] k_swtb's phase clocks (diagnostics build); [12..15] the queue heads of k_swf, k_swf1, k_swr, k_swtb, [16] k_swf1's request count
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ws->ix->device));
         ws->sw_blocks = (uint32_t)prop.multiProcessorCount;             // CUs: k_sw runs up to SW_MAX_BLOCKS_PER_CU blocks on each
@@ -1308,7 +1308,7 @@ static int pe_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const sa
     rc = align_resident_impl(ws, o, 2 * n_pairs, max_len, d_seqs, d_offs, d_results, st, 1);
     if (rc) return rc;
     hipEvent_t *ev = ws->n_timed == ti + 1 ? &ws->ev[(size_t)ti * EV_PER_CALL] : nullptr;      // the call above was timed: three more events
-    HIPCHK(hipMemsetAsync(ws->d_pctl, 0, 64, st));
+    HIPCHK(hipMemsetAsync(ws->d_pctl, 0, 80, st));
     launch_pair(n_pairs, pe->min_tlen, pe->max_tlen, (uint32_t)ws->ix->l_pac, static_cast<const uint32_t *>(d_offs), static_cast<salt_result_t *>(d_results),
                 ws->d_pairs, ws->d_req, ws->d_pctl, st);
     if (ev) HIPCHK(hipEventRecord(ev[8], st));
@@ -1328,7 +1328,7 @@ static int pe_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, const sa
         ws->sw_scr_bytes = need;
     }
     launch_sw(ws->ix->view, ws->ix->d_pac, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_req, ws->d_pctl, ws->d_swres,
-              ws->d_pctl + 1, ws->d_pctl + 12, ws->d_pctl + 7, ws->d_pctl + 4, ws->d_sw_scr, geom, max_len, st);   // pctl: requests, k_swf head, CIGAR items + head, overflow, (diagnostics), k_swtb head; [12] k_swr head
+              ws->d_pctl + 12, ws->d_pctl + 4, ws->d_sw_scr, geom, max_len, st);   // pctl: requests, -, CIGAR items + head, overflow, (diagnostics); [12..15] the Smith-Waterman kernels' queue heads
     if (ev) HIPCHK(hipEventRecord(ev[9], st));
     launch_pe_final(ws->ix->view, PackGeom::make(max_len), n_pairs, ws->d_pm, static_cast<salt_result_t *>(d_results), ws->d_pairs, ws->d_swres, ws->d_lvtab,
                     ws->d_pcq, ws->d_pctl + 2, ws->heavy_blocks, st);

@@ -104,12 +104,12 @@ struct PeSwRes { int32_t score1, score2, ref_begin, ref_end, read_begin, read_en
 struct PePair { uint32_t req0; uint8_t n_req; uint8_t rescued[2]; uint8_t pad; };             // requests req0 .. req0+n_req-1, in the order tried
 void launch_pair(uint32_t n_pairs, uint32_t min_tlen, uint32_t max_tlen, uint32_t l_pac, const uint32_t *offs, salt_result_t *res,
                  PePair *pairs, PeSwReq *req, uint32_t *pctl, hipStream_t st);
-// k_swf (forward pass: scores, end point), k_swr (reverse pass: begin point), k_swtb (banded traceback -> CIGAR); head / rev_head / tb_head: the
-// three kernels' queue heads (zeroed by the caller).
+// k_swf (+ k_swf1: forward pass: scores, end point), k_swr (reverse pass: begin point), k_swtb (banded traceback -> CIGAR); heads[0..3]: the
+// four kernels' queue heads, heads[4]: the number of requests k_swf leaves to k_swf1 (five words zeroed by the caller).
 // overflow: counts rescues this build cannot finish as the reference would (window beyond the scratch, band beyond SW_BAND_W, more than
 // SALT_MAX_CIGAR_OPS operations); the caller turns a non-zero count into an error instead of returning rows that differ from the reference's
 void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, const uint32_t *offs, const PeSwReq *req, const uint32_t *pctl,
-               PeSwRes *res, uint32_t *head, uint32_t *rev_head, uint32_t *tb_head, uint32_t *overflow, uint8_t *scratch, SwGeom g, uint32_t max_len, hipStream_t st);
+               PeSwRes *res, uint32_t *heads, uint32_t *overflow, uint8_t *scratch, SwGeom g, uint32_t max_len, hipStream_t st);
 static const uint32_t SW_MAX_BLOCKS_PER_CU = 16;   // one-wave blocks per CU at most
 static const uint64_t SW_SCRATCH_TOTAL = 2ull << 30;   // k_swtb's grid shrinks before its groups' global scratch passes 2 GiB
 uint32_t sw_blocks_per_cu(uint32_t max_len);

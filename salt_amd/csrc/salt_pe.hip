@@ -194,97 +194,127 @@ __device__ __forceinline__ uint32_t sw_prof_fields(bool masks, bool polish, uint
     return ((polish ? 2u : 3u) << 20) | (masks ? 0u : 2u << 16) | hit;
 }
 
+// The pass is cut into begin / column / end so that the groups of a wave can be at different columns of different requests (k_swr).
+template <int SEG> struct Pass1 {                                // one request's pass between two columns
+    int H[SEG], E[SEG]; uint32_t shp[(SEG + 5) / 6];             // shp: the 5-bit profile shifts of six stripes per register
+    RefStream rs; uint32_t w_ahead;                              // the next column's word
+    int last, max, end_ref, vMaxScore, vMaxMark;
+};
+// Every H, E and F here lies in [0, 32767] (scores are at most the read length), where the SSE2 operations reduce to plain
+// integer ones: adds_epi16(vH, profile) = vH + profile, subs_epu16(x, g) = max(x - g, 0).  The profile of a column is six
+// 4-bit fields (value + 3 per read code 0..3, N, "past the read"), so a cell's lookup is one bit-field extract.
+// H at the best column so far (what the end point is read from, ssw.c:504-512) is written a few dozen times per pass and read once:
+// it lives in the group's LDS (hm[j * 8 + lane]).
+template <int SEG, class ReadAt>
+__device__ __forceinline__ void pass1_begin(Pass1<SEG> &f, int readLen, ReadAt rd, short *hm, uint32_t *lw, const IndexView &ix, const uint8_t *pac, int aware,
+                                            uint32_t ref0, int n, int dir, int lane)
+{
+    const int segLen = (readLen + 7) / 8;
+#pragma unroll
+    for (int k = 0; k < (SEG + 5) / 6; ++k) f.shp[k] = 0;
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+        f.H[j] = 0; f.E[j] = 0; hm[j * 8 + lane] = 0;
+        const int q = j + lane * segLen;
+        const uint32_t code = (j < segLen && q < readLen) ? rd(q) : 5u;      // 5: past the read (profile 0)
+        f.shp[j / 6] |= (4u * (code > 5u ? 4u : code)) << (5 * (j % 6));
+    }
+    const bool masks = aware == 1;                               // 4-bit allele masks (mixRef) or the 2-bit genome
+    const uint32_t ws = masks ? 3u : 4u;
+    f.rs.lw = lw;
+    ref_stream_turn(f.rs, masks ? ix.ref : reinterpret_cast<const uint32_t *>(pac), ix.ref_len, ws, ref0, n, dir, 0, lane);
+    f.w_ahead = ref_stream_word(f.rs, ws, ref0, n, dir, 0);
+    f.last = 0; f.max = 0; f.end_ref = 0; f.vMaxScore = 0; f.vMaxMark = 0;
+}
+// pass column c (window position i = c forward, n - 1 - c reverse); returns the column's maximum
+template <int SEG>
+__device__ __forceinline__ int pass1_column(Pass1<SEG> &f, int c, int readLen, short *hm, const IndexView &ix, const uint8_t *pac, int aware,
+                                            uint32_t ref0, int n, int dir, int lane)
+{
+    const uint64_t gmask = 0xFFull << (threadIdx.x & 56u);
+    const int segLen = (readLen + 7) / 8, go = 3, ge = 1;      // aln.h:137-138
+    const bool masks = aware == 1, polish = aware == 2;
+    const uint32_t ws = masks ? 3u : 4u;
+    const int bias = polish ? 2 : 3;                             // the smallest score of the matrix in use, negated
+    const int i = dir ? n - 1 - c : c;
+    const uint32_t prof4 = sw_prof_fields(masks, polish, ref_word_symbol(f.w_ahead, masks, ref0, n, dir, c));
+    if (c + 1 == f.rs.cnext) ref_stream_turn(f.rs, masks ? ix.ref : reinterpret_cast<const uint32_t *>(pac), ix.ref_len, ws, ref0, n, dir, c + 1, lane);
+    f.w_ahead = ref_stream_word(f.rs, ws, ref0, n, dir, c + 1);
+    int vF = 0, vMaxColumn = 0;
+    int vH = dpp_row_shr<1>(f.last);                             // H of the last stripe, as the column before left it
+    if (lane == 0) vH = 0;
+    // (keeps the stripes' shifts packed: left alone, the compiler extracts all of them ahead of the loop into registers it does
+    // not have and reloads them from scratch memory stripe by stripe)
+#pragma unroll
+    for (int k = 0; k < (SEG + 5) / 6; ++k) asm volatile("" : "+v"(f.shp[k]));
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+        if (j < segLen) {
+            int h = vH + (int)((prof4 >> ((f.shp[j / 6] >> (5 * (j % 6))) & 31u)) & 15u) - bias;
+            int e = f.E[j];
+            h = h > e ? h : e; h = h > vF ? h : vF;
+            vMaxColumn = vMaxColumn > h ? vMaxColumn : h;
+            vH = f.H[j];                                         // the previous column's value: input of stripe j+1
+            f.H[j] = h;
+            h -= go; h = h > 0 ? h : 0;
+            e -= ge; e = e > h ? e : h; f.E[j] = e;
+            vF -= ge; vF = vF > h ? vF : h;
+        }
+    }
+    // lazy F (ssw.c:487-497) in closed form.  The reference shifts vF one lane up and sweeps the stripes (H = max(H, vF); vF -= ge),
+    // up to 8 times, leaving early once no lane has vF - ge > H - go.  The sweeps only EXTEND gaps (no new F is opened), so what
+    // stripe j of lane l can receive is max over k of (vF at the end of lane l-1-k's column) - k * segLen - j, floored at 0 by the
+    // saturating subtraction; and after the reference's early exit no H changes any more (from there on the lane's own F chain of
+    // the main loop, >= H[j] - go - ..., dominates the carried one), so taking the full maximum gives the same H.  A max-plus scan
+    // over the 8 lanes and one pass over the stripes replace the sweeps (which the 8 requests of a wave would each stretch to
+    // the longest of them).  E and the column maximum are not touched by the lazy pass there either.
+    {
+        int cf = dpp_row_shr<1>(vF);
+        if (lane == 0) cf = 0;
+        const int seg_ge = segLen * ge;
+        { int t = dpp_row_shr<1>(cf); t = lane >= 1 ? t - seg_ge : 0; t = t > 0 ? t : 0; cf = cf > t ? cf : t; }
+        { int t = dpp_row_shr<2>(cf); t = lane >= 2 ? t - 2 * seg_ge : 0; t = t > 0 ? t : 0; cf = cf > t ? cf : t; }
+        { int t = dpp_row_shr<4>(cf); t = lane >= 4 ? t - 4 * seg_ge : 0; t = t > 0 ? t : 0; cf = cf > t ? cf : t; }
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) {
+            if (j < segLen) { int fj = cf - j * ge; fj = fj > 0 ? fj : 0; f.H[j] = f.H[j] > fj ? f.H[j] : fj; f.last = f.H[j]; }
+        }
+    }
+    f.vMaxScore = f.vMaxScore > vMaxColumn ? f.vMaxScore : vMaxColumn;
+    if (__ballot(f.vMaxMark != f.vMaxScore) & gmask) {
+        f.vMaxMark = f.vMaxScore;
+        const int temp = dpp_max8(f.vMaxScore);
+        if (temp > f.max) {
+            f.max = temp; f.end_ref = i;
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) hm[j * 8 + lane] = (short)f.H[j];
+        }
+    }
+    return dpp_max8(vMaxColumn);
+}
+// the smallest read position holding the maximum in the best column (ssw.c:504-512)
+template <int SEG>
+__device__ __forceinline__ int pass1_end(const Pass1<SEG> &f, int readLen, const short *hm, int lane)
+{
+    const int segLen = (readLen + 7) / 8;
+    int end_read = readLen - 1;
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) if (j < segLen && (int)hm[j * 8 + lane] == f.max) { int t = j + lane * segLen; if (t < end_read) end_read = t; }
+    for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(end_read, o, 8); end_read = end_read < t ? end_read : t; }
+    return end_read;
+}
+// a whole pass of one request, the groups of the wave in step
 template <int SEG, class ReadAt>
 __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint8_t *pac, int aware, uint32_t ref0, int ref_dir, int refLen,
                                                  int readLen, ReadAt rd, int terminate, uint16_t *maxColumn, short *hm, uint32_t *lw,
                                                  int &out_max, int &out_end_ref, int &out_end_read, uint32_t *dbg_cols = nullptr)
 {
-    uint32_t n_cols = 0;
     const int lane = (int)(threadIdx.x & 7u);
-    const uint64_t gmask = 0xFFull << (threadIdx.x & 56u);
-    const int segLen = (readLen + 7) / 8, go = 3, ge = 1;      // aln.h:137-138
-    // Every H, E and F here lies in [0, 32767] (scores are at most the read length), where the SSE2 operations reduce to plain
-    // integer ones: adds_epi16(vH, profile) = vH + profile, subs_epu16(x, g) = max(x - g, 0).  The profile of a column is six
-    // 4-bit fields (value + 3 per read code 0..3, N, "past the read"), so a cell's lookup is one bit-field extract.
-    // H at the best column so far (what the end point is read from, ssw.c:504-512) is written a few dozen times per pass and read once:
-    // it lives in the group's LDS (hm[j * 8 + lane]), and the profile shifts of six stripes share a register
-    int H[SEG], E[SEG]; uint32_t shp[(SEG + 5) / 6];
-#pragma unroll
-    for (int k = 0; k < (SEG + 5) / 6; ++k) shp[k] = 0;
-#pragma unroll
-    for (int j = 0; j < SEG; ++j) {
-        H[j] = 0; E[j] = 0; hm[j * 8 + lane] = 0;
-        const int q = j + lane * segLen;
-        const uint32_t code = (j < segLen && q < readLen) ? rd(q) : 5u;      // 5: past the read (profile 0)
-        shp[j / 6] |= (4u * (code > 5u ? 4u : code)) << (5 * (j % 6));
-    }
-    int max = 0, end_ref = 0, vMaxScore = 0, vMaxMark = 0;
-    const bool masks = aware == 1, polish = aware == 2;          // 4-bit allele masks (mixRef) or the 2-bit genome
-    const uint32_t *words = masks ? ix.ref : reinterpret_cast<const uint32_t *>(pac);
-    const uint32_t ws = masks ? 3u : 4u;
-    const int bias = polish ? 2 : 3;                             // the smallest score of the matrix in use, negated
-    RefStream rs; rs.lw = lw;
-    ref_stream_turn(rs, words, ix.ref_len, ws, ref0, refLen, ref_dir, 0, lane);
-    uint32_t w_ahead = ref_stream_word(rs, ws, ref0, refLen, ref_dir, 0);
-    int last = 0;                                                // H of the last stripe, as the column before left it
+    Pass1<SEG> f;
+    pass1_begin<SEG>(f, readLen, rd, hm, lw, ix, pac, aware, ref0, refLen, ref_dir, lane);
     int mc_keep = 0, c = 0;                                      // lane c % 8 keeps column c's maximum until the group stores eight
     for (; c < refLen; ++c) {
-        const int i = ref_dir ? refLen - 1 - c : c;
-        const uint32_t prof4 = sw_prof_fields(masks, polish, ref_word_symbol(w_ahead, masks, ref0, refLen, ref_dir, c));
-        if (c + 1 == rs.cnext) ref_stream_turn(rs, words, ix.ref_len, ws, ref0, refLen, ref_dir, c + 1, lane);
-        w_ahead = ref_stream_word(rs, ws, ref0, refLen, ref_dir, c + 1);
-        int vF = 0, vMaxColumn = 0;
-        int vH = dpp_row_shr<1>(last);
-        if (lane == 0) vH = 0;
-        // (keeps the stripes' shifts packed: left alone, the compiler extracts all of them ahead of the loop into registers it does
-        // not have and reloads them from scratch memory stripe by stripe)
-#pragma unroll
-        for (int k = 0; k < (SEG + 5) / 6; ++k) asm volatile("" : "+v"(shp[k]));
-#pragma unroll
-        for (int j = 0; j < SEG; ++j) {
-            if (j < segLen) {
-                int h = vH + (int)((prof4 >> ((shp[j / 6] >> (5 * (j % 6))) & 31u)) & 15u) - bias;
-                int e = E[j];
-                h = h > e ? h : e; h = h > vF ? h : vF;
-                vMaxColumn = vMaxColumn > h ? vMaxColumn : h;
-                vH = H[j];                                       // the previous column's value: input of stripe j+1
-                H[j] = h;
-                h -= go; h = h > 0 ? h : 0;
-                e -= ge; e = e > h ? e : h; E[j] = e;
-                vF -= ge; vF = vF > h ? vF : h;
-            }
-        }
-        ++n_cols;
-        // lazy F (ssw.c:487-497) in closed form.  The reference shifts vF one lane up and sweeps the stripes (H = max(H, vF); vF -= ge),
-        // up to 8 times, leaving early once no lane has vF - ge > H - go.  The sweeps only EXTEND gaps (no new F is opened), so what
-        // stripe j of lane l can receive is max over k of (vF at the end of lane l-1-k's column) - k * segLen - j, floored at 0 by the
-        // saturating subtraction; and after the reference's early exit no H changes any more (from there on the lane's own F chain of
-        // the main loop, >= H[j] - go - ..., dominates the carried one), so taking the full maximum gives the same H.  A max-plus scan
-        // over the 8 lanes and one pass over the stripes replace the sweeps (which the 8 requests of a wave would each stretch to
-        // the longest of them).  E and the column maximum are not touched by the lazy pass there either.
-        {
-            int cf = dpp_row_shr<1>(vF);
-            if (lane == 0) cf = 0;
-            const int seg_ge = segLen * ge;
-            { int t = dpp_row_shr<1>(cf); t = lane >= 1 ? t - seg_ge : 0; t = t > 0 ? t : 0; cf = cf > t ? cf : t; }
-            { int t = dpp_row_shr<2>(cf); t = lane >= 2 ? t - 2 * seg_ge : 0; t = t > 0 ? t : 0; cf = cf > t ? cf : t; }
-            { int t = dpp_row_shr<4>(cf); t = lane >= 4 ? t - 4 * seg_ge : 0; t = t > 0 ? t : 0; cf = cf > t ? cf : t; }
-#pragma unroll
-            for (int j = 0; j < SEG; ++j) {
-                if (j < segLen) { int f = cf - j * ge; f = f > 0 ? f : 0; H[j] = H[j] > f ? H[j] : f; last = H[j]; }
-            }
-        }
-        vMaxScore = vMaxScore > vMaxColumn ? vMaxScore : vMaxColumn;
-        if (__ballot(vMaxMark != vMaxScore) & gmask) {
-            vMaxMark = vMaxScore;
-            const int temp = dpp_max8(vMaxScore);
-            if (temp > max) {
-                max = temp; end_ref = i;
-#pragma unroll
-                for (int j = 0; j < SEG; ++j) hm[j * 8 + lane] = (short)H[j];
-            }
-        }
-        const int mc = dpp_max8(vMaxColumn);
+        const int mc = pass1_column<SEG>(f, c, readLen, hm, ix, pac, aware, ref0, refLen, ref_dir, lane);
         if (maxColumn) {                                         // (forward passes only: column c is window position c)
             if (lane == (c & 7)) mc_keep = mc;
             if ((c & 7) == 7) maxColumn[c - 7 + lane] = (uint16_t)mc_keep;
@@ -292,20 +322,17 @@ __device__ __forceinline__ void sw_word_pass_reg(const IndexView &ix, const uint
         if (mc == terminate) { ++c; break; }
     }
     if (maxColumn && (c & 7) && lane < (c & 7)) maxColumn[(c & ~7) + lane] = (uint16_t)mc_keep;
-    int end_read = readLen - 1;
-#pragma unroll
-    for (int j = 0; j < SEG; ++j) if (j < segLen && (int)hm[j * 8 + lane] == max) { int t = j + lane * segLen; if (t < end_read) end_read = t; }
-    for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(end_read, o, 8); end_read = end_read < t ? end_read : t; }
-    out_max = max; out_end_ref = end_ref; out_end_read = end_read;
-    if (dbg_cols && lane == 0) { atomicAdd(dbg_cols, n_cols); atomicAdd(dbg_cols + 1, n_cols * (uint32_t)segLen); }
+    out_max = f.max; out_end_ref = f.end_ref; out_end_read = pass1_end<SEG>(f, readLen, hm, lane);
+    if (dbg_cols && lane == 0) { atomicAdd(dbg_cols, (uint32_t)c); atomicAdd(dbg_cols + 1, (uint32_t)c * (uint32_t)((readLen + 7) / 8)); }
 }
 
 // The forward pass of TWO requests in one group: each lane's H, E, F hold request A in the low and request B in the high 16 bits of a
 // register and the column's operations are the packed 16-bit ones (v_pk_add_u16, v_pk_max_i16, v_pk_sub_u16 clamp = subs_epu16), so a
-// column of both costs what a column of one did, apart from the two profile look-ups.  The requests of the whole WAVE must have the same
-// read length and scoring (the stripes then line up and their count is a scalar; paired-end mates do); their windows may differ in
-// length -- the shorter one's half keeps running with its maximum, end point and column maxima frozen.  Same operations per half in the
-// same order as sw_word_pass_reg, so the same values.
+// column of both costs what a column of one did, apart from the two profile look-ups.  The requests of the whole LAUNCH that take this
+// path have the same read length and scoring (the stripes then line up and their count is a scalar; paired-end mates do); their windows
+// may differ in length -- the shorter one's half keeps running with its maximum, end point and column maxima frozen.  Same operations per
+// half in the same order as sw_word_pass_reg, so the same values.  The pass is cut into begin / column / end so that the groups of a wave
+// can be at different columns of different pairs (k_swf).
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)); }
@@ -317,120 +344,132 @@ __device__ __forceinline__ uint32_t dpp_pk_max8(uint32_t x)
     t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true); x = pk_max(x, t);
     t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true); return pk_max(x, t);
 }
+template <int SEG> struct Fwd2 {                                 // a pair's forward pass between two columns
+    uint32_t H[SEG], E[SEG], shp[(SEG + 2) / 3];                 // shp: per stripe the 5-bit profile shifts of A and of B, three stripes per register
+    RefStream rsA, rsB;                                          // (both streams turn their blocks at the same columns)
+    uint32_t wA, wB;                                             // the next column's words
+    uint32_t last, mc_keep, vMaxScore, vMaxMark;
+    int maxA, maxB, erA, erB;
+};
+// segLen: the same for every group of the wave (a scalar); awA / awB: the scoring of the two requests (0 plain, 1 SNP-aware, 2 polish matrix)
 template <int SEG>
-__device__ __forceinline__ void sw_fwd2_reg(const IndexView &ix, const uint8_t *pac, int aware, uint32_t ref0A, uint32_t ref0B, int refLenA, int refLenB,
-                                            int readLen, const uint8_t *rdA, const uint8_t *rdB, uint16_t *mcA, uint16_t *mcB, short *hmA, short *hmB,
-                                            uint32_t *lw, int &maxA_out, int &maxB_out, int &endRefA, int &endRefB, int &endReadA, int &endReadB)
+__device__ __forceinline__ void fwd2_begin(Fwd2<SEG> &f, int segLen, int readLen, const uint8_t *rdA, const uint8_t *rdB, short *hmA, short *hmB, uint32_t *lw,
+                                           const IndexView &ix, const uint8_t *pac, int awA, int awB, uint32_t ref0A, uint32_t ref0B, int nCols, int lane)
 {
-    const int lane = (int)(threadIdx.x & 7u);
-    const uint64_t gmask = 0xFFull << (threadIdx.x & 56u);
-    readLen = __builtin_amdgcn_readfirstlane(readLen); aware = __builtin_amdgcn_readfirstlane(aware);     // the same in every group (the caller checked)
-    const int segLen = (readLen + 7) / 8;
-    const uint32_t go2 = 0x00030003u, ge2 = 0x00010001u;         // aln.h:137-138, both halves
-    uint32_t H[SEG], E[SEG], shp[(SEG + 2) / 3];                 // per stripe: the 5-bit profile shifts of A and of B, three stripes per register
+    const uint32_t *wordsA = awA == 1 ? ix.ref : reinterpret_cast<const uint32_t *>(pac), *wordsB = awB == 1 ? ix.ref : reinterpret_cast<const uint32_t *>(pac);
+    const uint32_t wsA = awA == 1 ? 3u : 4u, wsB = awB == 1 ? 3u : 4u, ref_len = ix.ref_len;
 #pragma unroll
-    for (int k = 0; k < (SEG + 2) / 3; ++k) shp[k] = 0;
+    for (int k = 0; k < (SEG + 2) / 3; ++k) f.shp[k] = 0;
 #pragma unroll
     for (int j = 0; j < SEG; ++j) {
-        H[j] = 0; E[j] = 0; hmA[j * 8 + lane] = 0; hmB[j * 8 + lane] = 0;
+        f.H[j] = 0; f.E[j] = 0; hmA[j * 8 + lane] = 0; hmB[j * 8 + lane] = 0;
         const int q = j + lane * segLen;
         const bool in = j < segLen && q < readLen;
         const uint32_t ca = in ? rdA[q] : 5u, cb = in ? rdB[q] : 5u;
-        shp[j / 3] |= ((4u * (ca > 5u ? 4u : ca)) | (4u * (cb > 5u ? 4u : cb)) << 5) << (10 * (j % 3));
+        f.shp[j / 3] |= ((4u * (ca > 5u ? 4u : ca)) | (4u * (cb > 5u ? 4u : cb)) << 5) << (10 * (j % 3));
     }
-    const bool masks = aware == 1, polish = aware == 2;
-    const uint32_t *words = masks ? ix.ref : reinterpret_cast<const uint32_t *>(pac);
-    const uint32_t ws = masks ? 3u : 4u;
-    const uint32_t negb2 = (uint32_t)(-(polish ? 2 : 3) & 0xFFFF) * 0x00010001u;
-    const int nCols = refLenA > refLenB ? refLenA : refLenB;
-    RefStream rsA, rsB; rsA.lw = lw; rsB.lw = lw + 8;            // (both streams turn their blocks at the same columns)
-    ref_stream_turn(rsA, words, ix.ref_len, ws, ref0A, nCols, 0, 0, lane); ref_stream_turn(rsB, words, ix.ref_len, ws, ref0B, nCols, 0, 0, lane);
-    uint32_t wA = ref_stream_word(rsA, ws, ref0A, nCols, 0, 0), wB = ref_stream_word(rsB, ws, ref0B, nCols, 0, 0);
-    uint32_t last = 0, mc_keep = 0;
-    int maxA = 0, maxB = 0, erA = 0, erB = 0;
-    uint32_t vMaxScore = 0, vMaxMark = 0;
+    f.rsA.lw = lw; f.rsB.lw = lw + 8;
+    ref_stream_turn(f.rsA, wordsA, ref_len, wsA, ref0A, nCols, 0, 0, lane); ref_stream_turn(f.rsB, wordsB, ref_len, wsB, ref0B, nCols, 0, 0, lane);
+    f.wA = ref_stream_word(f.rsA, wsA, ref0A, nCols, 0, 0); f.wB = ref_stream_word(f.rsB, wsB, ref0B, nCols, 0, 0);
+    f.last = 0; f.mc_keep = 0; f.vMaxScore = 0; f.vMaxMark = 0; f.maxA = 0; f.maxB = 0; f.erA = 0; f.erB = 0;
+}
+template <int SEG>
+__device__ __forceinline__ void fwd2_column(Fwd2<SEG> &f, int i, int segLen, const IndexView &ix, const uint8_t *pac, int awA, int awB,
+                                            uint32_t ref0A, uint32_t ref0B, int refLenA, int refLenB, int nCols, uint16_t *mcA, uint16_t *mcB,
+                                            short *hmA, short *hmB, int lane)
+{
+    const uint64_t gmask = 0xFFull << (threadIdx.x & 56u);
+    const uint32_t go2 = 0x00030003u, ge2 = 0x00010001u;         // aln.h:137-138, both halves
+    const bool masksA = awA == 1, masksB = awB == 1, polishA = awA == 2, polishB = awB == 2;
+    const uint32_t wsA = masksA ? 3u : 4u, wsB = masksB ? 3u : 4u;
+    const uint32_t negb2 = (uint32_t)(-(polishA ? 2 : 3) & 0xFFFF) | (uint32_t)(-(polishB ? 2 : 3) & 0xFFFF) << 16;
     const uint32_t seg_ge = (uint32_t)segLen * 0x00010001u;
-    for (int i = 0; i < nCols; ++i) {
-        // (past the end of the shorter window its half sees whatever follows in the genome: nothing of it is kept)
-        const uint32_t profA = sw_prof_fields(masks, polish, ref_word_symbol(wA, masks, ref0A, nCols, 0, i));
-        const uint32_t profB = sw_prof_fields(masks, polish, ref_word_symbol(wB, masks, ref0B, nCols, 0, i));
-        if (i + 1 == rsA.cnext) {
-            ref_stream_turn(rsA, words, ix.ref_len, ws, ref0A, nCols, 0, i + 1, lane); ref_stream_turn(rsB, words, ix.ref_len, ws, ref0B, nCols, 0, i + 1, lane);
-        }
-        wA = ref_stream_word(rsA, ws, ref0A, nCols, 0, i + 1); wB = ref_stream_word(rsB, ws, ref0B, nCols, 0, i + 1);
-        uint32_t vF = 0, vMaxColumn = 0;
-        uint32_t vH = (uint32_t)dpp_row_shr<1>((int)last);
-        if (lane == 0) vH = 0;
+    // (past the end of the shorter window its half sees whatever follows in the genome: nothing of it is kept)
+    const uint32_t profA = sw_prof_fields(masksA, polishA, ref_word_symbol(f.wA, masksA, ref0A, nCols, 0, i));
+    const uint32_t profB = sw_prof_fields(masksB, polishB, ref_word_symbol(f.wB, masksB, ref0B, nCols, 0, i));
+    if (i + 1 == f.rsA.cnext || i + 1 == f.rsB.cnext) {           // (a block of the 2-bit genome is twice as many columns: turning it early is harmless)
+        ref_stream_turn(f.rsA, masksA ? ix.ref : reinterpret_cast<const uint32_t *>(pac), ix.ref_len, wsA, ref0A, nCols, 0, i + 1, lane);
+        ref_stream_turn(f.rsB, masksB ? ix.ref : reinterpret_cast<const uint32_t *>(pac), ix.ref_len, wsB, ref0B, nCols, 0, i + 1, lane);
+    }
+    f.wA = ref_stream_word(f.rsA, wsA, ref0A, nCols, 0, i + 1); f.wB = ref_stream_word(f.rsB, wsB, ref0B, nCols, 0, i + 1);
+    uint32_t vF = 0, vMaxColumn = 0;
+    uint32_t vH = (uint32_t)dpp_row_shr<1>((int)f.last);
+    if (lane == 0) vH = 0;
 #pragma unroll
-        for (int k = 0; k < (SEG + 2) / 3; ++k) asm volatile("" : "+v"(shp[k]));          // (as in sw_word_pass_reg)
+    for (int k = 0; k < (SEG + 2) / 3; ++k) asm volatile("" : "+v"(f.shp[k]));          // (as in sw_word_pass_reg)
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+        if (j < segLen) {
+            const uint32_t t = f.shp[j / 3] >> (10 * (j % 3));
+            const uint32_t p = __builtin_amdgcn_ubfe(profA, t, 4u) | (__builtin_amdgcn_ubfe(profB, t >> 5, 4u) << 16);
+            uint32_t h = pk_add(pk_add(vH, p), negb2);
+            uint32_t e = f.E[j];
+            h = pk_max(h, e); h = pk_max(h, vF);
+            vMaxColumn = pk_max(vMaxColumn, h);
+            vH = f.H[j];
+            f.H[j] = h;
+            h = pk_subs(h, go2);
+            e = pk_subs(e, ge2); e = pk_max(e, h); f.E[j] = e;
+            vF = pk_subs(vF, ge2); vF = pk_max(vF, h);
+        }
+    }
+    {                                                            // lazy F in closed form (see sw_word_pass_reg), both halves
+        uint32_t cf = (uint32_t)dpp_row_shr<1>((int)vF);
+        if (lane == 0) cf = 0;
+        { uint32_t t = (uint32_t)dpp_row_shr<1>((int)cf); t = lane >= 1 ? pk_subs(t, seg_ge) : 0u; cf = pk_max(cf, t); }
+        { uint32_t t = (uint32_t)dpp_row_shr<2>((int)cf); t = lane >= 2 ? pk_subs(t, 2u * seg_ge) : 0u; cf = pk_max(cf, t); }
+        { uint32_t t = (uint32_t)dpp_row_shr<4>((int)cf); t = lane >= 4 ? pk_subs(t, 4u * seg_ge) : 0u; cf = pk_max(cf, t); }
 #pragma unroll
         for (int j = 0; j < SEG; ++j) {
-            if (j < segLen) {
-                const uint32_t t = shp[j / 3] >> (10 * (j % 3));
-                const uint32_t p = __builtin_amdgcn_ubfe(profA, t, 4u) | (__builtin_amdgcn_ubfe(profB, t >> 5, 4u) << 16);
-                uint32_t h = pk_add(pk_add(vH, p), negb2);
-                uint32_t e = E[j];
-                h = pk_max(h, e); h = pk_max(h, vF);
-                vMaxColumn = pk_max(vMaxColumn, h);
-                vH = H[j];
-                H[j] = h;
-                h = pk_subs(h, go2);
-                e = pk_subs(e, ge2); e = pk_max(e, h); E[j] = e;
-                vF = pk_subs(vF, ge2); vF = pk_max(vF, h);
-            }
-        }
-        {                                                        // lazy F in closed form (see sw_word_pass_reg), both halves
-            uint32_t cf = (uint32_t)dpp_row_shr<1>((int)vF);
-            if (lane == 0) cf = 0;
-            { uint32_t t = (uint32_t)dpp_row_shr<1>((int)cf); t = lane >= 1 ? pk_subs(t, seg_ge) : 0u; cf = pk_max(cf, t); }
-            { uint32_t t = (uint32_t)dpp_row_shr<2>((int)cf); t = lane >= 2 ? pk_subs(t, 2u * seg_ge) : 0u; cf = pk_max(cf, t); }
-            { uint32_t t = (uint32_t)dpp_row_shr<4>((int)cf); t = lane >= 4 ? pk_subs(t, 4u * seg_ge) : 0u; cf = pk_max(cf, t); }
-#pragma unroll
-            for (int j = 0; j < SEG; ++j) {
-                if (j < segLen) { H[j] = pk_max(H[j], pk_subs(cf, (uint32_t)j * 0x00010001u)); last = H[j]; }
-            }
-        }
-        vMaxScore = pk_max(vMaxScore, vMaxColumn);
-        if (__ballot(vMaxMark != vMaxScore) & gmask) {
-            vMaxMark = vMaxScore;
-            const uint32_t temp = dpp_pk_max8(vMaxScore);
-            const int tA = (int)(temp & 0xFFFFu), tB = (int)(temp >> 16);
-            if (tA > maxA && i < refLenA) {
-                maxA = tA; erA = i;
-#pragma unroll
-                for (int j = 0; j < SEG; ++j) hmA[j * 8 + lane] = (short)(H[j] & 0xFFFFu);
-            }
-            if (tB > maxB && i < refLenB) {
-                maxB = tB; erB = i;
-#pragma unroll
-                for (int j = 0; j < SEG; ++j) hmB[j * 8 + lane] = (short)(H[j] >> 16);
-            }
-        }
-        const uint32_t mc = dpp_pk_max8(vMaxColumn);
-        if (lane == (i & 7)) mc_keep = mc;
-        if ((i & 7) == 7) {
-            const int t = i - 7 + lane;
-            if (t < refLenA) mcA[t] = (uint16_t)(mc_keep & 0xFFFFu);
-            if (t < refLenB) mcB[t] = (uint16_t)(mc_keep >> 16);
+            if (j < segLen) { f.H[j] = pk_max(f.H[j], pk_subs(cf, (uint32_t)j * 0x00010001u)); f.last = f.H[j]; }
         }
     }
+    f.vMaxScore = pk_max(f.vMaxScore, vMaxColumn);
+    if (__ballot(f.vMaxMark != f.vMaxScore) & gmask) {
+        f.vMaxMark = f.vMaxScore;
+        const uint32_t temp = dpp_pk_max8(f.vMaxScore);
+        const int tA = (int)(temp & 0xFFFFu), tB = (int)(temp >> 16);
+        if (tA > f.maxA && i < refLenA) {
+            f.maxA = tA; f.erA = i;
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) hmA[j * 8 + lane] = (short)(f.H[j] & 0xFFFFu);
+        }
+        if (tB > f.maxB && i < refLenB) {
+            f.maxB = tB; f.erB = i;
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) hmB[j * 8 + lane] = (short)(f.H[j] >> 16);
+        }
+    }
+    const uint32_t mc = dpp_pk_max8(vMaxColumn);
+    if (lane == (i & 7)) f.mc_keep = mc;
+    if ((i & 7) == 7) {
+        const int t = i - 7 + lane;
+        if (t < refLenA) mcA[t] = (uint16_t)(f.mc_keep & 0xFFFFu);
+        if (t < refLenB) mcB[t] = (uint16_t)(f.mc_keep >> 16);
+    }
+}
+// after the last column: the column maxima still in the lanes, and the smallest read position holding each maximum (ssw.c:504-512)
+template <int SEG>
+__device__ __forceinline__ void fwd2_end(const Fwd2<SEG> &f, int segLen, int readLen, int refLenA, int refLenB, int nCols, uint16_t *mcA, uint16_t *mcB,
+                                         const short *hmA, const short *hmB, int lane, int &endReadA, int &endReadB)
+{
     if ((nCols & 7) && lane < (nCols & 7)) {
         const int t = (nCols & ~7) + lane;
-        if (t < refLenA) mcA[t] = (uint16_t)(mc_keep & 0xFFFFu);
-        if (t < refLenB) mcB[t] = (uint16_t)(mc_keep >> 16);
+        if (t < refLenA) mcA[t] = (uint16_t)(f.mc_keep & 0xFFFFu);
+        if (t < refLenB) mcB[t] = (uint16_t)(f.mc_keep >> 16);
     }
     int erdA = readLen - 1, erdB = readLen - 1;
 #pragma unroll
     for (int j = 0; j < SEG; ++j) if (j < segLen) {
         const int t = j + lane * segLen;
-        if ((int)hmA[j * 8 + lane] == maxA && t < erdA) erdA = t;
-        if ((int)hmB[j * 8 + lane] == maxB && t < erdB) erdB = t;
+        if ((int)hmA[j * 8 + lane] == f.maxA && t < erdA) erdA = t;
+        if ((int)hmB[j * 8 + lane] == f.maxB && t < erdB) erdB = t;
     }
     for (int o = 1; o < 8; o <<= 1) {
         int t = __shfl_xor(erdA, o, 8); erdA = erdA < t ? erdA : t;
         t = __shfl_xor(erdB, o, 8); erdB = erdB < t ? erdB : t;
     }
-    maxA_out = maxA; maxB_out = maxB; endRefA = erA; endRefB = erB; endReadA = erdA; endReadB = erdB;
+    endReadA = erdA; endReadB = erdB;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -626,7 +665,7 @@ __device__ __forceinline__ int tb_walk(const uint8_t *dir, const int64_t n_dir, 
 // (best score, its end point, second best: ssw.c:771-816) and leaves the requests that need their begin point with ok = 1; k_swr runs
 // the reverse pass from the end point for those (ssw.c:817-830) and leaves them with ok = 2 for k_swtb, the banded traceback.  Two
 // kernels rather than one: each column loop then has the registers to itself (as one kernel the loops reloaded spilled registers
-// at the top of every column, a memory round trip per column), and k_swf packs two requests per group (sw_fwd2_reg).
+// at the top of every column, a memory round trip per column), and k_swf packs two requests per group (Fwd2).
 // ---------------------------------------------------------------------------------------------
 // The register variants for reads up to 152 bases are capped at 128 VGPRs (four waves per SIMD)
 #define SALT_SW_WAVES(SEG) __attribute__((amdgpu_waves_per_eu(((SEG) == 13 || (SEG) == 19) ? 4 : 1, ((SEG) == 13 || (SEG) == 19) ? 4 : 8)))
@@ -662,89 +701,151 @@ __device__ __forceinline__ void sw_fwd_row(PeSwRes *o, const PeSwReq &rq, bool f
     }
 }
 
-template <int SEG>                     // 0: stripe rows in LDS (any read length); > 0: in registers, segLen <= SEG
-__global__ void __launch_bounds__(64) SALT_SW_WAVES(SEG)
+// k_swf: pairs of neighbouring requests through the packed forward pass.  Every 8-lane group runs its own pair and pulls the next one the
+// moment its window ends, inside the wave's one column loop (the groups of a wave sit at different columns of different pairs): no group
+// waits for the longest window of its wave, and the last pairs of the queue spread over all SIMDs.  (Wave-sized pulls of 16 requests
+// left 2.9 wave-tasks per SIMD at 46 783 requests: SIMDs with four of them ran twice as long as those with two.)  The two requests of a
+// pair may differ in scoring (a singleton's plain rescue next to a SNP-aware one).  A pair that cannot take the packed path -- another
+// read length than request 0's, a window beyond the scratch -- leaves with ok = 3 for k_swf1.  The loop ends for the whole wave at once, when no group has work left (a uniform exit: see k_swr).
+#ifndef SALT_SWF_WAVES
+#define SALT_SWF_WAVES 3          // 168 registers: the pair's rows, shifts and streams without spills (at 128 the packed shifts went to scratch and back every column)
+#endif
+template <int SEG>                     // stripe rows in registers, segLen <= SEG
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((SEG == 13 || SEG == 19) ? SALT_SWF_WAVES : 1, (SEG == 13 || SEG == 19) ? SALT_SWF_WAVES : 8)))
 k_swf(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
       const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
       uint32_t *__restrict__ overflow, uint8_t *__restrict__ scratch, uint32_t maxcol_bytes, uint32_t seg, int dbg_arg)
 {
-    const int dbg = SALT_DIAG_VAL(dbg_arg);                      // diagnostics build only: 2 = phase clocks, 4 = column counts, 32 = no pass, 128 = no pairs
+    const int dbg = SALT_DIAG_VAL(dbg_arg);                      // diagnostics build only: 2 = phase clocks, 4 = column counts, 32 / 128 = everything to k_swf1
+    extern __shared__ __attribute__((aligned(16))) uint8_t sw_lds[];
+    const uint32_t grp = threadIdx.x >> 3, lane = threadIdx.x & 7u;
+    const uint32_t rd = (8u * seg + 15u) & ~15u;
+    uint8_t *readA = sw_lds + (size_t)grp * 2u * rd, *readB = readA + rd;
+    short *hmA = reinterpret_cast<short *>(sw_lds + 16u * rd) + (size_t)grp * 2u * SEG * 8, *hmB = hmA + SEG * 8;      // 2 x [SEG][8] per group, behind the reads
+    uint32_t *lw = reinterpret_cast<uint32_t *>(sw_lds + sw_lds_words_at(seg, SEG, true)) + grp * 16u;                   // 2 x 8 window words per group
+    const uint32_t n_req = pctl[0];
+    if (n_req == 0) return;
+    uint16_t *mcA = reinterpret_cast<uint16_t *>(scratch + ((size_t)blockIdx.x * 8 + grp) * 2u * maxcol_bytes);
+    uint16_t *mcB = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(mcA) + maxcol_bytes);
+    // the launch's packed shape: request 0's read length
+    const uint32_t mate0 = req[0].mate;
+    const uint32_t Lref = (uint32_t)__builtin_amdgcn_readfirstlane((int)(offs[mate0 + 1] - offs[mate0]));
+    const int segLen = (int)(Lref + 7u) / 8;
+    const bool shape_ok = Lref >= 1u && Lref <= seg * 8u && segLen <= SEG && !(dbg & (32 | 128));
+    Fwd2<SEG> f;
+    uint32_t it0 = 0, ref0A = 0, ref0B = 0;
+    int i = 0, nCols = 0, refLenA = 0, refLenB = 0, awA = 0, awB = 0;
+    unsigned long long t0 = 0;
+    bool idle = true, done = false;
+    for (;;) {
+        if (idle && !done) {                                        // the group's next pair
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(head, 2u);
+            it0 = (uint32_t)__shfl((int)t, 0, 8);
+            if (it0 >= n_req) done = true;
+            else {
+                const bool two = it0 + 1 < n_req;
+                const PeSwReq rq0 = req[it0], rq1 = req[two ? it0 + 1 : it0];
+                const uint32_t off0 = offs[rq0.mate], L0 = offs[rq0.mate + 1] - off0, off1 = offs[rq1.mate], L1 = offs[rq1.mate + 1] - off1;
+                refLenA = (int)(rq0.end - rq0.start + 1); refLenB = (int)(rq1.end - rq1.start + 1);
+                const bool fits0 = rq0.start < ix.ref_len && refLenA > 0 && (uint64_t)refLenA * 2u <= maxcol_bytes;
+                const bool fits1 = rq1.start < ix.ref_len && refLenB > 0 && (uint64_t)refLenB * 2u <= maxcol_bytes;
+                // (the odd last request runs as a pair with itself)
+                if (!(shape_ok && fits0 && fits1 && L0 == Lref && L1 == Lref)) {
+                    if (lane == 0) { res[it0].ok = 3; if (two) res[it0 + 1].ok = 3; atomicAdd(head + 4, two ? 2u : 1u); }      // forward pass pending (head[4]: how many)
+                } else {
+                    if (dbg & 2) t0 = __builtin_amdgcn_s_memtime();
+                    sw_load_read(seqs, off0, Lref, rq0.strand, readA, lane); sw_load_read(seqs, off1, Lref, rq1.strand, readB, lane);
+                    ref0A = rq0.start; ref0B = rq1.start; nCols = refLenA > refLenB ? refLenA : refLenB; i = 0; awA = rq0.aware; awB = rq1.aware;
+                    fwd2_begin<SEG>(f, segLen, (int)Lref, readA, readB, hmA, hmB, lw, ix, pac, awA, awB, ref0A, ref0B, nCols, (int)lane);
+                    idle = false;
+                }
+            }
+        }
+        if (__all(done)) break;
+        if (!idle) {
+            asm volatile("; k_swf column begin");
+            fwd2_column<SEG>(f, i, segLen, ix, pac, awA, awB, ref0A, ref0B, refLenA, refLenB, nCols, mcA, mcB, hmA, hmB, (int)lane);
+            ++i;
+            asm volatile("; k_swf column end");
+            if (i == nCols) {                                       // the pair's rows; the group is free again
+                int edA, edB;
+                fwd2_end<SEG>(f, segLen, (int)Lref, refLenA, refLenB, nCols, mcA, mcB, hmA, hmB, (int)lane, edA, edB);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const bool two = it0 + 1 < n_req;
+                const PeSwReq rq0 = req[it0], rq1 = req[two ? it0 + 1 : it0];
+                sw_fwd_row(res + it0, rq0, true, refLenA, Lref, mcA, f.maxA, f.erA, edA, lane);
+                if (two) sw_fwd_row(res + it0 + 1, rq1, true, refLenB, Lref, mcB, f.maxB, f.erB, edB, lane);
+                if (lane == 0) {
+                    if (dbg & 2) atomicAdd(overflow + 1, (uint32_t)(__builtin_amdgcn_s_memtime() - t0));       // phase clock
+                    if (dbg & 4) atomicAdd(overflow + 1, (uint32_t)nCols);
+                }
+                idle = true;
+            }
+        }
+    }
+}
+
+// k_swf1: the forward pass of the requests k_swf left pending (ok = 3), or of all of them (all = 1: reads beyond the register variants),
+// one request at a time per group
+template <int SEG>                     // 0: stripe rows in LDS (any read length); > 0: in registers, segLen <= SEG
+__global__ void __launch_bounds__(64) SALT_SW_WAVES(SEG)
+k_swf1(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
+       const PeSwReq *__restrict__ req, const uint32_t *__restrict__ pctl, PeSwRes *__restrict__ res, uint32_t *__restrict__ head,
+       uint32_t *__restrict__ overflow, uint8_t *__restrict__ scratch, uint32_t maxcol_bytes, uint32_t seg, int all, int dbg_arg)
+{
+    const int dbg = SALT_DIAG_VAL(dbg_arg);                      // diagnostics build only: 4 = column counts, 32 = no pass
     extern __shared__ __attribute__((aligned(16))) uint8_t sw_lds[];
     const uint32_t grp = threadIdx.x >> 3, lane = threadIdx.x & 7u;
     SwLds s;
-    uint8_t *read2; short *hm2;                                   // the second request's bases and H-at-best (register variants)
     if (SEG == 0) {
         uint8_t *base = sw_lds + (size_t)grp * sw_group_bytes(seg);
         s.H[0] = reinterpret_cast<short *>(base); s.H[1] = s.H[0] + seg * 8; s.E = s.H[1] + seg * 8; s.Hmax = s.E + seg * 8;
         s.read = reinterpret_cast<uint8_t *>(s.Hmax + seg * 8);
-        read2 = s.read; hm2 = s.Hmax;
     } else {
         const uint32_t rd = (8u * seg + 15u) & ~15u;
         s.H[0] = s.H[1] = s.E = nullptr;
-        s.read = sw_lds + (size_t)grp * 2u * rd; read2 = s.read + rd;
-        s.Hmax = reinterpret_cast<short *>(sw_lds + 16u * rd) + (size_t)grp * 2u * (SEG ? SEG : 1) * 8;       // 2 x [SEG][8] per group, behind the reads
-        hm2 = s.Hmax + (SEG ? SEG : 1) * 8;
+        s.read = sw_lds + (size_t)grp * rd;
+        s.Hmax = reinterpret_cast<short *>(sw_lds + 8u * rd) + (size_t)grp * (SEG ? SEG : 1) * 8;
     }
-    uint32_t *lw = reinterpret_cast<uint32_t *>(sw_lds + sw_lds_words_at(seg, SEG, true)) + grp * 16u;      // 2 x 8 window words per group
+    uint32_t *lw = reinterpret_cast<uint32_t *>(sw_lds + sw_lds_words_at(seg, SEG, false)) + grp * 8u;
     const uint32_t n_req = pctl[0];
-    uint16_t *maxColumn0 = reinterpret_cast<uint16_t *>(scratch + ((size_t)blockIdx.x * 8 + grp) * 2u * maxcol_bytes);
-    uint16_t *maxColumn1 = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(maxColumn0) + maxcol_bytes);
-    // The wave pulls sixteen requests at a time, two neighbours per group, and leaves as a whole (a uniform exit): groups that drew numbers
-    // past the end sit the round out.  (Groups pulling one request each and leaving one by one is the shape this loop had; with hipcc 7.2 the
-    // kernel then never finished once the traceback had moved out of it -- tools/dbg/sw_hang.hip reproduces that -- so the exit is kept
-    // uniform.)
-    for (;;) {
+    if (!all && head[3] == 0) return;                              // (head[3]: the requests k_swf left pending, behind the four queue heads)
+    uint16_t *maxColumn = reinterpret_cast<uint16_t *>(scratch + ((size_t)blockIdx.x * 8 + grp) * 2u * maxcol_bytes);
+    for (;;) {                                                       // eight requests per pull, a uniform exit (see k_swr)
         uint32_t base = 0;
-        if (threadIdx.x == 0) base = atomicAdd(head, 16u);
+        if (threadIdx.x == 0) base = atomicAdd(head, 8u);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= n_req) break;
-        const uint32_t it0 = base + 2u * grp;
-        if (it0 >= n_req) continue;
-        const bool two = it0 + 1 < n_req;
-        const PeSwReq rq0 = req[it0], rq1 = req[two ? it0 + 1 : it0];
-        const uint32_t off0 = offs[rq0.mate], L0 = offs[rq0.mate + 1] - off0, off1 = offs[rq1.mate], L1 = offs[rq1.mate + 1] - off1;
-        const int refLen0 = (int)(rq0.end - rq0.start + 1), refLen1 = (int)(rq1.end - rq1.start + 1);
-        const bool sane0 = rq0.start < ix.ref_len && refLen0 > 0, sane1 = two && rq1.start < ix.ref_len && refLen1 > 0;
-        const bool skip = (dbg & 32) != 0;
-        const bool fits0 = sane0 && (uint64_t)refLen0 * 2u <= maxcol_bytes && L0 <= seg * 8u && !skip;
-        const bool fits1 = sane1 && (uint64_t)refLen1 * 2u <= maxcol_bytes && L1 <= seg * 8u && !skip;
-        if (lane == 0 && !skip && ((sane0 && !fits0) || (sane1 && !fits1))) atomicAdd(overflow, (uint32_t)(sane0 && !fits0) + (uint32_t)(sane1 && !fits1));
-        const unsigned long long t0 = dbg & 2 ? __builtin_amdgcn_s_memtime() : 0ull;
-        int m0 = 0, er0 = 0, ed0 = 0, m1 = 0, er1 = 0, ed1 = 0;
-        const uint32_t uL = (uint32_t)__builtin_amdgcn_readfirstlane((int)L0), uaware = (uint32_t)__builtin_amdgcn_readfirstlane((int)rq0.aware);
-        const bool pack = SEG != 0 && !(dbg & 128) &&
-                          __all(fits0 && fits1 && L0 == uL && L1 == uL && rq0.aware == uaware && rq1.aware == uaware);      // the whole wave or none
-        if (pack) {
-            sw_load_read(seqs, off0, L0, rq0.strand, s.read, lane); sw_load_read(seqs, off1, L1, rq1.strand, read2, lane);
-            sw_fwd2_reg<(SEG ? SEG : 1)>(ix, pac, (int)rq0.aware, rq0.start, rq1.start, refLen0, refLen1, (int)L0, s.read, read2, maxColumn0, maxColumn1,
-                                         s.Hmax, hm2, lw, m0, m1, er0, er1, ed0, ed1);
-            if ((dbg & 4) && lane == 0) atomicAdd(overflow + 1, (uint32_t)(refLen0 > refLen1 ? refLen0 : refLen1));
-        } else {
-            if (fits0) {
-                sw_load_read(seqs, off0, L0, rq0.strand, s.read, lane);
-                const uint8_t *rdp = s.read;
-                auto fwd = [&](int q) -> uint32_t { return rdp[q]; };
-                if (SEG == 0) sw_word_pass(ix, pac, (int)rq0.aware, s, rq0.start, 0, refLen0, (int)L0, fwd, 0xFFFF, maxColumn0, m0, er0, ed0);
-                else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, (int)rq0.aware, rq0.start, 0, refLen0, (int)L0, fwd, 0xFFFF, maxColumn0, s.Hmax, lw, m0, er0, ed0,
-                                                       (dbg & 4) ? overflow + 1 : nullptr);
-            }
-            if (fits1) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-                sw_load_read(seqs, off1, L1, rq1.strand, read2, lane);
-                const uint8_t *rdp = read2;
-                auto fwd = [&](int q) -> uint32_t { return rdp[q]; };
-                if (SEG == 0) sw_word_pass(ix, pac, (int)rq1.aware, s, rq1.start, 0, refLen1, (int)L1, fwd, 0xFFFF, maxColumn1, m1, er1, ed1);
-                else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, (int)rq1.aware, rq1.start, 0, refLen1, (int)L1, fwd, 0xFFFF, maxColumn1, hm2, lw, m1, er1, ed1,
-                                                       (dbg & 4) ? overflow + 1 : nullptr);
-            }
+        const uint32_t it = base + grp;
+        if (it >= n_req) continue;
+        if (!all && res[it].ok != 3) continue;
+        const PeSwReq rq = req[it];
+        const uint32_t off = offs[rq.mate], L = offs[rq.mate + 1] - off;
+        const int refLen = (int)(rq.end - rq.start + 1);
+        const bool sane = rq.start < ix.ref_len && refLen > 0;
+        const bool fits = sane && (uint64_t)refLen * 2u <= maxcol_bytes && L <= seg * 8u && !(dbg & 32);
+        if (lane == 0 && sane && !fits && !(dbg & 32)) atomicAdd(overflow, 1u);
+        int m = 0, er = 0, ed = 0;
+        if (fits) {
+            sw_load_read(seqs, off, L, rq.strand, s.read, lane);
+            const uint8_t *rdp = s.read;
+            auto fwd = [&](int q) -> uint32_t { return rdp[q]; };
+            if (SEG == 0) sw_word_pass(ix, pac, (int)rq.aware, s, rq.start, 0, refLen, (int)L, fwd, 0xFFFF, maxColumn, m, er, ed);
+            else sw_word_pass_reg<(SEG ? SEG : 1)>(ix, pac, (int)rq.aware, rq.start, 0, refLen, (int)L, fwd, 0xFFFF, maxColumn, s.Hmax, lw, m, er, ed,
+                                                   (dbg & 4) ? overflow + 1 : nullptr);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-        sw_fwd_row(res + it0, rq0, fits0, refLen0, L0, maxColumn0, m0, er0, ed0, lane);
-        if (two) sw_fwd_row(res + it0 + 1, rq1, fits1, refLen1, L1, maxColumn1, m1, er1, ed1, lane);
-        if ((dbg & 2) && lane == 0) atomicAdd(overflow + 1, (uint32_t)(__builtin_amdgcn_s_memtime() - t0));       // phase clock (10 ns ticks)
+        sw_fwd_row(res + it, rq, fits, refLen, L, maxColumn, m, er, ed, lane);
     }
 }
 
+// k_swr: the reverse pass from the end point of every request k_swf / k_swf1 left with ok = 1, eight requests per wave in step.  (One
+// request per group pulled inside the column loop, as k_swf does for its pairs, took 0.77 ms against 0.58 ms here: a reverse pass is
+// ~120 columns, and every group's start -- request, row, offsets, bases: four dependent loads -- holds up its whole wave.)
+// The wave pulls eight requests at a time, one per group, and leaves as a whole (a uniform exit): groups that drew a number past the end
+// sit the round out.  (Groups pulling one request each and leaving one by one is the shape this loop first had; with hipcc 7.2 the kernel
+// then never finished once the traceback had moved out of it -- tools/dbg/sw_hang.hip reproduces that -- so the exit is kept uniform.)
 template <int SEG>
 __global__ void __launch_bounds__(64) SALT_SW_WAVES(SEG)
 k_swr(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
@@ -767,7 +868,7 @@ k_swr(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__
     }
     uint32_t *lw = reinterpret_cast<uint32_t *>(sw_lds + sw_lds_words_at(seg, SEG, false)) + grp * 8u;
     const uint32_t n_req = pctl[0];
-    for (;;) {                                                       // eight requests per pull, a uniform exit (see k_swf)
+    for (;;) {
         uint32_t base = 0;
         if (threadIdx.x == 0) base = atomicAdd(head, 8u);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -985,20 +1086,19 @@ static int sw_seg_variant(uint32_t max_len)
     const uint32_t seg = (max_len + 7) / 8;
     return lds_only ? 0 : seg <= 13 ? 13 : seg <= 19 ? 19 : seg <= 32 ? 32 : 0;
 }
-uint32_t sw_lds_bytes(uint32_t max_len, bool fwd)
+uint32_t sw_lds_bytes(uint32_t max_len, bool pairs)
 {
-    const uint32_t seg = (max_len + 7) / 8, rd = (8u * seg + 15u) & ~15u;
+    const uint32_t seg = (max_len + 7) / 8;
     const uint32_t v = (uint32_t)sw_seg_variant(max_len);
-    // register variants: per group the read + H-at-best [SEG][8] shorts of each request in flight (k_swf: a pair, k_swr: one)
-    (void)rd;
-    return sw_lds_words_at(seg, v, fwd) + 8u * (fwd ? 64u : 32u);        // + the groups' window words (RefStream)
+    // register variants: per group the read + H-at-best [SEG][8] shorts of each request in flight (k_swf: a pair, k_swf1 / k_swr: one)
+    return sw_lds_words_at(seg, v, pairs && v) + 8u * (pairs && v ? 64u : 32u);        // + the groups' window words (RefStream)
 }
 // one-wave blocks per CU: what registers (the register variants) or LDS (the LDS variant) admit
 uint32_t sw_blocks_per_cu(uint32_t max_len)
 {
     int n = 0;
     const int v = sw_seg_variant(max_len);
-    const void *f = v == 13 ? (const void *)k_swf<13> : v == 19 ? (const void *)k_swf<19> : v == 32 ? (const void *)k_swf<32> : (const void *)k_swf<0>;
+    const void *f = v == 13 ? (const void *)k_swf<13> : v == 19 ? (const void *)k_swf<19> : v == 32 ? (const void *)k_swf<32> : (const void *)k_swf1<0>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64, sw_lds_bytes(max_len, true)) != hipSuccess || n < 1) n = 1;
     return (uint32_t)(n > (int)SW_MAX_BLOCKS_PER_CU ? (int)SW_MAX_BLOCKS_PER_CU : n);
 }
@@ -1039,7 +1139,7 @@ void sw_geom_limit(SwGeom &g, uint32_t blocks) { if (blocks < 1) blocks = 1; if 
 uint64_t sw_scratch_bytes(const SwGeom &g) { return (uint64_t)g.n_blocks * 16 * g.maxcol_bytes + (uint64_t)g.tb_blocks * 8 * g.tb_group_bytes; }
 
 void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, const uint32_t *offs, const PeSwReq *req, const uint32_t *pctl,
-               PeSwRes *res, uint32_t *head, uint32_t *rev_head, uint32_t *tb_head, uint32_t *overflow, uint8_t *scratch, SwGeom g, uint32_t max_len, hipStream_t st)
+               PeSwRes *res, uint32_t *heads, uint32_t *overflow, uint8_t *scratch, SwGeom g, uint32_t max_len, hipStream_t st)
 {
     const uint32_t seg = (max_len + 7) / 8;
 #ifdef SALT_DIAG
@@ -1047,18 +1147,22 @@ void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, con
 #else
     const int dbg = 0;
 #endif
-#define SALT_LAUNCH_SW(V) do { \
-        hipLaunchKernelGGL(k_swf<V>, dim3(g.n_blocks), dim3(64), sw_lds_bytes(max_len, true), st, ix, pac, seqs, offs, req, pctl, res, head, \
-                           overflow, scratch, g.maxcol_bytes, seg, dbg); \
-        hipLaunchKernelGGL(k_swr<V>, dim3(g.n_blocks), dim3(64), sw_lds_bytes(max_len, false), st, ix, pac, seqs, offs, req, pctl, res, rev_head, \
+    // heads[0..3]: the queue heads of k_swf, k_swf1, k_swr, k_swtb; heads[4]: the requests k_swf left to k_swf1
+#define SALT_LAUNCH_SW(V, ALL) do { \
+        hipLaunchKernelGGL(k_swf1<V>, dim3(g.n_blocks), dim3(64), sw_lds_bytes(max_len, false), st, ix, pac, seqs, offs, req, pctl, res, heads + 1, \
+                           overflow, scratch, g.maxcol_bytes, seg, ALL, dbg); \
+        hipLaunchKernelGGL(k_swr<V>, dim3(g.n_blocks), dim3(64), sw_lds_bytes(max_len, false), st, ix, pac, seqs, offs, req, pctl, res, heads + 2, \
                            overflow, seg, dbg); } while (0)
+#define SALT_LAUNCH_SWF(V) hipLaunchKernelGGL(k_swf<V>, dim3(g.n_blocks), dim3(64), sw_lds_bytes(max_len, true), st, ix, pac, seqs, offs, req, pctl, res, heads, \
+                                              overflow, scratch, g.maxcol_bytes, seg, dbg)
     switch (sw_seg_variant(max_len)) {
-    case 13: SALT_LAUNCH_SW(13); break;
-    case 19: SALT_LAUNCH_SW(19); break;
-    case 32: SALT_LAUNCH_SW(32); break;
-    default: SALT_LAUNCH_SW(0); break;
+    case 13: SALT_LAUNCH_SWF(13); SALT_LAUNCH_SW(13, 0); break;
+    case 19: SALT_LAUNCH_SWF(19); SALT_LAUNCH_SW(19, 0); break;
+    case 32: SALT_LAUNCH_SWF(32); SALT_LAUNCH_SW(32, 0); break;
+    default: SALT_LAUNCH_SW(0, 1); break;
     }
 #undef SALT_LAUNCH_SW
+#undef SALT_LAUNCH_SWF
     const TbGeom tg = tb_geom(max_len);
     int tb_dbg = 0;
 #ifdef SALT_DIAG
@@ -1066,7 +1170,7 @@ void launch_sw(const IndexView &ix, const uint8_t *pac, const uint8_t *seqs, con
     if (getenv("SALT_GPU_TB_MAXBW")) tb_dbg = atoi(getenv("SALT_GPU_TB_MAXBW"));
     if (getenv("SALT_GPU_TB_CLOCKS")) tb_dbg |= 0x10000;
 #endif
-    hipLaunchKernelGGL(k_swtb, dim3(g.tb_blocks), dim3(64), 8u * tg.group_b, st, ix, pac, seqs, offs, req, pctl, res, tb_head, overflow,
+    hipLaunchKernelGGL(k_swtb, dim3(g.tb_blocks), dim3(64), 8u * tg.group_b, st, ix, pac, seqs, offs, req, pctl, res, heads + 3, overflow,
                        scratch + (uint64_t)g.n_blocks * 16 * g.maxcol_bytes, g.tb_group_bytes, tg, tb_dbg);
 }
 

@@ -61,6 +61,8 @@ for f in forks[1:]:
 same = np.array_equal(d_res.cpu().numpy().view(salt_amd.RESULT_DTYPE)[["pos", "strand", "mapq"]], res[["pos", "strand", "mapq"]])
 pc = aln.pe_counts()
 print("rescue requests %d (%.1f %% of the mates), overflowed %d" % (pc[0], 100.0 * pc[0] / (2 * n_pairs), pc[4]))
+if os.environ.get("SALT_PE_RAW"):
+    print("pe counters", [int(x) for x in pc])
 if os.environ.get("SALT_GPU_SW_SKIP_TB") in ("4", "8"):
     print("k_sw columns per request %.1f, lazy-F stripe steps per column %.1f" % (pc[5] / max(pc[0], 1), pc[6] / max(pc[5], 1)))
 elif pc[5]:
