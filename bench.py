@@ -433,7 +433,7 @@ def main():
 def pe_leg(args, cfg, idx, alns, streams, genome, site, ora, oracle_py, dev, torch, np, salt_amd, workload, log):
     """BASELINE.json configs[3]: 2 x 150-base pairs, `-p -a 250 -b 550`, insert N(400, 50), 3 % of the fragment-end mates damaged (9 %
     substitutions + a 2-base deletion: seed-and-verify misses them, the Smith-Waterman rescue runs) and 1 % random, on the index of the
-    single-end leg.  A step = salt_gpu_align_pe_resident over one resident batch: k_pack ... k_cigar on the 2n mates, k_pair, k_sw,
+    single-end leg.  A step = salt_gpu_align_pe_resident over one resident batch: k_pack ... k_cigar on the 2n mates, k_pair, k_sw (k_swf, k_swr, k_swtb),
     k_pe_final (+ k_cigar); results stay in HBM.  Same protocol as the single-end leg: distinct resident batches rotated over the
     workspaces / streams, serialized steps for per-kernel times, the timed region between synchronisations."""
     L, n_pairs, n_batches, steps = 150, args.pe_pairs, max(1, args.pe_batches), max(1, args.pe_steps)
@@ -515,7 +515,7 @@ def pe_leg(args, cfg, idx, alns, streams, genome, site, ora, oracle_py, dev, tor
         db = {}
     # a rescue reads its window once forward and (to the end point) once backward as 4-bit masks or 2-bit bases, the mate, and writes a 160-byte row
     db["k_sw"] = int(pc[0]) * (2 * (550 + L) // 2 + L + 160)
-    # the roofline block is for the dominant MEMORY-bound kernel; k_sw (+ k_swtb, timed together) is integer DP in registers: its block
+    # the roofline block is for the dominant MEMORY-bound kernel; k_sw (k_swf, k_swr, k_swtb, timed together) is integer DP in registers: its block
     # (`valu`) gives the share of the chip's vector issue slots it used, from the committed PMC passes
     cand = {k: v for k, v in skm.items() if k in db and v > 0 and k != "k_sw"}
     dom = max(cand, key=lambda k: cand[k]) if cand else None
@@ -527,11 +527,12 @@ def pe_leg(args, cfg, idx, alns, streams, genome, site, ora, oracle_py, dev, tor
         except Exception:
             prof = {}
     if skm.get("k_sw"):
-        isw, itb = prof.get("issue", {}).get("k_sw", {}), prof.get("issue", {}).get("k_swtb", {})
-        out["valu"] = {"kernel": "k_sw + k_swtb (striped Smith-Waterman passes + banded traceback of the mate rescues)", "ms": round(skm["k_sw"], 3),
-                       "requests": int(pc[0]), "bound": "valu (integer DP in registers; no HBM or MFMA roofline applies)",
-                       "valu_issue_frac_k_sw": isw.get("valu_issue_frac"), "valu_issue_frac_k_swtb": itb.get("valu_issue_frac"),
-                       "valu_wave_insts_k_sw": isw.get("valu_wave_insts"), "ms_rocprof": {"k_sw": isw.get("kernel_ms_rocprof"), "k_swtb": itb.get("kernel_ms_rocprof")},
+        iss = {k: prof.get("issue", {}).get(k, {}) for k in ("k_swf", "k_swr", "k_swtb")}
+        out["valu"] = {"kernel": "k_sw = k_swf + k_swr + k_swtb (+ k_swf1): forward pass of request pairs in packed 16-bit lanes, reverse pass, banded traceback of the mate rescues",
+                       "ms": round(skm["k_sw"], 3), "requests": int(pc[0]), "bound": "valu (integer DP in registers; no HBM or MFMA roofline applies)",
+                       "valu_issue_frac": {k: v.get("valu_issue_frac") for k, v in iss.items()},
+                       "valu_wave_insts": {k: v.get("valu_wave_insts") for k, v in iss.items()},
+                       "ms_rocprof": {k: v.get("kernel_ms_rocprof") for k, v in iss.items()},
                        "source": "profiles/r03/pmc_summary_pe_%s.json (SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x duration x 2.4 GHz))" % args.workload}
     if dom:
         ach = db[dom] / (skm[dom] / 1e3) / 1e9
@@ -605,11 +606,20 @@ def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log, n_gpus=1):
         if line.startswith("[salt] text path:") or line.startswith("[salt] host phases"):
             detail = line[7:]
     sam_bytes = os.path.getsize(sam)
-    os.unlink(sam); os.unlink(fq)
+    os.unlink(sam)
+    # the same command with the SAM stream thrown away: what the pipeline does when no file system is in the way
+    null_s = None
+    with open(os.devnull, "wb") as fo:
+        p2 = subprocess.run([salt, "-d", "-c", "-t", str(threads), "--gpus", str(n_gpus), w["prefix"], fq], stdout=fo, stderr=subprocess.PIPE, timeout=900)
+    for line in p2.stderr.decode(errors="replace").splitlines():
+        if p2.returncode == 0 and line.startswith("[alnse_core]: total"):
+            null_s = float(line.split()[2])
+    os.unlink(fq)
     return {"value": round(n / align_s / 1e6, 3) if align_s else None, "unit": "Mreads/s", "reads": n, "threads": threads, "n_gpus": n_gpus,
+            "value_devnull": round(n / null_s / 1e6, 3) if null_s else None,
             "what": "salt -d -c -t %d --gpus N <idx> reads.fq > out.sam (one process, reads dealt to the GPUs' workers in chunks, one ordered SAM stream): FASTQ text in, SAM text out (%.2f GB), PCIe and host I/O included; clock = the binary's "
                     "[alnse_core] total (restarted where the reference restarts its own, behind the index reload, alnse.c:1366; workspace set-up included; ends with the "
-                    "last SAM byte written; index load + attach excluded, as SURVEY 8d defines it)" % (threads, sam_bytes / 1e9),
+                    "last SAM byte written; index load + attach excluded, as SURVEY 8d defines it); value_devnull: the same command with stdout on /dev/null" % (threads, sam_bytes / 1e9),
             "align_wall_s": align_s, "process_wall_s": round(wall, 2), "fastq_write_s": round(t_write, 2), "pipeline": detail}
 
 
@@ -644,9 +654,18 @@ def e2e_pe_leg(args, w, genome, site, workload, torch, np, log, n_gpus=1):
         if line.startswith("[salt] text path") or line.startswith("[salt] host phases"):
             detail = line[7:]
     sam_bytes = os.path.getsize(sam)
-    for f in fq + [sam]:
+    os.unlink(sam)
+    null_s = None
+    with open(os.devnull, "wb") as fo:
+        p2 = subprocess.run([os.path.join(ROOT, "salt_amd", "bin", "salt"), "-d", "-c", "-p", "-a", "250", "-b", "550", "-t", str(threads), "--gpus", str(n_gpus), w["prefix"]] + fq,
+                            stdout=fo, stderr=subprocess.PIPE, timeout=900)
+    for line in p2.stderr.decode(errors="replace").splitlines():
+        if p2.returncode == 0 and (line.startswith("[alnpe_core]: total") or line.startswith("[alnse_core]: total")):
+            null_s = float(line.split()[2])
+    for f in fq:
         os.unlink(f)
     return {"value": round(2 * n / align_s / 1e6, 3) if align_s else None, "unit": "M mates/s", "pairs": n, "read_len": L, "threads": threads, "n_gpus": n_gpus,
+            "value_devnull": round(2 * n / null_s / 1e6, 3) if null_s else None,
             "what": "salt -d -c -p -a 250 -b 550 -t %d <idx> r1.fq r2.fq > out.sam (%.2f GB of SAM); the binary's clock as in e2e" % (threads, sam_bytes / 1e9),
             "align_wall_s": align_s, "process_wall_s": round(wall, 2), "pipeline": detail}
 

@@ -211,7 +211,7 @@ int  salt_gpu_align_se_resident(salt_gpu_ws_t *ws, const salt_aln_opt_t *opt, ui
 /* Per-kernel device time.  After salt_gpu_ws_timing(ws, 1) every resident/host align call brackets its
  * kernels with HIP events on the stream it launches on; salt_gpu_ws_kernel_ms synchronises, adds the
  * elapsed times of all calls since the last read into ms[0] k_pack, ms[1] k_seed, ms[2] k_light, ms[3] k_heavy,
- * ms[4] k_gap, ms[5] k_gapfin, ms[6] k_cigar, and for paired-end calls ms[7] k_pair, ms[8] k_sw, ms[9] k_pe_final (with the k_cigar pass
+ * ms[4] k_gap, ms[5] k_gapfin, ms[6] k_cigar, and for paired-end calls ms[7] k_pair, ms[8] k_sw (the Smith-Waterman kernels k_swf, k_swf1, k_swr, k_swtb together), ms[9] k_pe_final (with the k_cigar pass
  * behind it); returns the number of calls in *n_calls and resets.  At most 256 calls are kept. */
 #define SALT_N_KERNELS 10
 int  salt_gpu_ws_timing(salt_gpu_ws_t *ws, int enable);

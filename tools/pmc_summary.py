@@ -17,7 +17,7 @@ import sys
 from collections import defaultdict
 
 KERNELS = ("k_pack", "k_seed_walk", "k_seed", "k_light2", "k_light", "k_queue_pack", "k_heavy_pe_big", "k_heavy_pe", "k_heavy_big", "k_heavy", "k_gapfin", "k_gap", "k_cigar",
-           "k_pair", "k_swtb", "k_sw", "k_pe_final", "k_fq_count", "k_fq_lines", "k_fq_parse", "k_fq_codes", "k_sam_len", "k_sam_write", "k_heads")
+           "k_pair", "k_swtb", "k_swf1", "k_swf", "k_swr", "k_pe_final", "k_fq_count", "k_fq_lines", "k_fq_parse", "k_fq_codes", "k_sam_len", "k_sam_write", "k_heads")
 CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md: peak engine clock; issue fractions are quoted against it (a lower bound of the true fraction)
 
 
