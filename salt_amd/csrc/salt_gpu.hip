@@ -56,6 +56,7 @@ struct salt_gpu_ws {
     uint8_t *d_raw = nullptr; uint64_t raw_cap = 0; uint32_t *d_tile = nullptr; uint64_t tile_cap = 0; uint32_t *d_lines = nullptr; uint64_t lines_cap = 0;
     FqRec *d_rec = nullptr; uint32_t *d_tctl = nullptr, *d_samoff = nullptr; void *d_scan = nullptr; size_t scan_bytes = 0;
     char *d_sam = nullptr, *h_sam = nullptr; uint64_t sam_cap = 0; char *d_rg = nullptr; std::string rg;
+    char *d_samslot = nullptr; SamSeg *d_samseg = nullptr;      // [max_reads]: the records' formatted heads and tails between k_sam_len and k_sam_write
     bool h_sam_owned = true;                                                 // false: the caller's page-locked buffer (salt_gpu_ws_reserve_text)
     uint32_t text_calls = 0;                                                 // SALT_TEXT_TRACE: stage clocks of the first text call
     uint32_t heavy_blocks = 2048, gap_blocks = 2048;
@@ -337,7 +338,7 @@ extern "C" void salt_gpu_ws_destroy(salt_gpu_ws_t *ws)
     if (!ws) return;
     hipSetDevice(ws->ix->device);
     hipFree(ws->d_seqs); hipFree(ws->d_offs); hipFree(ws->d_results); hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_wq); hipFree(ws->d_wq_cnt); hipFree(ws->d_pm); hipFree(ws->d_tb); hipFree(ws->d_heads); if (ws->h_heads) hipHostFree(ws->h_heads); hipFree(ws->d_ctr); hipFree(ws->d_queue); hipFree(ws->d_qsub); hipFree(ws->d_qctl); hipFree(ws->d_lvtab); hipFree(ws->d_gap);
-    hipFree(ws->d_raw); hipFree(ws->d_tile); hipFree(ws->d_lines); hipFree(ws->d_rec); hipFree(ws->d_tctl); hipFree(ws->d_samoff); hipFree(ws->d_scan); hipFree(ws->d_sam); hipFree(ws->d_rg);
+    hipFree(ws->d_raw); hipFree(ws->d_tile); hipFree(ws->d_lines); hipFree(ws->d_rec); hipFree(ws->d_tctl); hipFree(ws->d_samoff); hipFree(ws->d_samslot); hipFree(ws->d_samseg); hipFree(ws->d_scan); hipFree(ws->d_sam); hipFree(ws->d_rg);
     if (ws->h_sam && ws->h_sam_owned) hipHostFree(ws->h_sam);
     hipFree(ws->d_pe_scr); hipFree(ws->d_pairs); hipFree(ws->d_req); hipFree(ws->d_swres); hipFree(ws->d_pctl); hipFree(ws->d_sw_scr); hipFree(ws->d_pcq);
     if (ws->stream) hipStreamDestroy(ws->stream);
@@ -575,6 +576,7 @@ extern "C" int salt_gpu_ws_reserve_text(salt_gpu_ws_t *ws, const salt_aln_opt_t 
     REGROW(ws->d_lines, ws->lines_cap, 4ull * est_reads + 8, uint32_t);
     if (!ws->d_rec) HIPCHK(hipMalloc((void **)&ws->d_rec, (uint64_t)ws->max_reads * sizeof(FqRec)));
     if (!ws->d_samoff) HIPCHK(hipMalloc((void **)&ws->d_samoff, ((uint64_t)ws->max_reads + 2) * 4));
+    if (!ws->d_samslot) { HIPCHK(hipMalloc((void **)&ws->d_samslot, (uint64_t)ws->max_reads * SAM_SLOT)); HIPCHK(hipMalloc((void **)&ws->d_samseg, (uint64_t)ws->max_reads * sizeof(SamSeg))); }
     const uint64_t items = (uint64_t)est_reads * 2u * spr;
     if (items > ws->sai_cap) {
         hipFree(ws->d_sai_c); hipFree(ws->d_sai_r); hipFree(ws->d_wq); ws->d_sai_c = ws->d_sai_r = ws->d_wq = nullptr; ws->sai_cap = 0;
@@ -674,12 +676,13 @@ extern "C" int salt_gpu_align_se_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
         ws->rg = rg;
     }
     if (!ws->d_samoff) HIPCHK(hipMalloc((void **)&ws->d_samoff, ((uint64_t)ws->max_reads + 2) * 4));
+    if (!ws->d_samslot) { HIPCHK(hipMalloc((void **)&ws->d_samslot, (uint64_t)ws->max_reads * SAM_SLOT)); HIPCHK(hipMalloc((void **)&ws->d_samseg, (uint64_t)ws->max_reads * sizeof(SamSeg))); }
     SamDev d;
     d.raw = ws->d_raw; d.rec = ws->d_rec; d.seqs = ws->d_seqs; d.offs = ws->d_offs; d.res = ws->d_results;
     d.c_off = ix->d_c_off; d.c_name_off = ix->d_c_name_off; d.c_names = ix->d_c_names; d.n_contigs = ix->n_contigs;
     d.text = ix->view.text; d.ref = ix->view.ref; d.xa_cigar = to->print_xa_cigar; d.nm_md = to->print_nm_md;
     d.rg = ws->d_rg; d.rg_len = to->rg_id ? (int32_t)rg.size() : 0;
-    d.pe = 0; d.min_tlen = d.max_tlen = 0;
+    d.pe = 0; d.min_tlen = d.max_tlen = 0; d.slot = ws->d_samslot; d.seg = ws->d_samseg; d.tb = ws->d_tb; d.pg = PackGeom::make(ctl[1]);
     if (to->rg_id && rg.empty()) return fail(SALT_E_INVAL, "empty read group id");
     HIPCHK(launch_sam_len(d, n_rec, ws->d_samoff, reinterpret_cast<unsigned long long *>(ws->d_tctl + 4), ws->d_scan, ws->scan_bytes, st));
     uint32_t total = 0; unsigned long long total64 = 0;
@@ -787,12 +790,13 @@ extern "C" int salt_gpu_align_pe_text(salt_gpu_ws_t *ws, const salt_aln_opt_t *o
         ws->rg = rg;
     }
     if (!ws->d_samoff) HIPCHK(hipMalloc((void **)&ws->d_samoff, ((uint64_t)ws->max_reads + 2) * 4));
+    if (!ws->d_samslot) { HIPCHK(hipMalloc((void **)&ws->d_samslot, (uint64_t)ws->max_reads * SAM_SLOT)); HIPCHK(hipMalloc((void **)&ws->d_samseg, (uint64_t)ws->max_reads * sizeof(SamSeg))); }
     SamDev d;
     d.raw = ws->d_raw; d.rec = ws->d_rec; d.seqs = ws->d_seqs; d.offs = ws->d_offs; d.res = ws->d_results;
     d.c_off = ix->d_c_off; d.c_name_off = ix->d_c_name_off; d.c_names = ix->d_c_names; d.n_contigs = ix->n_contigs;
     d.text = ix->view.text; d.ref = ix->view.ref; d.xa_cigar = to->print_xa_cigar; d.nm_md = to->print_nm_md;
     d.rg = ws->d_rg; d.rg_len = to->rg_id ? (int32_t)rg.size() : 0;
-    d.pe = 1; d.min_tlen = pe->min_tlen; d.max_tlen = pe->max_tlen;
+    d.pe = 1; d.min_tlen = pe->min_tlen; d.max_tlen = pe->max_tlen; d.slot = ws->d_samslot; d.seg = ws->d_samseg; d.tb = ws->d_tb; d.pg = PackGeom::make(ctl[1]);
     HIPCHK(launch_sam_len(d, n_rec, ws->d_samoff, reinterpret_cast<unsigned long long *>(ws->d_tctl + 4), ws->d_scan, ws->scan_bytes, st));
     uint32_t total = 0, n_over = 0; unsigned long long total64 = 0;
     HIPCHK(hipMemcpyAsync(&total, ws->d_samoff + n_rec, 4, hipMemcpyDeviceToHost, st));

@@ -130,12 +130,17 @@ void launch_diag_lv(const IndexView &ix, uint32_t n, const uint32_t *pos, const 
 
 // ---- FASTQ text in, SAM text out (salt_text.hip) ----
 struct FqRec { uint32_t name_off, name_len, seq_off, len, qual_off; };        // one 4-line record: offsets into the raw block
+// per record, between k_sam_len and k_sam_write: the formatted head (flag ... the tab in front of SEQ) and tail (the tags) and their lengths
+static const uint32_t SAM_HEAD_CAP = 96, SAM_TAIL_CAP = 224, SAM_SLOT = SAM_HEAD_CAP + SAM_TAIL_CAP;
+struct SamSeg { uint16_t head_len, tail_len; uint8_t what, strand, over, pad; };      // what: 0 record, 1 empty line, 2 record without tail; over: head or tail outgrew the slot
 struct SamDev {                                                               // what the SAM kernels read (by value)
     const uint8_t *raw; const FqRec *rec; const uint8_t *seqs; const uint32_t *offs; const salt_result_t *res;
     const int64_t *c_off; const uint32_t *c_name_off; const char *c_names; int32_t n_contigs;      // contigs (bntann1_t: offset, name)
     const uint32_t *text, *ref;                                                // 2-bit genome, mixRef
     int32_t xa_cigar, nm_md; const char *rg; int32_t rg_len;
     int32_t pe; uint32_t min_tlen, max_tlen;                                   // pe: records 2p, 2p + 1 are the mates of pair p (alnpe_sam)
+    char *slot; SamSeg *seg;                                                   // [n] x SAM_SLOT bytes, [n]: written by k_sam_len, read by k_sam_write
+    const uint32_t *tb; PackGeom pg;                                           // k_pack's 2-bit records of the reads (MD / NM / XV by words), or null
 };
 hipError_t text_warm();                                     // forces the load of the text kernels' code object
 size_t text_scan_bytes(uint64_t max_items);

@@ -7,7 +7,7 @@
 //   k_fq_parse                one thread per 4-line record: name (up to the first white space, a trailing /1 /2 trimmed: query.c:139-143),
 //                             sequence and quality spans (CR trimmed), checks; read lengths for the offsets scan
 //   k_fq_codes                bases -> codes A0 C1 G2 T3 other 4 (nst_nt4_table), the aligner's input layout
-//   k_sam_len / k_sam_write   one thread per read: aln_samse (sam.c:87-182) with sam_add_xa (186-240) and sam_add_md_nm (246-328):
+//   k_sam_len / k_sam_write   aln_samse (sam.c:87-182) with sam_add_xa (186-240) and sam_add_md_nm (246-328): a thread per read formats the small fields, eight lanes per read copy name / SEQ / QUAL:
 //                             the exact record length first, an exclusive scan for the offsets, then the bytes -- the batch's SAM text
 //                             comes out contiguous and in input order.
 // Strict 4-line FASTQ only (what sequencers write); salt's host path keeps reading multi-line records the way kseq does.
@@ -111,8 +111,8 @@ __global__ void __launch_bounds__(256) k_fq_codes(const uint8_t *__restrict__ ra
 
 // ---- SAM text --------------------------------------------------------------------------------------------------------------
 template <bool WRITE> struct Emit {
-    char *p; uint32_t n;
-    __device__ __forceinline__ void put(char c) { if (WRITE) p[n] = c; ++n; }
+    char *p; uint32_t n; uint32_t cap = 0xFFFFFFFFu;           // bytes past cap are counted, not written
+    __device__ __forceinline__ void put(char c) { if (WRITE && n < cap) p[n] = c; ++n; }
     __device__ __forceinline__ void puts(const char *t) { while (*t) put(*t++); }
     __device__ __forceinline__ void putn(const uint8_t *t, uint32_t k) { for (uint32_t i = 0; i < k; ++i) put((char)t[i]); }
     __device__ __forceinline__ void putu(uint64_t v)
@@ -154,35 +154,115 @@ __device__ __forceinline__ uint32_t aligned_base(const uint8_t *sq, uint32_t L, 
 
 template <bool WRITE> __device__ void sam_tags(Emit<WRITE> &o, const SamDev &d, const salt_result_t *q, const uint8_t *sq, uint32_t L, uint32_t strand, bool md);
 
+// A record is  name | head | SEQ | '\t' | QUAL | tail | newline(s).  head (flag ... the tab in front of SEQ) and tail (the tags) are small
+// and irregular: one thread formats them (sam_head / sam_tail).  name, SEQ and QUAL are most of the bytes and plain copies: the lanes of
+// a group share them (k_sam_write).  what: 0 a record, 1 an empty line (a skipped read), 2 a record without tail (unmapped, sam.c:105-125).
+struct SamShape { uint32_t what, strand; };
 template <bool WRITE>
-__device__ uint32_t sam_record(const SamDev &d, uint32_t i, char *dst)
+__device__ SamShape sam_head(Emit<WRITE> &o, const SamDev &d, uint32_t i)
 {
-    Emit<WRITE> o{ dst, 0 };
     const salt_result_t *q = d.res + i;
-    if (q->skipped) return 0;                                         // > 200 N: the reference prints an empty line (alnse.c:1328,1437)
-    const FqRec r = d.rec[i];
-    const uint8_t *name = d.raw + r.name_off, *qual = d.raw + r.qual_off, *sq = d.seqs + d.offs[i];
-    const uint32_t L = r.len;
-    const char *NT = "ACGTN";
-    if (q->pos == 0xFFFFFFFFu) {                                      // sam.c:105-125
-        o.putn(name, r.name_len); o.puts("\t4\t*\t0\t0\t*\t*\t0\t0\t");
-        for (uint32_t j = 0; j < L; ++j) o.put(NT[sq[j] > 4 ? 4 : sq[j]]);
-        o.put('\t'); o.putn(qual, L);
-        return o.n;
-    }
+    if (q->skipped) return SamShape{ 1u, 0u };                       // > 200 N: the reference prints an empty line (alnse.c:1328,1437)
+    if (q->pos == 0xFFFFFFFFu) { o.puts("\t4\t*\t0\t0\t*\t*\t0\t0\t"); return SamShape{ 2u, 0u }; }      // sam.c:105-125
     const uint32_t strand = q->strand;
     const int rid = seq_id_dev(d, q->pos);
-    o.putn(name, r.name_len); o.put('\t'); o.putu(strand ? 16 : 0); o.put('\t');
+    o.put('\t'); o.putu(strand ? 16 : 0); o.put('\t');
     o.putn(reinterpret_cast<const uint8_t *>(d.c_names) + d.c_name_off[rid], d.c_name_off[rid + 1] - d.c_name_off[rid]); o.put('\t');
     o.putu((uint64_t)((int64_t)q->pos - d.c_off[rid] + 1)); o.put('\t'); o.putu(q->mapq); o.put('\t');
     put_cigar_dev(o, q->cigar, q->n_cigar);
     o.puts("\t*\t0\t0\t");
-    for (uint32_t j = 0; j < L; ++j) { const uint32_t c = aligned_base(sq, L, strand, j); o.put(NT[c > 4 ? 4 : c]); }
+    return SamShape{ 0u, strand };
+}
+template <bool WRITE>
+__device__ void sam_tail(Emit<WRITE> &o, const SamDev &d, uint32_t i, SamShape sh)
+{
+    if (sh.what) return;
+    sam_tags<WRITE>(o, d, d.res + i, d.seqs + d.offs[i], d.rec[i].len, sh.strand, d.nm_md != 0);
+}
+// SEQ and QUAL as the record shows them: the read's bases, or their reverse complement and the reversed qualities on strand 1
+__device__ __forceinline__ char seq_char(const uint8_t *sq, uint32_t L, uint32_t strand, uint32_t j)
+{
+    const uint32_t c = aligned_base(sq, L, strand, j);
+    return (char)((0x4E54474341ull >> (8u * (c > 4 ? 4u : c))) & 0xFFu);      // "ACGTN"
+}
+__device__ __forceinline__ char qual_char(const uint8_t *qual, uint32_t L, uint32_t strand, uint32_t j) { return (char)qual[strand ? L - 1 - j : j]; }
+
+template <bool WRITE> __device__ SamShape sam_head_pe(Emit<WRITE> &o, const SamDev &d, uint32_t i);
+template <bool WRITE> __device__ void sam_tail_pe(Emit<WRITE> &o, const SamDev &d, uint32_t i, SamShape sh);
+
+// the whole record by one thread (records whose head or tail outgrow their slot)
+template <bool WRITE>
+__device__ uint32_t sam_record(const SamDev &d, uint32_t i, char *dst)
+{
+    Emit<WRITE> o{ dst, 0 };
+    const FqRec r = d.rec[i];
+    const uint8_t *name = d.raw + r.name_off, *qual = d.raw + r.qual_off, *sq = d.seqs + d.offs[i];
+    Emit<false> probe{ nullptr, 0 };                                 // (what kind of record: a skipped read has no name either)
+    const SamShape sh = d.pe ? sam_head_pe<false>(probe, d, i) : sam_head<false>(probe, d, i);
+    if (sh.what == 1) return 0;
+    o.putn(name, r.name_len);
+    if (d.pe) (void)sam_head_pe<WRITE>(o, d, i); else (void)sam_head<WRITE>(o, d, i);
+    for (uint32_t j = 0; j < r.len; ++j) o.put(seq_char(sq, r.len, sh.strand, j));
     o.put('\t');
-    if (strand) for (uint32_t j = L; j > 0; --j) o.put((char)qual[j - 1]);
-    else o.putn(qual, L);
-    sam_tags<WRITE>(o, d, q, sq, L, strand, d.nm_md != 0);
+    for (uint32_t j = 0; j < r.len; ++j) o.put(qual_char(qual, r.len, sh.strand, j));
+    if (d.pe) sam_tail_pe<WRITE>(o, d, i, sh); else sam_tail<WRITE>(o, d, i, sh);
     return o.n;
+}
+
+// sixteen bases from base b0 on of a 2-bit array (16 per word, the first in the top bits); nv: how many of them exist
+__device__ __forceinline__ uint32_t tb_window(const uint32_t *w, uint32_t b0, uint32_t nv)
+{
+    const uint32_t wi = b0 >> 4, s2 = 2u * (b0 & 15u);
+    uint32_t x = w[wi] << s2;
+    if (s2 && nv > 16u - (b0 & 15u)) x |= w[wi + 1] >> (32u - s2);
+    return x;
+}
+// false: not this way (a read with N: the packed words carry N as 0)
+template <bool WRITE>
+__device__ bool sam_md_words(Emit<WRITE> &o, const SamDev &d, const salt_result_t *q, uint32_t i, uint32_t strand)
+{
+    const uint32_t *rec = d.tb + (uint64_t)i * d.pg.tb_stride;
+    const uint32_t *rw = rec + (strand ? d.pg.nw16 : 0u), *nw = rec + 2u * d.pg.nw16 + (strand ? d.pg.nw32 : 0u);
+    uint32_t any_n = 0;
+    for (uint32_t k = 0; k < d.pg.nw32; ++k) any_n |= nw[k];
+    if (any_n) return false;
+    const uint32_t n = q->cigar[0] >> 4, rp0 = q->pos, si0 = (uint32_t)q->seq_start;
+    const char *NT = "ACGTN";
+    int nm = 0, n_rs = 0, prev = -1;
+    o.puts("\tMD:Z:");
+    for (uint32_t c = 0; c < n; c += 16) {
+        const uint32_t nv = n - c < 16u ? n - c : 16u;
+        const uint32_t R = tb_window(rw, si0 + c, nv), G = tb_window(d.text, rp0 + c, nv);
+        uint32_t m = ((R ^ G) | ((R ^ G) >> 1)) & 0x55555555u;              // base j of the window: bit 30 - 2j
+        if (nv < 16u) m &= ~((1u << (32u - 2u * nv)) - 1u);
+        while (m) {
+            const uint32_t j = ((uint32_t)__clz((int)m) - 1u) >> 1, sh = 30u - 2u * j;
+            const int k = (int)(c + j);
+            if (k - prev - 1 > 0) o.putu((uint64_t)(k - prev - 1));
+            o.put(NT[(G >> sh) & 3u]);
+            if ((mask_at_dev(d.ref, rp0 + (uint32_t)k) & (1u << ((R >> sh) & 3u))) != 0 && n_rs < 64) ++n_rs;
+            prev = k; ++nm;
+            m &= ~(1u << sh);
+        }
+    }
+    if ((int)n - prev - 1 > 0) o.putu((uint64_t)((int)n - prev - 1));
+    o.puts("\tNM:i:"); o.putu((uint64_t)nm);
+    if (n_rs > 0) {                                                   // the offsets of the mismatches that are listed alleles
+        o.puts("\tXV:i:");
+        int seen = 0;
+        for (uint32_t c = 0; c < n && seen < n_rs; c += 16) {
+            const uint32_t nv = n - c < 16u ? n - c : 16u;
+            const uint32_t R = tb_window(rw, si0 + c, nv), G = tb_window(d.text, rp0 + c, nv);
+            uint32_t m = ((R ^ G) | ((R ^ G) >> 1)) & 0x55555555u;
+            if (nv < 16u) m &= ~((1u << (32u - 2u * nv)) - 1u);
+            while (m && seen < n_rs) {
+                const uint32_t j = ((uint32_t)__clz((int)m) - 1u) >> 1, sh = 30u - 2u * j;
+                if ((mask_at_dev(d.ref, rp0 + c + j) & (1u << ((R >> sh) & 3u))) != 0) { if (seen) o.put(','); o.putu((uint64_t)(c + j)); ++seen; }
+                m &= ~(1u << sh);
+            }
+        }
+    }
+    return true;
 }
 
 // XA and MD / NM / XV of one record, shared by both record kinds (sam_add_xa sam.c:186-240, sam_add_md_nm sam.c:246-328)
@@ -208,7 +288,11 @@ __device__ void sam_tags(Emit<WRITE> &o, const SamDev &d, const salt_result_t *q
                 o.putu(hit.n_diff); o.put(';');
             }
     }
-    if (md) {
+    // MD / NM / XV of an alignment without gaps (one M operation: nearly every record) from the packed 2-bit words of the read (k_pack's
+    // tb record of the aligned strand) and of the genome, sixteen bases per XOR: every load is issued before any is needed.  (The walk
+    // below takes a base of each per step and decides on it before the next load: ~100 dependent round trips per record.)
+    if (md && d.tb && q->n_cigar == 1 && (q->cigar[0] & 15) == 0 && sam_md_words<WRITE>(o, d, q, (uint32_t)(q - d.res), strand)) { }
+    else if (md) {
         int nm = 0, n_match = 0, n_rs = 0;
         uint32_t rp = q->pos; int si = q->seq_start;
         o.puts("\tMD:Z:");
@@ -252,17 +336,13 @@ __device__ void sam_tags(Emit<WRITE> &o, const SamDev &d, const salt_result_t *q
     if (d.rg_len) { o.puts("\tRG:Z:"); o.putn(reinterpret_cast<const uint8_t *>(d.rg), (uint32_t)d.rg_len); }
 }
 
-// one record of a pair (alnpe_sam, sam.c:331-457): record i = mate i & 1 of pair i >> 1; the caller adds the reference's two newlines
+// one record of a pair (alnpe_sam, sam.c:331-457): record i = mate i & 1 of pair i >> 1; the writer adds the reference's two newlines
 template <bool WRITE>
-__device__ uint32_t sam_record_pe(const SamDev &d, uint32_t i, char *dst)
+__device__ SamShape sam_head_pe(Emit<WRITE> &o, const SamDev &d, uint32_t i)
 {
-    Emit<WRITE> o{ dst, 0 };
     const uint32_t me = i, ot = i ^ 1u, m0 = i & ~1u;
     const salt_result_t *q = d.res + me, *qo = d.res + ot, *q0 = d.res + m0, *q1 = q0 + 1;
-    const FqRec r = d.rec[me];
-    const uint8_t *name = d.raw + r.name_off, *qual = d.raw + r.qual_off, *sq = d.seqs + d.offs[me];
-    const uint32_t L = r.len;
-    const char *NT = "ACGTN";
+    const uint32_t L = d.rec[me].len;
     const bool map_me = q->pos != 0xFFFFFFFFu, map_ot = qo->pos != 0xFFFFFFFFu;
     int rid_me = -1, rid_ot = -1; uint32_t pos_me = 0, pos_ot = 0;
     if (map_me) { rid_me = seq_id_dev(d, q->pos); pos_me = q->pos - (uint32_t)d.c_off[rid_me] + 1; }
@@ -282,7 +362,7 @@ __device__ uint32_t sam_record_pe(const SamDev &d, uint32_t i, char *dst)
     if (qo->strand == 1) flag |= 0x20;
     if (tlen != 0) flag |= 0x2;
     flag |= (i & 1u) ? 0x80 : 0x40;
-    o.putn(name, r.name_len); o.put('\t'); o.putu(flag); o.put('\t');
+    o.put('\t'); o.putu(flag); o.put('\t');
     auto contig = [&](int rid) { o.putn(reinterpret_cast<const uint8_t *>(d.c_names) + d.c_name_off[rid], d.c_name_off[rid + 1] - d.c_name_off[rid]); };
     if (map_me) {
         contig(rid_me); o.put('\t'); o.putu(pos_me); o.put('\t'); o.putu(q->mapq); o.put('\t');
@@ -298,44 +378,68 @@ __device__ uint32_t sam_record_pe(const SamDev &d, uint32_t i, char *dst)
     } else o.puts("*\t0\t");
     if (tlen != 0) { if (q->pos >= qo->pos) o.put('-'); o.putu((uint64_t)tlen); o.put('\t'); }
     else o.puts("0\t");
-    const uint32_t strand = q->strand == 1 ? 1u : 0u;
-    for (uint32_t j = 0; j < L; ++j) { const uint32_t c = aligned_base(sq, L, strand, j); o.put(NT[c > 4 ? 4 : c]); }
-    o.put('\t');
-    if (strand) for (uint32_t j = L; j > 0; --j) o.put((char)qual[j - 1]);
-    else o.putn(qual, L);
-    sam_tags<WRITE>(o, d, q, sq, L, strand, d.nm_md && map_me);
-    return o.n;
+    return SamShape{ 0u, q->strand == 1 ? 1u : 0u };
+}
+template <bool WRITE>
+__device__ void sam_tail_pe(Emit<WRITE> &o, const SamDev &d, uint32_t i, SamShape sh)
+{
+    const salt_result_t *q = d.res + i;
+    sam_tags<WRITE>(o, d, q, d.seqs + d.offs[i], d.rec[i].len, sh.strand, d.nm_md && q->pos != 0xFFFFFFFFu);
 }
 
+// k_sam_len: one thread per record formats the record's head and tail ONCE, into the record's slot (SAM_HEAD_CAP + SAM_TAIL_CAP bytes), and
+// leaves their lengths: the record's length is then arithmetic (name + head + 2 L + 1 + tail + newlines) and k_sam_write copies.
 // total64: the block's byte count in 64 bits next to the 32-bit offsets of the scan (a block whose SAM text passes 4 GiB is refused)
 __global__ void __launch_bounds__(256) k_sam_len(SamDev d, uint32_t n, uint32_t *__restrict__ len, unsigned long long *__restrict__ total64)
 {
     unsigned long long mine = 0;
-    if (d.pe) { TSTRIDE(i, n) { const uint32_t l = sam_record_pe<false>(d, (uint32_t)i, nullptr) + 2u; len[i] = l; mine += l; } }   // + the record's newline and the driver's (alnpe.c:640-648)
-    else { TSTRIDE(i, n) { const uint32_t l = sam_record<false>(d, (uint32_t)i, nullptr) + 1u; len[i] = l; mine += l; } }          // + the newline
+    TSTRIDE(i, n) {
+        char *slot = d.slot + (uint64_t)i * SAM_SLOT;
+        Emit<true> h{ slot, 0, SAM_HEAD_CAP }, t{ slot + SAM_HEAD_CAP, 0, SAM_TAIL_CAP };
+        SamShape sh;
+        if (d.pe) { sh = sam_head_pe<true>(h, d, (uint32_t)i); sam_tail_pe<true>(t, d, (uint32_t)i, sh); }
+        else { sh = sam_head<true>(h, d, (uint32_t)i); sam_tail<true>(t, d, (uint32_t)i, sh); }
+        const FqRec r = d.rec[i];
+        SamSeg g; g.head_len = (uint16_t)(h.n < 0xFFFFu ? h.n : 0xFFFFu); g.tail_len = (uint16_t)(t.n < 0xFFFFu ? t.n : 0xFFFFu);
+        g.what = (uint8_t)sh.what; g.strand = (uint8_t)sh.strand; g.over = (uint8_t)(h.n > SAM_HEAD_CAP || t.n > SAM_TAIL_CAP); g.pad = 0;
+        d.seg[i] = g;
+        const uint32_t l = (sh.what == 1 ? 0u : r.name_len + h.n + 2u * r.len + 1u + t.n) + (d.pe ? 2u : 1u);      // + the newline (PE: and the driver's, alnpe.c:640-648)
+        len[i] = l; mine += l;
+    }
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
     if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(total64, mine);
 }
-// One wave per 64 consecutive records.  A thread that formats its record straight into the output writes single bytes at its own
-// address: 64 different cache lines per store instruction.  The records of a wave are contiguous in the output (off[] is a scan), so
-// the threads format into an LDS image of that span and the wave then copies the span out with whole-line stores (PE, per 10^6
-// mates: 13 ms -> see DESIGN 4.3).  A span that does not fit the image (very long reads) is written the direct way.
-static constexpr uint32_t SAM_STAGE = 48u << 10;
-__global__ void __launch_bounds__(64) k_sam_write(SamDev d, uint32_t n, const uint32_t *__restrict__ off, char *__restrict__ out)
+// k_sam_write: eight lanes per record copy its pieces to the record's place in the block (off[] is the scan of the lengths): the name out of
+// the FASTQ text, the head out of the slot, SEQ from the aligner's codes (reverse complement on strand 1), QUAL from the FASTQ text
+// (reversed on strand 1), the tail out of the slot, the newline(s).  Every load is independent of every other: no lane walks a record byte
+// by byte behind its own loads, which is what a record per thread did (1.4 ms per 154 000 records, three waves per CU beside the 48 KB
+// LDS image the threads formatted into).  A record whose head or tail outgrew the slot is formatted by one lane, the old way.
+__global__ void __launch_bounds__(256) k_sam_write(SamDev d, uint32_t n, const uint32_t *__restrict__ off, char *__restrict__ out)
 {
-    __shared__ char stage[SAM_STAGE];
-    for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n; base += (uint64_t)gridDim.x * 64) {
-        const uint32_t i = (uint32_t)base + threadIdx.x, last = (uint32_t)(base + 64 < n ? base + 64 : n);
-        const uint32_t o0 = off[base], span = off[last] - o0;
-        const bool staged = span <= SAM_STAGE;
-        if (i < n) {
-            char *dst = staged ? stage + (off[i] - o0) : out + off[i];
-            if (d.pe) { const uint32_t w = sam_record_pe<true>(d, i, dst); dst[w] = '\n'; dst[w + 1] = '\n'; }
-            else { const uint32_t w = sam_record<true>(d, i, dst); dst[w] = '\n'; }
+    const uint32_t s = threadIdx.x & 7u;
+    const uint64_t grp = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3, n_grp = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+    for (uint64_t i = grp; i < n; i += n_grp) {
+        const SamSeg g = d.seg[i];
+        char *dst = out + off[i];
+        const uint32_t nl = d.pe ? 2u : 1u;
+        if (g.what == 1) { if (s < nl) dst[s] = '\n'; continue; }
+        if (g.over) {
+            if (s == 0) { const uint32_t w = sam_record<true>(d, (uint32_t)i, dst); dst[w] = '\n'; if (d.pe) dst[w + 1] = '\n'; }
+            continue;
         }
-        __syncthreads();
-        if (staged) for (uint32_t k = threadIdx.x; k < span; k += 64) out[o0 + k] = stage[k];
-        __syncthreads();
+        const FqRec r = d.rec[i];
+        const uint8_t *name = d.raw + r.name_off, *qual = d.raw + r.qual_off, *sq = d.seqs + d.offs[i];
+        const char *slot = d.slot + i * SAM_SLOT;
+        const uint32_t L = r.len, strand = g.strand;
+        for (uint32_t j = s; j < r.name_len; j += 8) dst[j] = (char)name[j];
+        dst += r.name_len;
+        for (uint32_t j = s; j < g.head_len; j += 8) dst[j] = slot[j];
+        dst += g.head_len;
+        for (uint32_t j = s; j < L; j += 8) { dst[j] = seq_char(sq, L, strand, j); dst[L + 1 + j] = qual_char(qual, L, strand, j); }
+        if (s == 0) dst[L] = '\t';
+        dst += 2u * L + 1u;
+        for (uint32_t j = s; j < g.tail_len; j += 8) dst[j] = slot[SAM_HEAD_CAP + j];
+        if (s < nl) dst[g.tail_len + s] = '\n';
     }
 }
 
@@ -415,8 +519,7 @@ hipError_t launch_sam_len(const SamDev &d, uint32_t n, uint32_t *off, unsigned l
 }
 hipError_t launch_sam_write(const SamDev &d, uint32_t n, const uint32_t *off, char *out, hipStream_t st)
 {
-    const uint64_t waves = ((uint64_t)n + 63) / 64;
-    hipLaunchKernelGGL(k_sam_write, dim3((uint32_t)(waves < 8192 ? waves : 8192)), dim3(64), 0, st, d, n, off, out);
+    hipLaunchKernelGGL(k_sam_write, dim3(tgrid((uint64_t)n * 8)), dim3(256), 0, st, d, n, off, out);
     return hipGetLastError();
 }
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end experiments with the `salt` binary on the GRCh38-scale workload (GPU box): builds the index once, writes one FASTQ file,
 then runs `salt -d -c` for every settings string given on the command line ("ENV=VAL,ENV=VAL"; "" = defaults).
-A setting IN=bgzf / IN=gz runs on a blocked-gzip / plain-gzip copy of the FASTQ (written once, 32 processes).
+A setting IN=bgzf / IN=gz runs on a blocked-gzip / plain-gzip copy of the FASTQ (written once, 32 processes); OUT=null sends the SAM to
+/dev/null; PROF=<dir> runs under rocprofv3 --kernel-trace --stats.
 usage: tools/e2e_text.py <n_reads> [settings ...]"""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -76,8 +77,13 @@ for s in settings:
             made[kind] = 1
             print("   (%s written in %.1f s, %.2f GB)" % (src, time.time() - tz, os.path.getsize(src) / 1e9))
     t0 = time.time()
+    cmd = [salt, "-d", "-c", "-t", env.pop("T", "64"), w["prefix"], src]
+    prof = env.pop("PROF", "")                                  # PROF=<dir>: the run under rocprofv3 --kernel-trace --stats, summary CSV into <dir>
+    if prof:
+        env["TMPDIR"] = "/tmp"
+        cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.abspath(prof), "-o", "kt", "--"] + cmd
     with open("/dev/null" if to_null else sam, "wb") as fo:
-        r = subprocess.run([salt, "-d", "-c", "-t", env.pop("T", "64"), w["prefix"], src], stdout=fo, stderr=subprocess.PIPE, env=env)
+        r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env, cwd="/tmp" if prof else None)
     tail = [l for l in r.stderr.decode().splitlines() if l.startswith("[salt") or l.startswith("[alnse_core]: total")]
     print("== %s  (rc %d, process %.1f s)" % (s or "defaults", r.returncode, time.time() - t0))
     for l in tail:
