@@ -712,6 +712,34 @@ def test_cli_text_path_and_host_pipeline_give_the_reference_sam(case, lambda_cli
     assert strip(open(f, "rb").read()) == want
 
 
+def test_cli_text_path_records_that_outgrow_their_slot(tmp_path):
+    """k_sam_len formats a record's head (flag ... CIGAR) and tail (the tags) into a fixed slot (96 + 224 bytes) that k_sam_write copies; a
+    record that outgrows it is written whole by one lane.  A contig name of 120 characters overflows the head of every record mapped
+    there and the XA list of every read with hits there: the text path must still print what the host pipeline prints (SE and PE)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    salt, salt_idx = os.path.join(root, "salt_amd", "bin", "salt"), os.path.join(root, "salt_amd", "bin", "salt-idx")
+    fa = open(os.path.join(LAMBDA, "genome.fa"), "rb").read().split(b"\n")
+    names = [l[1:].split()[0] for l in fa if l.startswith(b">")]
+    # (the SNP file's chromosome names are cut at 31 characters, hapmap.c: the first contig keeps its name and its SNPs, the second gets the
+    # long name and none)
+    long_of = {n: (n if k == 0 else n + b"_" + b"x" * (119 - len(n))) for k, n in enumerate(names)}
+    (tmp_path / "g.fa").write_bytes(b"\n".join((b">" + long_of[l[1:].split()[0]]) if l.startswith(b">") else l for l in fa))
+    snps = open(os.path.join(LAMBDA, "snps.txt"), "rb").read().split(b"\n")
+    (tmp_path / "s.txt").write_bytes(b"\n".join(l for l in snps if l.split(b"\t")[0] == names[0]) + b"\n")
+    prefix = str(tmp_path / "idx")
+    subprocess.run([salt_idx, "-k", "19", str(tmp_path / "g.fa"), str(tmp_path / "s.txt"), prefix], check=True, stderr=subprocess.DEVNULL)
+    strip = lambda out: b"".join(l for l in out.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    for args in (["-d", "-c", prefix, os.path.join(LAMBDA, "reads_se.fq")],
+                 ["-d", "-c", "-p", "-a", "350", "-b", "650", prefix, os.path.join(LAMBDA, "reads_pe_1.fq"), os.path.join(LAMBDA, "reads_pe_2.fq")]):
+        a = subprocess.run([salt] + args, capture_output=True, env=dict(os.environ, SALT_CHUNK_BYTES="50000"))
+        b = subprocess.run([salt] + args, capture_output=True, env=dict(os.environ, SALT_HOST_PIPELINE="1"))
+        assert a.returncode == 0 and b.returncode == 0, (a.stderr[-300:], b.stderr[-300:])
+        assert b"text path" in a.stderr and b"text path" not in b.stderr
+        assert strip(a.stdout) == strip(b.stdout)
+        body = [l for l in a.stdout.split(b"\n") if l and not l.startswith(b"@")]
+        assert sum(1 for l in body if len(l.split(b"\t")[2]) == 120) > 100         # heads beyond the slot were there to be written
+
+
 def test_cli_text_path_reads_crlf_and_a_last_record_without_newline(lambda_cli_index, tmp_path):
     """CRLF line ends and a file that ends without a newline, through the text path (chunked) and the host pipeline alike."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -231,6 +231,40 @@ def test_gpu_pe_long_mates_match_oracle(tiny_pe, L, window):
     assert pc[0] > 50 and pc[4] == 0, pc                # rescues ran, none overflowed
 
 
+def test_gpu_pe_mixed_mate_lengths_match_oracle(tiny_pe):
+    """Mates trimmed to 90 ... 150 bases in one batch.  k_swf packs two rescue requests per 8-lane group when both have the launch's read
+    length (request 0's) and hands every other pair to k_swf1; the reverse pass and the traceback see every stripe count.  Every field
+    against the oracle."""
+    import sys
+    import salt_amd
+    from salt_amd import workload
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_py
+    w, _, _ = tiny_pe
+    L = 150
+    seqs, offs, _, _ = workload.make_pairs(w["genome"], w["snp_pos"], w["snp_mask"], 1500, L, seed=77, insert_mean=400, insert_sd=40, damaged=0.25, orphan=0.02)
+    rng = np.random.default_rng(5)
+    keep = np.where(rng.random(2 * 1500) < 0.5, L, rng.integers(90, L, 2 * 1500)).astype(np.uint32)
+    keep[0] = L                                                      # request 0 sets the packed shape: most pairs keep it
+    pieces = [seqs[offs[i]:offs[i] + keep[i]] for i in range(2 * 1500)]
+    seqs2 = np.concatenate(pieces); offs2 = np.concatenate([[0], np.cumsum(keep)]).astype(np.uint32)
+    idx = salt_amd.Index.reload(w["prefix"])
+    opt, _ = salt_amd.AlnOpt.from_argv(["-p", "-a", "250", "-b", "550"], idx.l_seed)
+    aln = salt_amd.GpuAligner(idx, device=0, max_reads=len(offs2) - 1, max_bases=int(offs2[-1]) + 64)
+    res = aln.alnpe_core1(opt, idx, seqs2, offs2)
+    pc = aln.pe_counts()
+    aln.close()
+    ora = oracle_py.Oracle(w["prefix"])
+    oo = ora.opt(l_overlap=opt.l_overlap, max_seed=opt.max_seed, max_locate=opt.max_locate, seed_only_ref=opt.seed_only_ref)
+    want = ora.align_pe(oo, seqs2, offs2, opt.min_tlen, opt.max_tlen, n_threads=16)
+    ora.close()
+    idx.destroy()
+    bad = oracle_py.compare(res, want, pe=True)
+    detail = [(int(i), [(f, res[f][i].tolist(), want[f][i].tolist()) for f in ("pos", "strand", "n_diff", "is_gap", "mapq", "b0", "b1", "seq_start", "seq_end")]) for i in bad[:4]]
+    assert len(bad) == 0, (len(bad), detail)
+    assert pc[0] > 300 and pc[4] == 0, pc                # rescues ran, none overflowed
+
+
 def test_cli_pe_infers_the_insert_window_like_the_oracle(tmp_path):
     """`salt -p -b 0`: the window is inferred from the first batch (N3; the reference prints "not implemented" there).  The product CLI and
     the oracle CLI must announce the same window and print the same SAM."""
