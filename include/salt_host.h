@@ -74,6 +74,8 @@ typedef struct {
     const char *(*last_error)(void);
 } salt_idx_backend_t;
 #define SALT_IDX_NO_LP 1            /* flags: do not write <prefix>.lp (the local patterns as text; `salt` never reads it) */
+#define SALT_IDX_ALL_FILES 2        /* also write what the reference indexer writes and `salt` never reads: <prefix>.R.pac, .R.rpac, .R.ann, .R.amb,
+                                       .R.forward.bwt / .occ / .sa (Index_src/index1.c:150-176): the directory then equals the reference's file for file */
 int salt_idx_build(const char *fn_fa, const char *fn_snp, const char *prefix, int l_seed);
 int salt_idx_build_ex(const char *fn_fa, const char *fn_snp, const char *prefix, int l_seed, const salt_idx_backend_t *backend, int flags);
 /* The same from memory (what bench.py and the tests use for generated genomes): contigs as base letters (as a FASTA would hold

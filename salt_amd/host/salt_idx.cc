@@ -19,7 +19,11 @@
 // genomes indexable; handed in through salt_idx_backend_t) and SA-IS on the host (written from the published algorithm;
 // 32-bit or 64-bit indices by text length) for machines without a GPU.  Everything around the sort -- packing, local
 // patterns, Occ tables, mixRef -- runs on host threads.
-// Not written: .R.forward.*, .R.pac/.rpac/.ann/.amb -- `salt` never reads them (rbwt.c:495-498).
+// `salt` never reads .R.forward.*, .R.pac/.rpac/.ann/.amb (rbwt.c:495-498); SALT_IDX_ALL_FILES (salt-idx --all-files) writes them too, so
+// that the directory equals the reference indexer's file for file:
+//   .R.pac/.R.rpac/.R.ann/.R.amb       R_bns_fasta2bntseq                 4bit_bntseq.c:170-295
+//   .R.forward.bwt/.occ                Rbwt_bwt_bwtgen on .R.rpac         index1.c:162-167
+//   .R.forward.sa                      Rbwt_gen_sa(direction=+1)          rbwt.c:424-475
 #include "../../include/salt_host.h"
 #include <zlib.h>
 #include <cstdio>
@@ -524,6 +528,104 @@ const char *cpu_last_error(void) { return "host suffix sorter failed"; }
 
 const salt_idx_backend_t CPU_BACKEND = { 0, cpu_build_c, cpu_build_r, cpu_last_error };
 
+// explicit Occ of a 4-bit BWT code: 16-bit values every 256 symbols relative to 32-bit values every 65536 (4bit_bwt_gen.c:1409-1459).
+// Padding nibbles (zero) count as 'A' exactly as in the stored code.
+void r_occ_tables(const std::vector<uint32_t> &code, uint64_t n, std::vector<uint32_t> &occ, std::vector<uint32_t> &major)
+{
+    const uint64_t n_val = (n + 255) / 256 + 1;
+    const uint64_t occ_words = (n_val + 1) / 2 * 5, major_words = (n_val + 255) / 256 * 5;
+    occ.assign((size_t)occ_words, 0); major.assign((size_t)major_words, 0);
+    const uint64_t n_blk = n_val - 1;                   // 256-symbol blocks of the stored code
+    std::vector<uint32_t> bc((size_t)(n_blk + 1) * 5, 0);      // running counts in front of every block
+    const int T = n_threads();
+    std::vector<std::vector<uint32_t>> part((size_t)T, std::vector<uint32_t>(5, 0));
+    std::vector<std::pair<uint64_t, uint64_t>> rng((size_t)T, { 0, 0 });
+    parallel_for(n_blk, 256, [&](uint64_t lo, uint64_t hi, int t) {
+        uint32_t run[5] = { 0, 0, 0, 0, 0 };
+        rng[(size_t)t] = { lo, hi };
+        for (uint64_t b = lo; b < hi; ++b) {
+            memcpy(&bc[(size_t)b * 5], run, sizeof run);        // relative to the thread's start; rebased below
+            for (uint32_t q = 0; q < 32; ++q) {
+                uint32_t wv = code[(size_t)(b * 32 + q)];
+                for (int k = 0; k < 8; ++k) { const uint32_t s = (wv >> (28 - 4 * k)) & 15u; if (s < 5) ++run[s]; }
+            }
+        }
+        memcpy(part[(size_t)t].data(), run, sizeof run);
+    });
+    uint32_t base[5] = { 0, 0, 0, 0, 0 };
+    std::vector<std::vector<uint32_t>> start((size_t)T, std::vector<uint32_t>(5, 0));
+    for (int t = 0; t < T; ++t) { if (rng[(size_t)t].second <= rng[(size_t)t].first) continue; memcpy(start[(size_t)t].data(), base, sizeof base); for (int c = 0; c < 5; ++c) base[c] += part[(size_t)t][(size_t)c]; }
+    memcpy(&bc[(size_t)n_blk * 5], base, sizeof base);
+    parallel_for(n_blk, 256, [&](uint64_t lo, uint64_t hi, int) {
+        int t = 0; while (t < T && !(rng[(size_t)t].first <= lo && lo < rng[(size_t)t].second)) ++t;
+        for (uint64_t b = lo; b < hi; ++b) {
+            while (!(rng[(size_t)t].first <= b && b < rng[(size_t)t].second)) ++t;
+            for (int c = 0; c < 5; ++c) bc[(size_t)b * 5 + (size_t)c] += start[(size_t)t][(size_t)c];
+        }
+    });
+    parallel_for(n_val, 512, [&](uint64_t lo, uint64_t hi, int) {
+        for (uint64_t e = lo; e < hi; ++e) {
+            const uint32_t *run = &bc[(size_t)e * 5], *mb = &bc[(size_t)(e / 256 * 256) * 5];
+            if (e % 256 == 0) for (int c = 0; c < 5; ++c) major[(size_t)(e / 256) * 5 + (size_t)c] = run[c];
+            for (int c = 0; c < 5; ++c) {
+                const uint32_t v = run[c] - mb[c];
+                uint32_t &o = occ[(size_t)(e / 2) * 5 + (size_t)c];
+                // two values per word, the even one in the high half; a thread owns whole words (ranges are multiples of 512)
+                if (e % 2 == 0) o |= v << 16; else o |= v & 0xFFFFu;
+                // the last word always gets both halves (4bit_bwt_gen.c:1146-1163): with an odd number of values its low half repeats the high one
+                if (e + 1 == n_val && e % 2 == 0) o |= v & 0xFFFFu;
+            }
+        }
+    });
+}
+
+// .R.ann / .R.amb from the local-pattern text as R_bns_fasta2bntseq reads it with kseq (4bit_bntseq.c:170-217, R_bns_dump :57-84): one
+// "sequence" per record, name up to the first blank, the rest of the header line as comment; holes = runs of the SAME non-ACGT# letter
+// inside a record
+bool r_ann_amb(const std::vector<char> &lp, uint64_t l_pac, std::string &ann, std::string &amb)
+{
+    struct Hole { uint64_t off; uint32_t len; char c; };
+    std::vector<Hole> holes;
+    std::string body; char num[96];
+    uint64_t offset = 0; uint32_t n_seqs = 0;
+    size_t i = 0; const size_t N = lp.size();
+    auto is_base = [](char ch) { return ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'a' || ch == 'c' || ch == 'g' || ch == 't' || ch == '#'; };
+    while (i < N) {
+        if (lp[i] != '>') { ++i; continue; }
+        size_t e = i + 1; while (e < N && lp[e] != '\n') ++e;
+        size_t ne = i + 1; while (ne < e && lp[ne] != ' ' && lp[ne] != '\t') ++ne;
+        const std::string name(&lp[i + 1], ne - (i + 1));
+        const std::string anno = ne < e ? std::string(&lp[ne + 1], e - (ne + 1)) : std::string("(null)");
+        i = e < N ? e + 1 : N;
+        uint32_t len = 0, n_ambs = 0; char lasts = 0;
+        while (i < N && lp[i] != '>') {                         // the record's lines (a '>' only opens a record at a line's start)
+            size_t le = i; while (le < N && lp[le] != '\n') ++le;
+            for (size_t k = i; k < le; ++k) {
+                const char ch = lp[k];
+                if (ch == '\r' || ch == ' ' || ch == '\t') continue;      // kseq keeps graphic characters only
+                if (!is_base(ch)) {
+                    if (lasts == ch && !holes.empty()) ++holes.back().len;
+                    else { holes.push_back(Hole{ offset + len, 1, ch }); ++n_ambs; }
+                }
+                lasts = ch; ++len;
+            }
+            i = le < N ? le + 1 : N;
+        }
+        snprintf(num, sizeof num, "%d ", 0); body += num; body += name;
+        if (!anno.empty()) { body += ' '; body += anno; }
+        body += '\n';
+        snprintf(num, sizeof num, "%lld %d %d\n", (long long)offset, (int)len, (int)n_ambs); body += num;
+        offset += len; ++n_seqs;
+    }
+    if (offset != l_pac) { g_ierr = "internal: local-pattern text and R text differ in length"; return false; }
+    snprintf(num, sizeof num, "%lld %d %u\n", (long long)l_pac, (int)n_seqs, 11u);
+    ann = std::string(num) + body;
+    snprintf(num, sizeof num, "%lld %d %u\n", (long long)l_pac, (int)n_seqs, (unsigned)holes.size());
+    amb = num;
+    for (const Hole &h : holes) { snprintf(num, sizeof num, "%lld %d %c\n", (long long)h.off, (int)h.len, h.c); amb += num; }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // the build proper
 // ---------------------------------------------------------------------------------------------
@@ -615,10 +717,10 @@ int build_core(const std::vector<ContigView> &fa, std::vector<Group> &groups, co
     // ---------------- local patterns (.lp) and the R text ----------------
     t0 = now_s();
     LocalPatterns lpat;
-    const bool want_lp = !(flags & SALT_IDX_NO_LP);
-    if (!local_patterns(fa, groups, l_seed, want_lp, lpat)) return -1;
+    const bool want_lp = !(flags & SALT_IDX_NO_LP), need_lp = want_lp || (flags & SALT_IDX_ALL_FILES);      // (.R.ann / .R.amb are read off the text)
+    if (!local_patterns(fa, groups, l_seed, need_lp, lpat)) return -1;
     if (want_lp) ok = ok && write_file(prefix + ".lp", lpat.lp.data(), lpat.lp.size());
-    { std::vector<char>().swap(lpat.lp); }
+    if (!(flags & SALT_IDX_ALL_FILES)) { std::vector<char>().swap(lpat.lp); }
     if (verbose()) fprintf(stderr, "[salt-idx] local patterns: %.2f s (%zu symbols, %zu segments)\n", now_s() - t0, lpat.rtext.size(), lpat.sharp_off.size());
     // ---------------- R part: BWT / Occ / SA ----------------
     {
@@ -647,60 +749,65 @@ int build_core(const std::vector<ContigView> &fa, std::vector<Group> &groups, co
         if (n_sharp > 1) rsa[(size_t)n_sharp] = lpat.sharp_hdr[1] - 1;
         const uint32_t h8[8] = { (uint32_t)n, inv_sa0, cum[1], cum[2], cum[3], cum[4], cum[5], (uint32_t)words };
         ok = ok && write_file2(prefix + ".R.backward.bwt", h8, sizeof h8, code.data(), code.size() * 4);
-        // explicit Occ: 16-bit values every 256 symbols relative to 32-bit values every 65536 (4bit_bwt_gen.c:1409-1459).  Padding
-        // nibbles (zero) count as 'A' exactly as in the stored code.
-        const uint64_t n_val = (n + 255) / 256 + 1;
-        const uint64_t occ_words = (n_val + 1) / 2 * 5, major_words = (n_val + 255) / 256 * 5;
-        std::vector<uint32_t> occ((size_t)occ_words, 0), major((size_t)major_words, 0);
-        {
-            const uint64_t n_blk = n_val - 1;                   // 256-symbol blocks of the stored code
-            std::vector<uint32_t> bc((size_t)(n_blk + 1) * 5, 0);      // running counts in front of every block
-            const int T = n_threads();
-            std::vector<std::vector<uint32_t>> part((size_t)T, std::vector<uint32_t>(5, 0));
-            std::vector<std::pair<uint64_t, uint64_t>> rng((size_t)T, { 0, 0 });
-            parallel_for(n_blk, 256, [&](uint64_t lo, uint64_t hi, int t) {
-                uint32_t run[5] = { 0, 0, 0, 0, 0 };
-                rng[(size_t)t] = { lo, hi };
-                for (uint64_t b = lo; b < hi; ++b) {
-                    memcpy(&bc[(size_t)b * 5], run, sizeof run);        // relative to the thread's start; rebased below
-                    for (uint32_t q = 0; q < 32; ++q) {
-                        uint32_t wv = code[(size_t)(b * 32 + q)];
-                        for (int k = 0; k < 8; ++k) { const uint32_t s = (wv >> (28 - 4 * k)) & 15u; if (s < 5) ++run[s]; }
-                    }
-                }
-                memcpy(part[(size_t)t].data(), run, sizeof run);
-            });
-            uint32_t base[5] = { 0, 0, 0, 0, 0 };
-            std::vector<std::vector<uint32_t>> start((size_t)T, std::vector<uint32_t>(5, 0));
-            for (int t = 0; t < T; ++t) { if (rng[(size_t)t].second <= rng[(size_t)t].first) continue; memcpy(start[(size_t)t].data(), base, sizeof base); for (int c = 0; c < 5; ++c) base[c] += part[(size_t)t][(size_t)c]; }
-            memcpy(&bc[(size_t)n_blk * 5], base, sizeof base);
-            parallel_for(n_blk, 256, [&](uint64_t lo, uint64_t hi, int) {
-                int t = 0; while (t < T && !(rng[(size_t)t].first <= lo && lo < rng[(size_t)t].second)) ++t;
-                for (uint64_t b = lo; b < hi; ++b) {
-                    while (!(rng[(size_t)t].first <= b && b < rng[(size_t)t].second)) ++t;
-                    for (int c = 0; c < 5; ++c) bc[(size_t)b * 5 + (size_t)c] += start[(size_t)t][(size_t)c];
-                }
-            });
-            parallel_for(n_val, 512, [&](uint64_t lo, uint64_t hi, int) {
-                for (uint64_t e = lo; e < hi; ++e) {
-                    const uint32_t *run = &bc[(size_t)e * 5], *mb = &bc[(size_t)(e / 256 * 256) * 5];
-                    if (e % 256 == 0) for (int c = 0; c < 5; ++c) major[(size_t)(e / 256) * 5 + (size_t)c] = run[c];
-                    for (int c = 0; c < 5; ++c) {
-                        const uint32_t v = run[c] - mb[c];
-                        uint32_t &o = occ[(size_t)(e / 2) * 5 + (size_t)c];
-                        // two values per word, the even one in the high half; a thread owns whole words (ranges are multiples of 512)
-                        if (e % 2 == 0) o |= v << 16; else o |= v & 0xFFFFu;
-                        // the last word always gets both halves (4bit_bwt_gen.c:1146-1163): with an odd number of values its low half repeats the high one
-                        if (e + 1 == n_val && e % 2 == 0) o |= v & 0xFFFFu;
-                    }
-                }
-            });
-        }
-        const uint32_t ow = (uint32_t)occ_words, mw = (uint32_t)major_words;
+        std::vector<uint32_t> occ, major;
+        r_occ_tables(code, n, occ, major);
+        const uint32_t ow = (uint32_t)occ.size(), mw = (uint32_t)major.size();
         ok = ok && write_file2(prefix + ".R.backward.occ", &ow, 4, occ.data(), occ.size() * 4, &mw, 4, major.data(), major.size() * 4);
         const uint32_t n_rows = (uint32_t)(n_sharp + 1);
         ok = ok && write_file2(prefix + ".R.backward.sa", &n_rows, 4, rsa.data(), rsa.size() * 4);
         if (verbose()) fprintf(stderr, "[salt-idx] R index (suffix array, BWT, Occ, '#' rows) + files: %.2f s\n", now_s() - t0);
+        if (flags & SALT_IDX_ALL_FILES) {
+            t0 = now_s();
+            // .R.pac / .R.rpac: the R text and its reverse, two 4-bit symbols per byte, the first in the high nibble; the tail bytes of
+            // bntseq's pac files (4bit_bntseq.c:262-287)
+            std::vector<uint8_t> rev((size_t)n);
+            parallel_for(n, 1 << 16, [&](uint64_t lo, uint64_t hi, int) { for (uint64_t i = lo; i < hi; ++i) rev[(size_t)i] = rtext[(size_t)(n - 1 - i)]; });
+            for (int which = 0; which < 2; ++which) {
+                const uint8_t *t = which ? rev.data() : rtext;
+                std::vector<uint8_t> pac((size_t)(n / 2 + (n & 1)) + 2, 0);
+                parallel_for((n + 1) / 2, 1 << 15, [&](uint64_t lo, uint64_t hi, int) {
+                    for (uint64_t b = lo; b < hi; ++b) pac[(size_t)b] = (uint8_t)((t[(size_t)(2 * b)] << 4) | (2 * b + 1 < n ? t[(size_t)(2 * b + 1)] : 0));
+                });
+                size_t len = (size_t)(n / 2 + (n & 1));
+                if (n % 2 == 0) pac[len++] = 0;
+                pac[len++] = (uint8_t)(n % 2);
+                ok = ok && write_file(prefix + (which ? ".R.rpac" : ".R.pac"), pac.data(), len);
+            }
+            std::string ann, amb;
+            if (!r_ann_amb(lpat.lp, n, ann, amb)) return -1;
+            ok = ok && write_file(prefix + ".R.ann", ann.data(), ann.size()) && write_file(prefix + ".R.amb", amb.data(), amb.size());
+            // the forward index = the same construction on the reversed text.  Its '#' table (Rbwt_gen_sa, direction +1) gives the k-th '#'
+            // of the R text, in text order, the header value of its own record.  The backend reports rows through the backward rule
+            // (row of the j-th '#' <- hdr[j + 2] - (distance to the next '#'), last '#' not written), so it is handed headers that make
+            // that value j + 1, and the rows are read back from there.
+            std::vector<uint32_t> off2((size_t)n_sharp), hdr2((size_t)n_sharp, 0), fcode((size_t)words, 0), fidx((size_t)n_sharp + 1, 0), fsa((size_t)n_sharp + 1, 0);
+            for (uint64_t j = 0; j < n_sharp; ++j) off2[(size_t)j] = (uint32_t)(n - 1 - lpat.sharp_off[(size_t)(n_sharp - 1 - j)]);
+            for (uint64_t j = 0; j + 2 < n_sharp; ++j) hdr2[(size_t)j + 2] = (uint32_t)(j + 1) + (off2[(size_t)j + 1] - off2[(size_t)j]);
+            uint32_t finv = 0;
+            if (be->build_r(be->device, rev.data(), n, off2.data(), hdr2.data(), n_sharp, cum[4], &finv, fcode.data(), words, fidx.data()) != 0) {
+                g_ierr = std::string("R forward index: ") + be->last_error(); return -1;
+            }
+            const uint32_t tail = n_sharp > 1 ? 0u - (off2[(size_t)n_sharp - 1] - off2[(size_t)n_sharp - 2]) : 0u;      // what the rule leaves for j = n_sharp - 2
+            bool seen_last = false;
+            for (uint64_t r = 0; r < n_sharp; ++r) {
+                const uint32_t v = fidx[(size_t)r];
+                uint64_t j;
+                if (n_sharp > 1 && v == tail) j = n_sharp - 2;
+                else if (v == 0) { if (seen_last) { g_ierr = "internal: forward '#' rows"; return -1; } seen_last = true; j = n_sharp - 1; }
+                else j = (uint64_t)v - 1;
+                if (j >= n_sharp) { g_ierr = "internal: forward '#' rows"; return -1; }
+                fsa[(size_t)r] = lpat.sharp_hdr[(size_t)(n_sharp - 1 - j)];
+            }
+            const uint32_t fh8[8] = { (uint32_t)n, finv, cum[1], cum[2], cum[3], cum[4], cum[5], (uint32_t)words };
+            ok = ok && write_file2(prefix + ".R.forward.bwt", fh8, sizeof fh8, fcode.data(), fcode.size() * 4);
+            std::vector<uint32_t> focc, fmajor;
+            r_occ_tables(fcode, n, focc, fmajor);
+            const uint32_t fow = (uint32_t)focc.size(), fmw = (uint32_t)fmajor.size();
+            ok = ok && write_file2(prefix + ".R.forward.occ", &fow, 4, focc.data(), focc.size() * 4, &fmw, 4, fmajor.data(), fmajor.size() * 4);
+            ok = ok && write_file2(prefix + ".R.forward.sa", &n_rows, 4, fsa.data(), fsa.size() * 4);
+            if (verbose()) fprintf(stderr, "[salt-idx] R text files and forward index: %.2f s\n", now_s() - t0);
+        }
+        { std::vector<char>().swap(lpat.lp); }
     }
     // ---------------- mixRef (.ref) ----------------
     {

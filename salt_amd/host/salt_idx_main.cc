@@ -13,18 +13,19 @@
 
 static int usage()
 {
-    fprintf(stderr, "Usage: salt-idx [-k seed_length(25)] [--gpu[=device]] [--no-lp] <ref.fa> <snp file> <index prefix>\n");
+    fprintf(stderr, "Usage: salt-idx [-k seed_length(25)] [--gpu[=device]] [--no-lp] [--all-files] <ref.fa> <snp file> <index prefix>\n");
     return 1;
 }
 
 int main(int argc, char **argv)
 {
     int k = 25, c, gpu = -1, flags = 0;
-    static const struct option lo[] = { { "gpu", 2, 0, 1000 }, { "no-lp", 0, 0, 1001 }, { "help", 0, 0, 'h' }, { 0, 0, 0, 0 } };
+    static const struct option lo[] = { { "gpu", 2, 0, 1000 }, { "no-lp", 0, 0, 1001 }, { "all-files", 0, 0, 1002 }, { "help", 0, 0, 'h' }, { 0, 0, 0, 0 } };
     while ((c = getopt_long(argc, argv, "k:h", lo, nullptr)) >= 0) {
         if (c == 'k') k = atoi(optarg);
         else if (c == 1000) gpu = optarg ? atoi(optarg) : 0;
         else if (c == 1001) flags |= SALT_IDX_NO_LP;
+        else if (c == 1002) flags |= SALT_IDX_ALL_FILES;          // the files the reference indexer writes and `salt` never reads, too
         else return usage();
     }
     if (argc - optind != 3) return usage();

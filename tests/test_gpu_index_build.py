@@ -72,6 +72,20 @@ def test_device_builder_writes_the_reference_files(case, tmp_path):
     _same_index_files(prefix, d)
 
 
+@pytest.mark.parametrize("case", ["lambda", "dense"])
+def test_device_builder_all_files(case, tmp_path):
+    """`salt-idx --gpu --all-files`: the R text files and the forward R index (the device suffix sorter on the reversed text), by the
+    digests of the real reference indexer's files."""
+    d = LAMBDA if case == "lambda" else os.path.join(GOLDEN, "index_cases", case)
+    prefix = str(tmp_path / "idx")
+    p = subprocess.run([os.path.join(ROOT, "salt_amd", "bin", "salt-idx"), "--gpu", "--all-files", "-k", "19", os.path.join(d, "genome.fa"),
+                        os.path.join(d, "snps.txt"), prefix], capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-500:]
+    _same_index_files(prefix, d)
+    for sfx, sha in (l.split() for l in open(os.path.join(d, "idx.unread.sha256"))):
+        assert hashlib.sha256(open(prefix + sfx, "rb").read()).hexdigest() == sha, sfx
+
+
 def test_device_and_host_builders_agree_on_a_repeat_rich_genome(tmp_path):
     """2 Mbp with a 300-base repeat family, a tandem block and 9 500 SNPs, from memory (salt_idx_build_mem): every file of the device
     build equals the host build's."""

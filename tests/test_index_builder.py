@@ -67,6 +67,32 @@ def test_builder_on_stress_cases(case, tmp_path):
     assert hashlib.sha256(open(prefix + ".C.lkt", "rb").read()).hexdigest() == open(os.path.join(d, "idx.C.lkt.sha256")).read().strip()
 
 
+UNREAD_DIRS = [LAMBDA] + [os.path.join(GOLDEN, "index_cases", c) for c in INDEX_CASES]
+
+
+@pytest.mark.parametrize("d", UNREAD_DIRS, ids=[os.path.basename(x) for x in UNREAD_DIRS])
+def test_builder_all_files_equal_the_reference_indexers(d, tmp_path):
+    """SALT_IDX_ALL_FILES (salt-idx --all-files): the files the reference indexer writes and `salt` never reads -- the R text as 4-bit
+    pac and reversed pac, its .ann / .amb, and the FORWARD R index (BWT, Occ, '#' table of the reversed text) -- byte for byte, by the
+    digests of the real reference indexer's files (tests/golden/make_unread_file_digests.py); the files `salt` reads are unchanged by it."""
+    import salt_amd
+    lib = salt_amd.host_lib()
+    lib.salt_idx_build_ex.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    lib.salt_idx_build.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+    lib.salt_idx_last_error.restype = ctypes.c_char_p
+    prefix, plain = str(tmp_path / "idx"), str(tmp_path / "plain")
+    fa, snp = os.path.join(d, "genome.fa").encode(), os.path.join(d, "snps.txt").encode()
+    assert lib.salt_idx_build_ex(fa, snp, prefix.encode(), 19, None, 2) == 0, lib.salt_idx_last_error()
+    assert lib.salt_idx_build(fa, snp, plain.encode(), 19) == 0, lib.salt_idx_last_error()
+    want = dict(l.split() for l in open(os.path.join(d, "idx.unread.sha256")))
+    assert len(want) == 7
+    for sfx, sha in want.items():
+        assert hashlib.sha256(open(prefix + sfx, "rb").read()).hexdigest() == sha, sfx
+        assert not os.path.exists(plain + sfx)
+    for sfx in (".R.seedLen", ".C.pac", ".C.bwt", ".C.sa", ".lp", ".R.backward.bwt", ".R.backward.occ", ".R.backward.sa", ".ref"):
+        assert open(prefix + sfx, "rb").read() == open(plain + sfx, "rb").read(), sfx
+
+
 def test_host_loader_and_abi_symbols():
     """The C-ABI libraries load without a GPU and export every symbol include/*.h declares."""
     import re
