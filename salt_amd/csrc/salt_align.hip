@@ -2148,13 +2148,13 @@ k_light(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_light2: k_light with TWO reads per wave (32 lanes each) for short reads with few seed slots (L <= 120, spr <= 8:
-// the 100-bp single-end case).  k_light is bound by instruction issue and by the dispatch of one workgroup per read; with
+// k_light2: k_light with TWO reads per wave (32 lanes each) for reads with few seed slots (spr <= 8; L <= 120 with four lanes per
+// located row: the 100-bp single-end case; L <= 248 with eight: 150-base reads and mates).  k_light is bound by instruction issue and by the dispatch of one workgroup per read; with
 // two reads per wave both halve.  Same steps, same results; every ballot / shuffle stays inside the read's half-wave.
 // ---------------------------------------------------------------------------------------------
 static constexpr int L2_SLOTS = 8;       // seed slots per list
 struct LightLds2 {
-    uint32_t pm[2][16];
+    uint32_t pm[2][32];                  // (reads up to 120 bases use 15 words per strand, up to 248 bases 31)
     uint32_t sp[4][L2_SLOTS], off[4][L2_SLOTS];
     uint32_t pre[4][L2_SLOTS + 1];
     uint32_t loci[2][LT_LOCI];
@@ -2238,7 +2238,9 @@ __device__ __forceinline__ void rule_sparse_h(const uint32_t *pos, const uint8_t
 // L2_WAVES waves per workgroup; each wave still works alone on its two reads (no block-level synchronisation).  Two waves per
 // workgroup halve the number of workgroups the dispatcher has to place (5 x 10^5 -> 2.5 x 10^5 per batch): the kernel alone takes
 // the same 0.48 ms, but with other batches' kernels on the GPU the step rate rises ~6 %; four are slower again.
-template <int L2_WAVES>
+// LN: lanes per located row in the window check: 4 cover reads up to 120 bases, 8 up to 248 (150-base mates and reads; the seed slots
+// bound the length before that: spr <= 8)
+template <int L2_WAVES, int LN = 4>
 __global__ void __launch_bounds__(64 * L2_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
          const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r, salt_result_t *__restrict__ results,
@@ -2254,16 +2256,16 @@ k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
     if (r >= ap.n_reads) return;
     const uint32_t *rec = pm + (uint64_t)r * ap.pg.pm_stride;
     const uint32_t L = rec[2 * ap.pg.nw8];
-    bool heavy = L > 120u || L < (uint32_t)ap.l_seed || ap.spr > (uint32_t)L2_SLOTS || ap.max_locate < 2 * 64;
+    bool heavy = L > (LN == 8 ? 248u : 120u) || L < (uint32_t)ap.l_seed || ap.spr > (uint32_t)L2_SLOTS || ap.max_locate < 2 * 64;
     if (!heavy) {
         // ---- round trip 1: the read (one-hot nibble words, both strands) and its seeds ----
-        const uint32_t nw = (L + 7) >> 3;                                   // <= 15
+        const uint32_t nw = (L + 7) >> 3;                                   // <= 15 (LN = 4) / <= 31 (LN = 8)
         uint32_t n_amb = 0;
-        if (hl < 2 * nw) {
-            const uint32_t s = hl >= nw, j = s ? hl - nw : hl;
+        for (uint32_t x = hl; x < 2 * nw; x += 32) {                        // (one trip for reads up to 128 bases)
+            const uint32_t s = x >= nw, j = s ? x - nw : x;
             const uint32_t word = rec[s * ap.pg.nw8 + j];
             w.pm[s][j] = word;
-            if (!s) n_amb = (uint32_t)__popc(word & (word >> 1) & (word >> 2) & (word >> 3) & 0x11111111u);
+            if (!s) n_amb += (uint32_t)__popc(word & (word >> 1) & (word >> 2) & (word >> 3) & 0x11111111u);
         }
         if (ap.max_amb < L) {
             for (int o = 16; o > 0; o >>= 1) n_amb += (uint32_t)__shfl_xor((int)n_amb, o);
@@ -2335,31 +2337,33 @@ k_light2(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm,
                 }
             }
             WSYNC();
-            // ---- round trip 3: masked Hamming distance of every located row of both strands, 4 lanes per row ----
+            // ---- round trip 3: masked Hamming distance of every located row of both strands, LN lanes per row ----
             {
-                const uint32_t sub = hl & 3u, q = hl >> 2, n = n_s[0] + n_s[1];
+                constexpr uint32_t RPG = 32u / LN;                           // rows of one group of loads per half-wave
+                const uint32_t sub = hl & (uint32_t)(LN - 1), q = hl / (uint32_t)LN, n = n_s[0] + n_s[1];
                 const uint32_t nvalid = L > 32u * sub ? (L - 32u * sub < 32u ? L - 32u * sub : 32u) : 0u;
                 uint32_t pa[4], pb[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { const bool in = (4 * sub + t) < nw; pa[t] = in ? w.pm[0][4 * sub + t] : 0u; pb[t] = in ? w.pm[1][4 * sub + t] : 0u; }
-                for (uint32_t b = 0; b < n; b += 32) {                      // 4 groups of 8 rows per trip
+                for (uint32_t b = 0; b < n; b += 4u * RPG) {                // 4 groups of RPG rows per trip
                     uint32_t pos[4]; u32x4_a4 x[4]; bool act[4], rev[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        if (b + 8u * g >= n) break;
-                        const uint32_t c = b + 8u * g + q;
+                        if (b + RPG * g >= n) break;
+                        const uint32_t c = b + RPG * g + q;
                         act[g] = c < n; rev[g] = c >= n_s[0];
                         pos[g] = act[g] ? (rev[g] ? w.loci[1][c - n_s[0]] : w.loci[0][c]) : 0u;
                         if (pos[g] >= ix.ref_len) pos[g] = 0xFFFFFFFFu;      // wrapped below 0 (see mismatch_capped): no load, INF
-                        x[g] = *reinterpret_cast<const u32x4_a4 *>(ix.ref + ((pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) + 4 * sub);
+                        if (LN == 8 && !(4u * sub < nw + 1u)) x[g] = u32x4_a4{ 0u, 0u, 0u, 0u };       // this lane's words lie behind the window: never fetched
+                        else x[g] = *reinterpret_cast<const u32x4_a4 *>(ix.ref + ((pos[g] == 0xFFFFFFFFu ? 0u : pos[g]) >> 3) + 4 * sub);
                     }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        if (b + 8u * g >= n) break;
+                        if (b + RPG * g >= n) break;
                         const uint32_t pw[4] = { rev[g] ? pb[0] : pa[0], rev[g] ? pb[1] : pa[1], rev[g] ? pb[2] : pa[2], rev[g] ? pb[3] : pa[3] };
-                        const uint32_t mism = quad_mismatch(x[g], pos[g], pw, nvalid);
+                        const uint32_t mism = quad_mismatch<LN>(x[g], pos[g], pw, nvalid);
                         if (act[g] && sub == 0) {
-                            const uint32_t c = b + 8u * g + q;
+                            const uint32_t c = b + RPG * g + q;
                             const uint8_t v = (uint8_t)((mism > 3 || pos[g] == 0xFFFFFFFFu) ? INF : mism);
                             if (rev[g]) w.val[1][c - n_s[0]] = v; else w.val[0][c] = v;
                         }
@@ -2496,9 +2500,10 @@ void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm
     if (!ap.n_reads) return;
     hipMemsetAsync(qsub, 0, (size_t)QSEG * QSEG_STRIDE * 4, st);
     static const bool no_half = getenv("SALT_GPU_NO_LIGHT2") && atoi(getenv("SALT_GPU_NO_LIGHT2"));
-    if (!no_half && !ctr && !SALT_DIAG_VAL(ap.dbg_stop) && ap.spr <= (uint32_t)L2_SLOTS && ap.pg.nw8 <= 15) {          // reads of at most 120 bases: two per wave
+    if (!no_half && !ctr && !SALT_DIAG_VAL(ap.dbg_stop) && ap.spr <= (uint32_t)L2_SLOTS && ap.pg.nw8 <= 31) {          // reads of at most 120 / 248 bases with at most 8 seed slots: two per wave
         static const int wv = getenv("SALT_GPU_L2_WAVES") ? atoi(getenv("SALT_GPU_L2_WAVES")) : 2;
-        if (wv == 1) hipLaunchKernelGGL(k_light2<1>, dim3((ap.n_reads + 1) / 2), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, qseg, qsub);
+        if (ap.pg.nw8 > 15) hipLaunchKernelGGL((k_light2<2, 8>), dim3((ap.n_reads + 3) / 4), dim3(128), 0, st, ix, ap, pm, sai_c, sai_r, results, qseg, qsub);
+        else if (wv == 1) hipLaunchKernelGGL(k_light2<1>, dim3((ap.n_reads + 1) / 2), dim3(64), 0, st, ix, ap, pm, sai_c, sai_r, results, qseg, qsub);
         else hipLaunchKernelGGL(k_light2<2>, dim3((ap.n_reads + 3) / 4), dim3(128), 0, st, ix, ap, pm, sai_c, sai_r, results, qseg, qsub);
     } else
         hipLaunchKernelGGL(k_light, dim3((ap.n_reads + LT_WAVES - 1) / LT_WAVES), dim3(64 * LT_WAVES), 0, st, ix, ap, pm, sai_c, sai_r, results, qseg, qsub, ctr);
