@@ -594,7 +594,7 @@ def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log, n_gpus=1):
     sam = os.path.join(d, "e2e.sam")
     t0 = time.time()
     with open(sam, "wb") as fo:
-        p = subprocess.run([salt, "-d", "-c", "-t", str(threads), "--gpus", str(n_gpus), w["prefix"], fq], stdout=fo, stderr=subprocess.PIPE, timeout=900)
+        p = subprocess.run([salt, "-d", "-c", "-t", str(threads), "--gpus", str(n_gpus), w["prefix"], fq], stdout=fo, stderr=subprocess.PIPE, timeout=300)
     wall = time.time() - t0
     err = p.stderr.decode(errors="replace")
     if p.returncode != 0:
@@ -610,7 +610,7 @@ def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log, n_gpus=1):
     # the same command with the SAM stream thrown away: what the pipeline does when no file system is in the way
     null_s = None
     with open(os.devnull, "wb") as fo:
-        p2 = subprocess.run([salt, "-d", "-c", "-t", str(threads), "--gpus", str(n_gpus), w["prefix"], fq], stdout=fo, stderr=subprocess.PIPE, timeout=900)
+        p2 = subprocess.run([salt, "-d", "-c", "-t", str(threads), "--gpus", str(n_gpus), w["prefix"], fq], stdout=fo, stderr=subprocess.PIPE, timeout=300)
     for line in p2.stderr.decode(errors="replace").splitlines():
         if p2.returncode == 0 and line.startswith("[alnse_core]: total"):
             null_s = float(line.split()[2])
@@ -642,7 +642,7 @@ def e2e_pe_leg(args, w, genome, site, workload, torch, np, log, n_gpus=1):
     t0 = time.time()
     with open(sam, "wb") as fo:
         p = subprocess.run([os.path.join(ROOT, "salt_amd", "bin", "salt"), "-d", "-c", "-p", "-a", "250", "-b", "550", "-t", str(threads), "--gpus", str(n_gpus), w["prefix"]] + fq,
-                           stdout=fo, stderr=subprocess.PIPE, timeout=900)
+                           stdout=fo, stderr=subprocess.PIPE, timeout=300)
     wall = time.time() - t0
     err = p.stderr.decode(errors="replace")
     if p.returncode != 0:
@@ -658,7 +658,7 @@ def e2e_pe_leg(args, w, genome, site, workload, torch, np, log, n_gpus=1):
     null_s = None
     with open(os.devnull, "wb") as fo:
         p2 = subprocess.run([os.path.join(ROOT, "salt_amd", "bin", "salt"), "-d", "-c", "-p", "-a", "250", "-b", "550", "-t", str(threads), "--gpus", str(n_gpus), w["prefix"]] + fq,
-                            stdout=fo, stderr=subprocess.PIPE, timeout=900)
+                            stdout=fo, stderr=subprocess.PIPE, timeout=300)
     for line in p2.stderr.decode(errors="replace").splitlines():
         if p2.returncode == 0 and (line.startswith("[alnpe_core]: total") or line.startswith("[alnse_core]: total")):
             null_s = float(line.split()[2])
