@@ -23,6 +23,7 @@
 #include <ctime>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -729,42 +730,92 @@ static inline uint64_t count_nl8(uint64_t w)               // newlines among the
     return (uint64_t)__builtin_popcountll(y);
 }
 
+// The chunk boundaries of one file of a pair: chunk k starts where line 4 k pairs_per_chunk starts.  Counting lines is a pass over the
+// whole file, and one thread counts ~4 GB/s -- 30 M mates/s of 150-base pairs, less than one GPU aligns.  So the file goes in segments of
+// 32 MiB to PE_SCAN_THREADS threads: each counts its segment's newlines, learns how many lines lie in front of it once the segments before
+// it are counted (a running sum kept under the scan's mutex), finds the chunk starts that fall inside its segment in the bytes it still
+// holds, and publishes them after the segment before it has published its own.
+static const int PE_SCAN_THREADS = 4;
 static void pe_scan_file(const char *fn, int f, uint64_t pairs_per_chunk, PeScan &S, std::atomic<bool> &failed)
 {
     const int fd = open(fn, O_RDONLY);
     const uint64_t lines_per_chunk = 4 * pairs_per_chunk;
-    auto publish = [&](uint64_t o) { { std::lock_guard<std::mutex> lk(S.mu); S.off[f].push_back(o); } S.cv.notify_all(); };
     if (fd < 0) { { std::lock_guard<std::mutex> lk(S.mu); S.bad = true; S.done[f] = true; } S.cv.notify_all(); return; }
-    publish(0);
-    std::vector<char> buf((size_t)4 << 20);
-    uint64_t pos = 0, lines = 0, next = lines_per_chunk;    // lines seen so far; the line count at which the next chunk starts
-    char last = '\n';
-    for (;;) {
-        if (failed) break;
-        const ssize_t got = pread(fd, buf.data(), buf.size(), (off_t)pos);
-        if (got <= 0) break;
-        last = buf[(size_t)got - 1];
-        size_t i = 0;
-        while (i < (size_t)got) {
-            // whole 4 KiB pieces that cannot reach the next boundary are counted 8 bytes at a time
-            const size_t piece = std::min<size_t>(4096, (size_t)got - i);
+    struct stat st;
+    const uint64_t size = fstat(fd, &st) == 0 ? (uint64_t)st.st_size : 0;
+    { std::lock_guard<std::mutex> lk(S.mu); S.off[f].push_back(0); }
+    S.cv.notify_all();
+    uint64_t SEG = 32ull << 20;
+    if (const char *e = getenv("SALT_PE_SCAN_SEG_BYTES")) { const long long v = atoll(e); if (v >= 64) SEG = (uint64_t)v; }      // tests: many segments in a small file
+    const uint64_t n_seg = (size + SEG - 1) / SEG;
+    std::mutex mu; std::condition_variable cv;               // the order among this file's segments
+    std::vector<int64_t> cnt((size_t)n_seg, -1);             // newlines of a segment, once counted
+    std::vector<uint64_t> before((size_t)n_seg + 1, 0);      // lines in front of a segment, known for segments < known
+    uint64_t known = 0, published = 0;                       // segments whose `before` is known / whose boundaries are out
+    std::atomic<uint64_t> next_seg{ 0 };
+    std::atomic<bool> short_read{ false };
+    char last_byte = '\n';
+    auto work = [&]() {
+        std::vector<char> buf((size_t)SEG);
+        for (;;) {
+            const uint64_t sg = next_seg.fetch_add(1);
+            if (sg >= n_seg || failed) break;
+            const uint64_t lo = sg * SEG, want = std::min<uint64_t>(SEG, size - lo);
+            uint64_t got = 0;
+            while (got < want) { const ssize_t r = pread(fd, buf.data() + got, (size_t)(want - got), (off_t)(lo + got)); if (r <= 0) break; got += (uint64_t)r; }
+            if (got != want) short_read = true;               // (the file shrank under us: the workers' own reads will fail on it)
             uint64_t c = 0; size_t j = 0;
-            for (; j + 8 <= piece; j += 8) { uint64_t w; memcpy(&w, buf.data() + i + j, 8); c += count_nl8(w); }
-            for (; j < piece; ++j) c += buf[i + j] == '\n';
-            if (lines + c < next) { lines += c; i += piece; continue; }
-            for (j = 0; j < piece; ++j)                      // the boundary lies in this piece: byte by byte
-                if (buf[i + j] == '\n' && ++lines == next) { publish(pos + i + j + 1); next += lines_per_chunk; }
-            i += piece;
+            for (; j + 8 <= (size_t)got; j += 8) { uint64_t w; memcpy(&w, buf.data() + j, 8); c += count_nl8(w); }
+            for (; j < (size_t)got; ++j) c += buf[j] == '\n';
+            uint64_t l0;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cnt[(size_t)sg] = (int64_t)c;
+                while (known < n_seg && cnt[(size_t)known] >= 0) { before[(size_t)known + 1] = before[(size_t)known] + (uint64_t)cnt[(size_t)known]; ++known; }
+                cv.notify_all();
+                while (known <= sg && !failed) cv.wait_for(lk, std::chrono::milliseconds(50));      // (a failed run notifies nobody here)
+                if (known <= sg) break;
+                l0 = before[(size_t)sg];
+                if (sg + 1 == n_seg && got) last_byte = buf[(size_t)got - 1];
+            }
+            // chunk starts inside this segment: the byte behind the newline that completes line m * lines_per_chunk, l0 < m * lpc <= l0 + c
+            std::vector<uint64_t> mine;
+            uint64_t nextb = (l0 / lines_per_chunk + 1) * lines_per_chunk, lines = l0;
+            for (size_t i = 0; i < (size_t)got && nextb <= l0 + c; ) {
+                const size_t piece = std::min<size_t>(4096, (size_t)got - i);
+                uint64_t pc = 0; size_t q = 0;
+                for (; q + 8 <= piece; q += 8) { uint64_t w; memcpy(&w, buf.data() + i + q, 8); pc += count_nl8(w); }
+                for (; q < piece; ++q) pc += buf[i + q] == '\n';
+                if (lines + pc < nextb) { lines += pc; i += piece; continue; }
+                for (q = 0; q < piece; ++q)
+                    if (buf[i + q] == '\n' && ++lines == nextb) { mine.push_back(lo + i + q + 1); nextb += lines_per_chunk; }
+                i += piece;
+            }
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                while (published != sg && !failed) cv.wait_for(lk, std::chrono::milliseconds(50));
+                if (published != sg) break;
+                if (!mine.empty()) {
+                    { std::lock_guard<std::mutex> lk2(S.mu); for (uint64_t o : mine) if (o < size) S.off[f].push_back(o); }      // (a start at the very end is the file's end, added below)
+                    S.cv.notify_all();
+                }
+                published = sg + 1;
+                cv.notify_all();
+            }
         }
-        pos += (uint64_t)got;
-    }
+    };
+    std::vector<std::thread> th;
+    const int nt = (int)std::min<uint64_t>((uint64_t)PE_SCAN_THREADS, std::max<uint64_t>(n_seg, 1));
+    for (int t = 0; t < nt; ++t) th.emplace_back(work);
+    for (auto &t : th) t.join();
     close(fd);
-    if (last != '\n') ++lines;                              // a last line without its newline
+    uint64_t lines = known == n_seg ? before[(size_t)n_seg] : 0;
+    if (size && last_byte != '\n') ++lines;                   // a last line without its newline
     {
         std::lock_guard<std::mutex> lk(S.mu);
-        if (S.off[f].back() != pos) S.off[f].push_back(pos);
+        if (S.off[f].back() != size) S.off[f].push_back(size);
         S.records[f] = lines / 4; S.done[f] = true;
-        if (lines % 4) S.bad = true;
+        if (lines % 4 || short_read || (failed && known != n_seg)) S.bad = true;
     }
     S.cv.notify_all();
 }

@@ -58,7 +58,7 @@ def test_salt_reports_a_device_error_and_exits_nonzero(stub_tree, tmp_path):
 
 @pytest.mark.parametrize("case,gpus", [("pe_default", 2), ("pe_r5", 3)])
 def test_salt_pe_text_path_cuts_both_files_by_record_count(case, gpus, stub_tree, tmp_path):
-    """The paired-end driver: two scanner threads publish the offsets of every n-th record of both files, workers of several
+    """The paired-end driver: the scanners of the two files publish the offsets of every n-th record, workers of several
     "devices" take chunk k of both, blocks come out in input order.  Chunks of a dozen pairs; mates whose records differ in length
     between the two files (names of different lengths), so that the same chunk has different byte ranges in the two files."""
     d, prefix = stub_tree
@@ -76,6 +76,11 @@ def test_salt_pe_text_path_cuts_both_files_by_record_count(case, gpus, stub_tree
     assert out.returncode == 0, out.stderr[-500:]
     assert b"text path (paired end)" in out.stderr
     assert strip(out.stdout) == want
+    # the scanners count lines in segments on several threads each: a few hundred segments per file instead of one
+    for seg in ("1000", "4097", "70000"):
+        seg_out = subprocess.run([str(d / "bin" / "salt")] + read_cases()[case] + ["-t", "16", "--gpus", str(gpus), prefix, f1, str(f2)], capture_output=True,
+                                 env=dict(env, SALT_PE_SCAN_SEG_BYTES=seg, SALT_STUB_LOG=str(tmp_path / "seg.log")))
+        assert seg_out.returncode == 0 and strip(seg_out.stdout) == want, (seg, seg_out.stderr[-300:])
     rows = [l.split() for l in open(log).read().splitlines()]
     assert sum(int(r[1]) for r in rows) == 1000 and len(rows) > 20
     assert {int(r[0]) for r in rows} == set(range(gpus))
