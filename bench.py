@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1000000, help="reads given to the CPU baseline / parity check")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--e2e-reads", type=int, default=32000000, help="reads of the end-to-end leg (`salt` binary, FASTQ -> SAM); 0 = skip")
-    ap.add_argument("--e2e-pairs", type=int, default=4000000, help="pairs (2 x 150) of the paired-end end-to-end leg (`salt -p`); 0 = skip")
+    ap.add_argument("--e2e-pairs", type=int, default=8000000, help="pairs (2 x 150) of the paired-end end-to-end leg (`salt -p`); 0 = skip")
     ap.add_argument("--pe-pairs", type=int, default=500000, help="pairs (2 x 150) per step of the paired-end kernel-stage leg; 0 = skip")
     ap.add_argument("--pe-steps", type=int, default=16)
     ap.add_argument("--pe-batches", type=int, default=4)
