@@ -3,11 +3,13 @@
 //   k_pair   one lane per pair: pairing2 / pairing_singleton up to the point where they call Smith-Waterman
 //            (Align_src/alnpe.c:94-258, 395-480): accept the primaries if properly oriented and spaced, else the best
 //            pair among the alternative hits, else queue up to two rescue windows (tried in the reference's order).
-//   k_sw     eight lanes per rescue request = the eight 16-bit lanes of the reference's SSE2 word kernel
-//            (sw_sse2_word, ssw.c:371-547), emulated operation by operation because its "lazy F" pass is not the
-//            textbook recurrence (a deletion may not follow an insertion across a stripe boundary); forward pass,
-//            reverse pass from the end point (ssw_align, ssw.c:771-856), second-best score outside the mask, then the
-//            banded traceback (banded_sw, ssw.c:549-727) by the group's first lane.
+//   k_swf    eight lanes per PAIR of rescue requests = the eight 16-bit lanes of the reference's SSE2 word kernel
+//            (sw_sse2_word, ssw.c:371-547), two requests in the halves of every register, emulated operation by operation because
+//            its "lazy F" pass is not the textbook recurrence (a deletion may not follow an insertion across a stripe
+//            boundary): the forward pass and the second-best score outside the mask (ssw_align, ssw.c:771-816).  k_swf1: the
+//            same for requests that cannot be paired, one per group.
+//   k_swr    the reverse pass from the end point (ssw.c:817-830), eight lanes per request.
+//   k_swtb   the banded traceback (banded_sw, ssw.c:549-727), eight lanes per alignment.
 // The results are applied to the mates by k_pe_final (salt_align.hip), which also writes the CIGARs.
 #include "salt_device.h"
 #include <stdlib.h>
@@ -897,7 +899,7 @@ k_swr(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_swtb: the banded traceback of the requests k_sw left with ok = 2 (ssw.c:837-848), eight lanes per alignment (tb_band_pass)
+// k_swtb: the banded traceback of the requests k_swr left with ok = 2 (ssw.c:837-848), eight lanes per alignment (tb_band_pass)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 k_swtb(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__ seqs, const uint32_t *__restrict__ offs,
@@ -915,7 +917,7 @@ k_swtb(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict_
     uint8_t *const gdir = my + 3u * SW_BAND_W * 4u;
     const uint64_t gdir_cap = group_bytes > 3u * SW_BAND_W * 4u ? group_bytes - 3u * SW_BAND_W * 4u : 0u;
     const uint32_t n_req = pctl[0];
-    for (;;) {                                                       // eight requests per pull, a uniform exit (see k_sw)
+    for (;;) {                                                       // eight requests per pull, a uniform exit (see k_swr)
         uint32_t base = 0;
         if (threadIdx.x == 0) base = atomicAdd(head, 8u);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -1114,7 +1116,7 @@ static TbGeom tb_geom(uint32_t max_len)
     t.group_b = t.read_b + t.ref_b + 3u * t.row_w * 4u + t.dir_b;
     return t;
 }
-// Scratch geometry of one launch: k_sw's groups keep the per-column maxima of the longest window (max_window columns) in global memory;
+// Scratch geometry of one launch: k_swf's groups keep the per-column maxima of the longest window (max_window columns) in global memory;
 // k_swtb's groups three band rows and the direction bytes of the widest band the rows hold (one byte per cell) for alignments whose band
 // outgrows the LDS -- its grid is cut back before that passes SW_SCRATCH_TOTAL.
 SwGeom sw_geom(uint32_t max_len, uint64_t max_window, uint32_t cus)
