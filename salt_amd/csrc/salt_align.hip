@@ -1353,15 +1353,18 @@ __device__ __attribute__((noinline)) void lv_cigar(const uint32_t *ref, W &w, Lv
 __device__ __forceinline__ void lane_text(const uint32_t *__restrict__ ref, uint32_t *T, uint32_t pos, uint32_t tl)
 {
     const uint32_t w0 = pos >> 3, sh = (pos & 7u) * 4u, nwt = (tl + 7) >> 3;
-    uint32_t lo = ref[w0];
-    for (uint32_t j = 0; j < (uint32_t)LLV_TW; ++j) {
+    // every word of the window is asked for before the first is used (one load, one wait, one store per word was 22 memory round trips
+    // in a row per candidate)
+    uint32_t wv[LLV_TW + 1];
+#pragma unroll
+    for (int j = 0; j <= LLV_TW; ++j) wv[j] = (uint32_t)j <= nwt ? ref[w0 + (uint32_t)j] : 0u;
+#pragma unroll
+    for (int j = 0; j < LLV_TW; ++j) {
         uint32_t word = 0;
-        if (j < nwt) {
-            const uint32_t hi = ref[w0 + j + 1];
-            word = __funnelshift_r(lo, hi, sh);
-            const uint32_t rem = tl - j * 8;
+        if ((uint32_t)j < nwt) {
+            word = __funnelshift_r(wv[j], wv[j + 1], sh);
+            const uint32_t rem = tl - (uint32_t)j * 8;
             if (rem < 8) word &= (1u << (4 * rem)) - 1u;
-            lo = hi;
         }
         T[j] = word;
     }
