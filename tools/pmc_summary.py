@@ -49,6 +49,9 @@ def gather(fn, loads):
         vals = [by[d] for d in sorted(by)]
         if vals:
             w = k.split("<")[1].split(">")[0] if "<" in k else "?"
+            if w.strip() == "1024":                      # runs of 64 consecutive 16-byte rows: 16 sectors per run, one run per 64 lane-loads
+                print("FETCH_SIZE per 64-byte sector of a random 1 KB run of 16-byte rows: %.1f bytes (mean of %d launches)" % (sum(vals) / len(vals) * 1024 / (loads / 4), len(vals)))
+                continue
             n = loads / 4 if w.strip() == "64" else loads
             print("FETCH_SIZE per random %s-byte record: %.1f bytes (mean of %d launches)" % (w, sum(vals) / len(vals) * 1024 / n, len(vals)))
 

@@ -39,8 +39,8 @@ template <int W> void run(const uint32_t *d, uint64_t bytes, uint64_t n_loads, u
     }
     float ms; hipEventElapsedTime(&ms, a, b);
     const double per_rec = W == 64 || W == 1024 ? n_loads / 4.0 : (double)n_loads;      // sectors: four 16-byte lanes each
-    printf("W = %4d B: %.0f M records in %.3f ms = %.2f G records/s; at one 64-B sector each = %.2f TB/s, useful %.2f TB/s\n", W, per_rec / 1e6, ms, per_rec / ms / 1e6,
-           per_rec * 64 / ms / 1e9, per_rec * W / ms / 1e9);
+    printf("W = %4d B: %.0f M %s in %.3f ms = %.2f G/s; at one 64-B sector each = %.2f TB/s, useful %.2f TB/s\n", W, per_rec / 1e6, W == 1024 ? "sectors (runs of 64 rows x 16 B)" : "records", ms,
+           per_rec / ms / 1e6, per_rec * 64 / ms / 1e9, per_rec * (W == 1024 ? 64 : W) / ms / 1e9);
 }
 int main(int argc, char **argv)
 {
