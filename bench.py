@@ -337,22 +337,37 @@ def main():
         rq = pk.get(pkey(dom), {}).get("TCC_EA0_RDREQ_sum")
         if rq:
             # how far the kernel is from the memory system's limit for its access shape: random 64-byte requests per second (a second adjacent sector per window is free)
+            def req_rates(k, ms):                                        # read requests (TCC_EA0_RDREQ) + write requests (WRITE_SIZE, KiB, / 64 B) of a kernel
+                v = pk.get(pkey(k), {})
+                rd, wr = v.get("TCC_EA0_RDREQ_sum", 0.0), v.get("WRITE_SIZE", 0.0) * 1024.0 / SECTOR
+                return {"read_requests": int(rd), "write_requests": int(wr), "G_per_s": round((rd + wr) / (ms / 1e3) / 1e9, 1) if ms else None}
+            wr = pk.get(pkey(dom), {}).get("WRITE_SIZE", 0.0) * 1024.0 / SECTOR
             roof["random_requests"] = {"per_launch": int(rq), "G_per_s": round(rq / (serial_kms[dom] / 1e3) / 1e9, 1), "ceiling_G_per_s": RANDOM_REQ_GPS,
                                        "frac_of_ceiling": round(rq / (serial_kms[dom] / 1e3) / 1e9 / RANDOM_REQ_GPS, 3),
+                                       "with_writes": {"per_launch": int(rq + wr), "G_per_s": round((rq + wr) / (serial_kms[dom] / 1e3) / 1e9, 1),
+                                                       "ms_at_the_ceiling": round((rq + wr) / (RANDOM_REQ_GPS * 1e9) * 1e3, 3)},
+                                       "all_kernels": {k: req_rates(k, serial_kms.get(k, 0.0)) for k in ("k_seed", "k_light", "k_heavy", "k_gap") if serial_kms.get(k)},
+                                       "ceilings_by_shape_G_per_s": {"4-byte": 48, "16-byte": 38, "32-byte": 38, "64-byte (4 lanes x 16 B)": 47,
+                                                                     "source": "tools/ubench/gather, the same from 16 ... 240 GiB tables and from 65 000 ... 2 000 000 loads in flight (profiles/r03/gather_rate*.log)"},
                                        "whole_step_G_per_s_wall": round(sum(v.get("TCC_EA0_RDREQ_sum", 0) for v in pk.values()) / (dt / args.steps) / 1e9, 1),
-                                       "source": "TCC_EA0_RDREQ_sum per launch (%s/pmc_tcc_*.csv) / this run's HIP-event time; ceiling: tools/ubench/gather" % prof_dir}
+                                       "source": "TCC_EA0_RDREQ_sum (+ WRITE_SIZE / 64 B) per launch (%s/pmc_tcc_*.csv, pmc_write_*.csv) / this run's HIP-event time; ceiling: tools/ubench/gather; "
+                                                 "k_seed in all_kernels is k_seed + k_seed_walk (one timing slot: their counters are added)" % prof_dir}
+            if "k_seed" in roof["random_requests"]["all_kernels"]:
+                a, b = pk.get("k_seed", {}), pk.get("k_seed_walk", {})
+                rd = a.get("TCC_EA0_RDREQ_sum", 0.0) + b.get("TCC_EA0_RDREQ_sum", 0.0); wr2 = (a.get("WRITE_SIZE", 0.0) + b.get("WRITE_SIZE", 0.0)) * 1024.0 / SECTOR
+                roof["random_requests"]["all_kernels"]["k_seed"] = {"read_requests": int(rd), "write_requests": int(wr2), "G_per_s": round((rd + wr2) / (serial_kms["k_seed"] / 1e3) / 1e9, 1)}
         alltr = prof.get("hbm_bytes_per_launch", {})
         if alltr:
             roof["whole_step_traffic_GBps_wall"] = round(sum(alltr.values()) / (dt / args.steps) / 1e9, 1)
         ir = prof.get("issue", {}).get(pkey(dom))
         if ir:
             roof["issue_bound"] = ir
-        roof["limiter"] = ("memory latency x resident waves, not a bandwidth: k_seed and k_light2 fill every wave slot (8 per SIMD) with dependent chains of random loads "
-                           "(a W-mer gather, then up to k - W Occ steps per seed; 3 round trips per read pair), k_heavy's reads make ~20 dependent round trips each on its one-wave "
-                           "persistent blocks (salt_gpu_ws_create: 8 per CU unless SALT_GPU_HEAVY_PER_CU says otherwise).  With 4 or more streams the step is pinned at the sum of the slot-filling kernels plus the part of k_heavy that does not hide behind them "
-                           "(2 streams: the serialized sum; 4, 6, 8: the same plateau).  random_requests.frac_of_ceiling and frac (bytes) say how far the memory system is from ITS "
-                           "limits: about half of the random-request rate and a fifth of the streaming peak.  Halving k_heavy's requests (the context table, DESIGN 3) "
-                           "took 14 % off its time: that is what a latency bound looks like")
+        roof["limiter"] = ("the rate at which the memory system serves dependent, sector-sized random requests into a 195 GiB image, not its byte bandwidth: with the write requests "
+                           "counted k_seed makes its requests at 41 G/s (the micro-benchmark's ceiling for its shape), k_seed_walk at 30 G/s (0.8 of the 38 G/s its 32-byte blocks reach), "
+                           "k_heavy at 26 G/s -- and k_heavy does not move with more resident waves (8 / 12 / 16 one-wave blocks per CU: the same time, every wave 1.5 - 2 x slower: the L1's "
+                           "own latency and its return path stall, profiles/r03/heavy_mem_counters_8_vs_12_per_cu.log) nor with more loads in flight per wave "
+                           "(profiles/r03/ab_heavy_locate_mlp.log).  random_requests.with_writes.ms_at_the_ceiling is what the kernel's requests would take at the gather ceiling; "
+                           "what moves the step from here is fewer requests per read (the context tables did that: DESIGN 3, 4.2, 5.0)")
         roof["counters"] = {k: int(v) for k, v in ctr.items() if k.startswith("d_")}
         out["roofline"] = roof
 
