@@ -135,10 +135,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
+        wait = datetime.timedelta(minutes=40)                               # ranks > 0 sit in the last barrier while rank 0 runs the end-to-end legs (four `salt` runs)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=wait)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=wait)
 
     cfg = workload.CONFIGS[args.workload]
     L, n_reads = cfg["read_len"], (args.reads or cfg["n_reads"])
