@@ -307,7 +307,8 @@ def main():
             db = device_bytes(ctr, n_reads, L, spr)
         except KeyError:
             db = None
-        dom = max(serial_kms, key=lambda k: serial_kms[k])
+        # the dominant kernel among those whose bytes are counted (the memory-bound ones; on a toy workload a gapped-pass kernel can be the longest)
+        dom = max([k for k in serial_kms if db and k in db] or list(serial_kms), key=lambda k: serial_kms[k])
         prof, prof_dir = {}, None
         for rd in ("r03", "r02"):                               # the newest committed profile of this workload
             pf = os.path.join(ROOT, "profiles", rd, "pmc_summary_%s.json" % args.workload)

@@ -678,6 +678,33 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["steps"] == 4
 
 
+def test_bench_line_keeps_its_contract_on_the_mini_workload(tmp_path):
+    """bench.py at N = 1 on the small workload: ONE JSON line with the driver's keys, the roofline and cpu_baseline objects, the
+    paired-end leg, both end-to-end legs (each also with its stream on /dev/null) and parity on a timed step."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SALT_BENCH_WORKLOAD="mini", SALT_GPU_LKT_LEN="14", SALT_BENCH_CACHE=str(tmp_path))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--cpu-sample", "5000", "--e2e-reads", "40000",
+                          "--e2e-pairs", "10000", "--pe-pairs", "5000", "--pe-steps", "4", "--pe-batches", "2", "--pe-check", "1000"],
+                         capture_output=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-800:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["metric"] == "Mreads/s" or d["unit"] == "Mreads/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["value"] > 0 and d["higher_is_better"] is True and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["achieved"] > 0 and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] in ("port", "reference") and c["sample"]
+    assert d["parity"]["path"] == "timed step" and d["parity"]["mismatching_reads"] == 0
+    assert d["pe"]["value"] > 0 and d["pe"]["parity"]["mismatching_mates"] == 0 and "roofline" in d["pe"]
+    assert d["e2e"]["value"] > 0 and d["e2e"]["value_devnull"] > 0 and d["e2e_pe"]["value"] > 0 and d["e2e_pe"]["value_devnull"] > 0
+
+
 @pytest.fixture(scope="module")
 def lambda_cli_index(tmp_path_factory):
     """The lambda fixture indexed by salt-idx (the committed index lacks the 64 MiB .C.lkt)."""
