@@ -22,11 +22,14 @@ def asan_bins():
 def test_index_builder_under_asan_ubsan(case, asan_bins, tmp_path):
     d = LAMBDA if case == "lambda" else os.path.join(GOLDEN, "index_cases", case)
     prefix = str(tmp_path / "idx")
-    p = subprocess.run([asan_bins[0], "-k", "19", os.path.join(d, "genome.fa"), os.path.join(d, "snps.txt"), prefix], capture_output=True, env=ENV)
+    p = subprocess.run([asan_bins[0], "--all-files", "-k", "19", os.path.join(d, "genome.fa"), os.path.join(d, "snps.txt"), prefix], capture_output=True, env=ENV)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     assert b"runtime error" not in p.stderr and b"AddressSanitizer" not in p.stderr, p.stderr.decode()[-2000:]
     for sfx in (".C.bwt", ".C.sa", ".R.backward.bwt", ".R.backward.occ"):
         assert open(prefix + sfx, "rb").read() == open(os.path.join(d, "idx" + sfx), "rb").read(), sfx
+    import hashlib
+    for sfx, sha in (l.split() for l in open(os.path.join(d, "idx.unread.sha256"))):      # --all-files: the R text files and the forward R index
+        assert hashlib.sha256(open(prefix + sfx, "rb").read()).hexdigest() == sha, sfx
 
 
 @pytest.mark.parametrize("case", ["se_default", "pe_default"])
