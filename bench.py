@@ -395,6 +395,36 @@ def main():
                                    "sample": "first %d reads of batch %d of the same workload, oracle/libsalt_oracle.so (bit-exact CPU restatement "
                                              "of the reference), %d threads = every hardware thread of this box, align time only (%.1f s)" % (ns, timed_batch, cores, cpu_dt),
                                    "speedup_1gpu": round(value / world / (ns / cpu_dt / 1e6), 1)}
+            # the REAL reference binary on the same index files and a bounded sample of the same reads, when it is there (oracle/_ref/salt:
+            # built from /root/reference by oracle/Makefile in the build container, shipped as a binary; test infrastructure like the
+            # oracle): its own [alnse_core] clock (index reload excluded, SAM to /dev/null included, as the reference reports itself)
+            ref_bin = os.path.join(ROOT, "oracle", "_ref", "salt")
+            if os.access(ref_bin, os.X_OK):
+                try:
+                    nr = min(ns, 500000)
+                    fqp = os.path.join(w["dir"], "cpu_sample.fq")
+                    with open(fqp, "wb") as f:
+                        f.write(workload.fastq_bytes(hs[:nr * L], nr, L, first_id=0))
+                    # the reference's own thread pool gets slower with more threads on this box (16: 3.1 s, 32: 3.8 s, 64: 7.5 s, 128: 14.5 s
+                    # for the same 500 000 reads): a short sweep, the best count is the baseline
+                    sweep = {}
+                    for thr in [t for t in (8, 16, 32) if t <= cores] or [cores]:
+                        rp = subprocess.run([ref_bin, "-d", "-c", "-t", str(thr), w["prefix"], fqp], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+                        tot = [l for l in rp.stderr.decode(errors="replace").splitlines() if l.startswith("[alnse_core]: total")]
+                        if rp.returncode == 0 and tot:
+                            sweep[thr] = float(tot[-1].split()[2])
+                    os.unlink(fqp)
+                    if sweep:
+                        thr = min(sweep, key=lambda t: sweep[t]); ref_s = sweep[thr]
+                        port = dict(out["cpu_baseline"])
+                        out["cpu_baseline"] = {"value": round(nr / ref_s / 1e6, 5), "unit": "Mreads/s", "cores": thr, "cpu_model": cpu_model, "kind": "reference",
+                                               "sample": "first %d reads of batch %d of the same workload as a FASTQ file, the reference's own binary (oracle/_ref/salt -d -c -t %d on the "
+                                                         "same index files, SAM to /dev/null), its [alnse_core] total (%.1f s; index reload excluded as it reports itself); the best of "
+                                                         "a thread sweep: its pool gets slower beyond 16 - 32 threads on this box" % (nr, timed_batch, thr, ref_s),
+                                               "thread_sweep_s": {str(t): round(v, 2) for t, v in sweep.items()},
+                                               "speedup_1gpu": round(value / world / (nr / ref_s / 1e6), 1), "port": port}
+                except Exception as ex:                                     # the port's number stays
+                    out["cpu_baseline"]["reference_error"] = repr(ex)[:200]
             out["parity"] = {"path": "timed step", "what": "rows left by the last step of the timed region (batch %d, workspace %d) vs the oracle, every field" % (timed_batch, last % n_streams),
                              "checked_reads": int(ns), "mismatching_reads": int(len(bad)),
                              "mapped_fraction": round(float((gres["pos"] != 0xFFFFFFFF).mean()), 5)}
