@@ -621,13 +621,40 @@ def pe_leg(args, cfg, idx, alns, streams, genome, site, ora, oracle_py, dev, tor
     return out
 
 
+def input_dir(d, need_bytes):
+    """Where the end-to-end legs put their FASTQ input: memory (/dev/shm) when it has the room, so that the gigabytes of input written a
+    moment before the run are not dirty pages the kernel is still writing back while `salt` writes its SAM file (the measured leg is
+    FASTQ text in the page cache -> SAM text into a file either way); else next to the index."""
+    try:
+        st = os.statvfs("/dev/shm")
+        if st.f_bavail * st.f_frsize > 2 * need_bytes + (8 << 30):
+            return "/dev/shm"
+    except OSError:
+        pass
+    return d
+
+
+def remove_at_exit(*paths):
+    """Input files are removed when their leg ends; this covers a leg that raised in between (a file in /dev/shm is held in memory)."""
+    import atexit
+
+    def rm():
+        for f in paths:
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+    atexit.register(rm)
+
+
 def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log, n_gpus=1):
     """`salt -d -c` on a FASTQ file of the same workload: the binary's own clock (starts when the index is loaded and attached, like the
     reference's; ends with the last SAM byte written), plus the whole process."""
     L = cfg["read_len"]
     d = w["dir"]
-    fq = os.path.join(d, "e2e.fq")
     n = args.e2e_reads
+    fq = os.path.join(input_dir(d, n * (2 * L + 32)), "salt_bench_e2e.fq")
+    remove_at_exit(fq)
     t0 = time.time()
     with open(fq, "wb") as f:
         done = 0
@@ -668,14 +695,16 @@ def e2e_leg(args, cfg, w, genome, site, workload, torch, np, log, n_gpus=1):
             "what": "salt -d -c -t %d --gpus N <idx> reads.fq > out.sam (one process, reads dealt to the GPUs' workers in chunks, one ordered SAM stream): FASTQ text in, SAM text out (%.2f GB), PCIe and host I/O included; clock = the binary's "
                     "[alnse_core] total (restarted where the reference restarts its own, behind the index reload, alnse.c:1366; workspace set-up included; ends with the "
                     "last SAM byte written; index load + attach excluded, as SURVEY 8d defines it); value_devnull: the same command with stdout on /dev/null" % (threads, sam_bytes / 1e9),
-            "align_wall_s": align_s, "process_wall_s": round(wall, 2), "fastq_write_s": round(t_write, 2), "pipeline": detail}
+            "align_wall_s": align_s, "process_wall_s": round(wall, 2), "fastq_write_s": round(t_write, 2), "input_dir": os.path.dirname(fq), "pipeline": detail}
 
 
 def e2e_pe_leg(args, w, genome, site, workload, torch, np, log, n_gpus=1):
     """`salt -d -c -p -a 250 -b 550` on two FASTQ files of 2 x 150-base pairs of the same genome (BASELINE's paired-end configuration): the
     binary's own clock as in e2e_leg."""
     L, n, d = 150, args.e2e_pairs, w["dir"]
-    fq = [os.path.join(d, "e2e_1.fq"), os.path.join(d, "e2e_2.fq")]
+    di = input_dir(d, 2 * n * (2 * L + 32))
+    fq = [os.path.join(di, "salt_bench_e2e_1.fq"), os.path.join(di, "salt_bench_e2e_2.fq")]
+    remove_at_exit(*fq)
     with open(fq[0], "wb") as f1, open(fq[1], "wb") as f2:
         done = 0
         while done < n:
@@ -715,7 +744,7 @@ def e2e_pe_leg(args, w, genome, site, workload, torch, np, log, n_gpus=1):
     return {"value": round(2 * n / align_s / 1e6, 3) if align_s else None, "unit": "M mates/s", "pairs": n, "read_len": L, "threads": threads, "n_gpus": n_gpus,
             "value_devnull": round(2 * n / null_s / 1e6, 3) if null_s else None,
             "what": "salt -d -c -p -a 250 -b 550 -t %d <idx> r1.fq r2.fq > out.sam (%.2f GB of SAM); the binary's clock as in e2e" % (threads, sam_bytes / 1e9),
-            "align_wall_s": align_s, "process_wall_s": round(wall, 2), "pipeline": detail}
+            "align_wall_s": align_s, "process_wall_s": round(wall, 2), "input_dir": di, "pipeline": detail}
 
 
 if __name__ == "__main__":
