@@ -467,7 +467,9 @@ def main():
                 out["e2e"] = e2e_leg(args, cfg, w, genome, site, workload, torch, np, log, 1 if os.environ.get("SALT_BENCH_SAME_GPU") else world)
             except Exception as ex:                                    # the leg is a report, not a gate
                 out["e2e"] = {"error": str(ex)[:300]}
-        if args.e2e_pairs > 0 and args.e2e_reads > 0:
+        if args.e2e_pairs > 0 and args.e2e_reads > 0 and world > 1 and "error" in out.get("e2e", {}):
+            out["e2e_pe"] = {"error": "skipped: the single-end `salt --gpus %d` run did not finish (see e2e.error)" % world}     # not another wait of minutes on the same cause
+        elif args.e2e_pairs > 0 and args.e2e_reads > 0:
             try:
                 out["e2e_pe"] = e2e_pe_leg(args, w, genome, site, workload, torch, np, log, 1 if os.environ.get("SALT_BENCH_SAME_GPU") else world)
             except Exception as ex:
