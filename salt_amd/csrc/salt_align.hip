@@ -1156,14 +1156,29 @@ __device__ __forceinline__ void rule_unsorted(const uint32_t *pos, const uint8_t
     uint32_t mp[VMAX + 1];
 #pragma unroll
     for (int t = 0; t <= VMAX; ++t) mp[t] = NONE;
+    // The members of P are few (a repeat read's list: ~900 located rows, a handful inside the bound), and the hits below are six more
+    // passes over whatever they are taken from: while P has at most 64 members, member k is copied to lane k (scalar steps per member,
+    // none for a trip without one) and the hit passes run on that register copy instead of the list.
+    uint32_t my_p = 0, my_v = NONE, n_p = 0;                      // n_p > 64: P outgrew the lanes, the passes walk the list
     for (uint32_t b = 0; b < n; b += 64) {
         const uint32_t i = b + lane;
-        if (i < n) {
-            const uint32_t p = pos[i], v = val[i];
-            if (v <= bound && in_range(p)) {
+        uint32_t p = 0, v = NONE;
+        if (i < n) { p = pos[i]; v = val[i]; }
+        const bool in = i < n && v <= bound && in_range(p);
+        if (in) {
 #pragma unroll
-                for (int t = 0; t <= VMAX; ++t) if (v == (uint32_t)t && p < mp[t]) mp[t] = p;
-            }
+            for (int t = 0; t <= VMAX; ++t) if (v == (uint32_t)t && p < mp[t]) mp[t] = p;
+        }
+        uint64_t m = __ballot(in);
+        if (m && n_p <= 64u) {
+            if (n_p + (uint32_t)__popcll(m) > 64u) n_p = 65u;
+            else
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)p, l), vl = (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+                    if (lane == n_p) { my_p = pl; my_v = vl; }
+                    ++n_p; m &= m - 1;
+                }
         }
     }
 #pragma unroll
@@ -1179,8 +1194,18 @@ __device__ __forceinline__ void rule_unsorted(const uint32_t *pos, const uint8_t
     for (int t = VMAX; t >= 0; --t) if (mp[t] != NONE) { any = true; best_v = (uint32_t)t; best_pos = mp[t]; }
     if (!any) return;
     unsigned long long last = 0;
+    const bool in_lanes = n_p <= 64u;
+    unsigned long long my_key = ~0ull;                            // this lane's member, if it counts (p < the smallest position of a smaller distance)
+    if (in_lanes && lane < n_p) {
+        uint32_t lim = NONE;
+#pragma unroll
+        for (int t = 1; t <= VMAX; ++t) if (my_v == (uint32_t)t) lim = before[t];
+        if (my_p < lim) my_key = ((unsigned long long)my_p << 8) | my_v;
+    }
     for (uint32_t h = 0; h < (uint32_t)NHIT; ++h) {
         unsigned long long cur = ~0ull;
+        if (in_lanes) { if (h == 0 || my_key > last) cur = my_key; }
+        else
         for (uint32_t b = 0; b < n; b += 64) {
             const uint32_t i = b + lane;
             if (i < n) {
@@ -1489,7 +1514,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             // duplicates included -- rule_unsorted needs neither).  Strand 1's rows are still in `loci` (unless the context table
             // thinned them: the gapped pass needs every row); strand 0's are located again.  (Single end and paired end alike.)
             uint32_t slot = 0;
-            if (lane == 0) slot = atomicAdd(&g.gctl[2], 1u);
+            if (lane == 0) slot = atomicAdd(&g.gctl[QC(2)], 1u);
             slot = (uint32_t)__shfl((int)slot, 0);
             if (slot < g.cap) {
                 uint32_t ns[2], off[2];
@@ -1506,7 +1531,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                     }
                     if (n > 1024u * LLV_N) { ok = false; break; }        // a work item names its chunk in 10 bits; PE lists can be longer
                     uint32_t o = 0;
-                    if (lane == 0) o = atomicAdd(&g.gctl[8], n);
+                    if (lane == 0) o = atomicAdd(&g.gctl[QC(8)], n);
                     o = (uint32_t)__shfl((int)o, 0);
                     ok = (uint64_t)o + n <= g.pool;
                     if (ok) for (uint32_t i = lane; i < n; i += 64) g.gloci[o + i] = loci[i];
@@ -1514,7 +1539,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
                 }
                 const uint32_t ch0 = ok ? (ns[0] + LLV_N - 1) / LLV_N : 0, ch1 = ok ? (ns[1] + LLV_N - 1) / LLV_N : 0;
                 uint32_t base = 0;
-                if (ok && lane == 0) base = atomicAdd(&g.gctl[5], ch0 + ch1);
+                if (ok && lane == 0) base = atomicAdd(&g.gctl[QC(5)], ch0 + ch1);
                 base = (uint32_t)__shfl((int)base, 0);
                 ok = ok && (uint64_t)base + ch0 + ch1 <= g.items_cap;
                 if (lane == 0) {
@@ -1546,7 +1571,7 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
             // ... which takes the lane-LV scratch this block does not carry: the read goes to the overflow queue and the pass behind
             // this kernel (the same code in a block that has it) starts it again.  Nothing of it has been written yet.
             if (lanes_fit && n_cand_nogap > 0) {
-                if (lane == 0) g.ovq[atomicAdd(&g.gctl[9], 1u)] = r;
+                if (lane == 0) g.ovq[atomicAdd(&g.gctl[QC(9)], 1u)] = r;
                 return;
             }
         }
@@ -1681,11 +1706,28 @@ __device__ __forceinline__ void align_general(const IndexView ix, const AlignPar
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent kernels: one-wave blocks pull work items through counters in qctl[] until the head passes the count
-//   qctl[0] reads queued by k_light    qctl[1] k_heavy head
+// Persistent kernels: one-wave blocks pull work items through counters in qctl[] until the head passes the count (control word k lives
+// at qctl[QC(k)], a cache line of its own; k_heavy, k_gap and k_gapfin take their items through ranged heads instead: pop_ranged)
+//   qctl[0] reads queued by k_light    qctl[1] (was k_heavy's head)
 //   qctl[2] gapped reads (slots)       qctl[3] k_gap head        qctl[4] k_gapfin head
 //   qctl[5] k_gap items                qctl[6] CIGAR items       qctl[7] k_cigar head      qctl[8] pool entries used
 // ---------------------------------------------------------------------------------------------
+static constexpr uint32_t HEAVY_HEADS = 64, HEAVY_HEAD_STRIDE = 64;          // ranges of the queue with a head of their own; words between the heads
+// Thread 0 of a persistent one-wave block: the next item of a queue of n_items cut into HEAVY_HEADS ranges (heads[range * HEAVY_HEAD_STRIDE],
+// zero at launch); 0xFFFFFFFF once every range is empty.  seg / tried: where this block is (start at blockIdx % HEAVY_HEADS, 0).
+__device__ __forceinline__ uint32_t pop_ranged(uint32_t *heads, const uint32_t n_items, uint32_t &seg, uint32_t &tried)
+{
+    while (tried < HEAVY_HEADS) {
+        const uint32_t lo = (uint32_t)((uint64_t)n_items * seg / HEAVY_HEADS), hi = (uint32_t)((uint64_t)n_items * (seg + 1u) / HEAVY_HEADS);
+        uint32_t *h = heads + seg * HEAVY_HEAD_STRIDE;
+        if (lo < hi && __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hi - lo) {      // (a look first: late waves do not queue up on an empty range's counter)
+            const uint32_t k = atomicAdd(h, 1u);
+            if (k < hi - lo) return lo + k;
+        }
+        seg = (seg + 1u) & (HEAVY_HEADS - 1u); ++tried;
+    }
+    return 0xFFFFFFFFu;
+}
 template <bool PE, bool GL, class W>
 __device__ __forceinline__ void heavy_body(const IndexView &ix, const AlignParams &ap, const uint32_t *__restrict__ pm,
                                            const uint4 *__restrict__ sai_c, const uint4 *__restrict__ sai_r,
@@ -1700,13 +1742,24 @@ __device__ __forceinline__ void heavy_body(const IndexView &ix, const AlignParam
     if (ctr) { for (int i = threadIdx.x; i < SALT_CTR_N; i += 64) s_phase[i] = 0; }
     WSYNC();
     // the usual pass takes the reads k_light queued (or all of them); the overflow pass the ones a block without the lane-LV scratch left
-    const uint32_t n_items = overflow_pass ? g.gctl[9] : ap.all_heavy ? ap.n_reads : g.gctl[0];
+    const uint32_t n_items = overflow_pass ? g.gctl[QC(9)] : ap.all_heavy ? ap.n_reads : g.gctl[QC(0)];
+    // One read per pop.  The pops of all waves on ONE counter are served one after the other, ~14 ns each whatever the waves do in between
+    // (75 700 queued reads: 1.09 of the kernel's 1.165 ms, the same at 8, 12 and 16 blocks per CU; time = 0.08 ms + 14.4 ns x reads from
+    // 9 000 to 150 000 reads, profiles/r03/heavy_vs_batch.log).  So the queue is cut into HEAVY_HEADS ranges with a head each, 256 bytes
+    // apart; a wave starts at range blockIdx % HEAVY_HEADS and moves on to the next when one is empty (pop_ranged).  k_gap and k_gapfin
+    // take their items the same way (heads + 1, + 2); the counters k_heavy's gapped reads push through are a cache line apart each (QC()).
+    uint32_t seg = blockIdx.x & (HEAVY_HEADS - 1u), tried = 0;
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(&g.gctl[overflow_pass ? 10 : 1], 1u);
+        if (threadIdx.x == 0) {
+            uint32_t got = 0xFFFFFFFFu;
+            if (overflow_pass) { got = atomicAdd(&g.gctl[QC(10)], 1u); if (got >= n_items) got = 0xFFFFFFFFu; }
+            else got = pop_ranged(g.qheads, n_items, seg, tried);
+            s_item = got;
+        }
         WSYNC();
         const uint32_t it = s_item;
         WSYNC();
-        if (it >= n_items) break;
+        if (it == 0xFFFFFFFFu) break;
         const uint32_t r = overflow_pass ? g.ovq[it] : ap.all_heavy ? it : queue[it];
         align_general<PE, GL>(ix, ap, w, r, pm, sai_c, sai_r, results, ctr, phase, lvtab + blockIdx.x, g,
                           pe_scr ? reinterpret_cast<uint32_t *>(pe_scr + (size_t)blockIdx.x * PE_LOCI_CAP * 5) : nullptr,
@@ -1720,7 +1773,13 @@ __device__ __forceinline__ void heavy_body(const IndexView &ix, const AlignParam
     }
 }
 
-#ifdef SALT_HEAVY_WAVES                     /* A/B builds: cap the registers of the persistent kernels for that many waves per SIMD */
+// Registers of the persistent kernels capped for four waves per SIMD (128 VGPRs, ~20 spilled on rare paths): 16 one-wave blocks per CU.
+// Uncapped (12 per CU) k_heavy takes 0.83 ms per 10^6 GRCh38-scale reads and k_heavy_pe 2.01 per 10^6 mates; capped 0.73 and 1.76, and the
+// kernels of the other batches in flight find more room beside them (profiles/r03/ab_heavy_ranged_pops.log).  -DSALT_HEAVY_WAVES=0: no cap.
+#ifndef SALT_HEAVY_WAVES
+#define SALT_HEAVY_WAVES 4
+#endif
+#if SALT_HEAVY_WAVES > 0
 #define HEAVY_OCC __attribute__((amdgpu_waves_per_eu(SALT_HEAVY_WAVES, SALT_HEAVY_WAVES)))
 #else
 #define HEAVY_OCC
@@ -1748,13 +1807,14 @@ k_gap(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, GapBufs g)
     __shared__ GapLds s;
     __shared__ uint32_t s_item;
     const uint32_t lane = lane_id();
-    const uint32_t n_items = g.gctl[5] < g.items_cap ? g.gctl[5] : g.items_cap;
+    const uint32_t n_items = g.gctl[QC(5)] < g.items_cap ? g.gctl[QC(5)] : g.items_cap;
+    uint32_t seg = blockIdx.x & (HEAVY_HEADS - 1u), tried = 0;
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(&g.gctl[3], 1u);
+        if (threadIdx.x == 0) s_item = pop_ranged(g.qheads + 1, n_items, seg, tried);
         WSYNC();
         const uint32_t it = s_item;
         WSYNC();
-        if (it >= n_items) break;
+        if (it == 0xFFFFFFFFu) break;
         const uint32_t item = g.gitems[it], slot = item >> 11, strand = (item >> 10) & 1u, chunk = item & 1023u;
         const uint32_t r = g.gq[slot];
         const uint32_t *rec = pm + (uint64_t)r * ap.pg.pm_stride;
@@ -1787,13 +1847,14 @@ k_gapfin(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, salt_res
     __shared__ uint32_t s_item;
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull;
-    const uint32_t n_items = g.gctl[2] < g.cap ? g.gctl[2] : g.cap;
+    const uint32_t n_items = g.gctl[QC(2)] < g.cap ? g.gctl[QC(2)] : g.cap;
+    uint32_t seg = blockIdx.x & (HEAVY_HEADS - 1u), tried = 0;
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(&g.gctl[4], 1u);
+        if (threadIdx.x == 0) s_item = pop_ranged(g.qheads + 2, n_items, seg, tried);
         WSYNC();
         const uint32_t slot = s_item;
         WSYNC();
-        if (slot >= n_items) break;
+        if (slot == 0xFFFFFFFFu) break;
         const uint64_t rt0 = ctr ? __builtin_amdgcn_s_memrealtime() : 0;
         const uint32_t r = g.gq[slot];
         if (r == 0xFFFFFFFFu) continue;                                   // the pool was full: k_heavy finished this read itself
@@ -1844,7 +1905,7 @@ k_gapfin(IndexView ix, AlignParams ap, const uint32_t *__restrict__ pm, salt_res
                     out->hits[s][j].is_gap = 1; out->hits[s][j].strand = (uint16_t)s;
                 }
             if (n_cig_items > first_cig) {                                // main hit (which = 0) and every alternative hit (1 + index)
-                const uint32_t base = atomicAdd(&g.gctl[6], n_cig_items - first_cig);
+                const uint32_t base = atomicAdd(&g.gctl[QC(6)], n_cig_items - first_cig);
                 for (uint32_t c = first_cig; c < n_cig_items; ++c) g.cq[base + c - first_cig] = (r << 3) | c;
             }
             if (ctr) atomicMax(ctr + SALT_CTR_MAX_GAPFIN, ((unsigned long long)(__builtin_amdgcn_s_memrealtime() - rt0) << 32) | r);
@@ -1920,7 +1981,7 @@ k_queue_pack(const uint32_t *__restrict__ qseg, const uint32_t *__restrict__ qsu
         uint32_t base = 0, total = 0;
         for (uint32_t s = 0; s < QSEG; ++s) { const uint32_t c = qsub[s * QSEG_STRIDE]; if (s < blockIdx.x) base += c; total += c; }
         base_s = base; cnt_s = qsub[blockIdx.x * QSEG_STRIDE];
-        if (blockIdx.x == 0) qctl[0] = total;
+        if (blockIdx.x == 0) qctl[QC(0)] = total;
     }
     __syncthreads();
     const uint32_t *src = qseg + (size_t)blockIdx.x * qseg_cap(n_reads);
@@ -2514,6 +2575,7 @@ void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm
 }
 size_t queue_words(uint32_t max_reads) { return (size_t)max_reads * 2 + (size_t)QSEG * qseg_cap(max_reads); }     // flat queue | overflow queue | segments
 uint32_t queue_sub_words() { return QSEG * QSEG_STRIDE; }
+uint32_t queue_heads_offset() { static_assert(HEAVY_HEADS == QSEG && HEAVY_HEAD_STRIDE == QSEG_STRIDE, "k_heavy's heads live in the segments' counter slots"); return QSEG_STRIDE / 2; }
 
 // ---------------------------------------------------------------------------------------------
 // k_diag_rule: unit access to rule_unsorted / rule_sparse (tests only).  One wave per case; out[case] = any, best_pos,
@@ -2776,12 +2838,12 @@ uint32_t heavy_blocks_per_cu()
 
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, unsigned long long *ctr,
-                  uint32_t n_blocks, uint32_t gap_blocks, void *lvtab, const GapBufs &g_in, uint32_t *ovq, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st)
+                  uint32_t n_blocks, uint32_t gap_blocks, void *lvtab, const GapBufs &g_in, uint32_t *ovq, uint32_t *qheads, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st)
 {
     if (!ap.n_reads) { if (ev3) for (int i = 0; i < 3; ++i) hipEventRecord(ev3[i], st); return; }
     uint32_t blocks = n_blocks < ap.n_reads ? n_blocks : ap.n_reads;
     LvTables *tab = static_cast<LvTables *>(lvtab);
-    GapBufs g = g_in; g.ovq = ovq;
+    GapBufs g = g_in; g.ovq = ovq; g.qheads = qheads;
     // The usual shape (7.5 KB of LDS per block) when the batch fits it: at most 32 seed slots per strand and k_gap's buffers to hand gapped
     // reads to; the few reads it cannot finish (no k_gap slot left) wait in the overflow queue for the pass right behind it, which runs
     // the all-in-one shape (18.6 KB) and leaves at once when the queue is empty.  SALT_GPU_HEAVY_BIG=1: the all-in-one shape for everything.
@@ -2808,7 +2870,7 @@ void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm
     if (ev3) hipEventRecord(ev3[1], st);
     hipLaunchKernelGGL(k_gapfin, dim3((n_blocks + 3) / 4), dim3(64), 0, st, ix, ap, pm, results, g, ctr);
     if (ev3) hipEventRecord(ev3[2], st);
-    hipLaunchKernelGGL(k_cigar, dim3((n_blocks + 1) / 2), dim3(64), 0, st, ix, ap.pg, pm, results, g.cq, g.gctl + 6, g.gctl + 7, g.cap * (1u + SALT_MAX_HITS), tab);
+    hipLaunchKernelGGL(k_cigar, dim3((n_blocks + 1) / 2), dim3(64), 0, st, ix, ap.pg, pm, results, g.cq, g.gctl + QC(6), g.gctl + QC(7), g.cap * (1u + SALT_MAX_HITS), tab);
 }
 
 GapBufs gap_bufs_layout(uint8_t *base, uint32_t cap, uint32_t *gctl, size_t *bytes)

@@ -294,7 +294,7 @@ extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint
     CHKW(hipMemset(ws->d_results, 0, (uint64_t)max_reads * sizeof(salt_result_t)));
     CHKW(hipMalloc((void **)&ws->d_queue, queue_words(max_reads) * 4));         // the reads k_light queues (flat, and the segments they arrive in) + k_heavy's overflow queue
     CHKW(hipMalloc((void **)&ws->d_qsub, (size_t)queue_sub_words() * 4));
-    CHKW(hipMalloc((void **)&ws->d_qctl, 16 * 4));
+    CHKW(hipMalloc((void **)&ws->d_qctl, (size_t)QCTL_WORDS * 4));
     ws->gcap = max_reads < (1u << 20) ? max_reads : (1u << 20);         // slots for reads whose gapped pass is deferred (44 B each + their rows in the pool)
     if (const char *e3 = getenv("SALT_GPU_NO_GAP_DEFER")) if (atoi(e3)) ws->gcap = 0;
     if (const char *e3 = getenv("SALT_GPU_GAP_SLOTS")) { const int v = atoi(e3); if (v > 0 && (uint32_t)v < ws->gcap) ws->gcap = (uint32_t)v; }     // tests: the overflow pass
@@ -306,11 +306,11 @@ extern "C" int salt_gpu_ws_create(salt_gpu_index_t *ix, uint32_t max_reads, uint
     {
         hipDeviceProp_t prop;
         CHKW(hipGetDeviceProperties(&prop, ix->device));
-        uint32_t per_cu = heavy_blocks_per_cu();                           // what LDS / VGPRs admit (12)
-        // Eight by default: the persistent kernels are latency bound (alone: 4 -> 1.98, 5 -> 1.64, 6 -> 1.40, 8 -> 1.17 ms per 10^6
-        // GRCh38-scale reads), and since k_light2 no longer waits for its queue counter the 4-stream step is the same for 4 ... 8
-        // (2.50-2.52 ms; 10 -> 2.61), so the count that is best for the kernel alone is taken (profiles/r02/ab_heavy_per_cu_final.log)
-        if (per_cu > 8) per_cu = 8;
+        uint32_t per_cu = heavy_blocks_per_cu();                           // what LDS / VGPRs admit (16)
+        // All of them: the persistent kernels are latency bound (alone: 4 -> 1.98, 5 -> 1.64, 6 -> 1.40, 8 -> 1.12, 12 -> 0.82, 16 -> 0.73 ms
+        // per 10^6 GRCh38-scale reads; paired end 8 -> 2.65, 12 -> 2.01, 16 -> 1.76).  Until the waves took their reads through ONE counter the kernel stood at
+        // 1.165 ms from 8 blocks per CU on (the counter's ~14 ns per pop x 75 700 reads) and eight was the default; with the ranged heads
+        // (pop_ranged, salt_align.hip) it follows the waves again (profiles/r03/ab_heavy_ranged_pops.log)
         if (const char *e2 = getenv("SALT_GPU_HEAVY_PER_CU")) { int v = atoi(e2); if (v > 0 && (uint32_t)v <= heavy_blocks_per_cu()) per_cu = (uint32_t)v; }
         ws->heavy_blocks = (uint32_t)prop.multiProcessorCount * per_cu;    // persistent one-wave blocks
         // k_gap's items (64 candidates' Landau-Vishkin distances, ~70 us each) are independent and need no table of their own: its grid is
@@ -414,7 +414,7 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     unsigned long long *ctr = o->collect_counters ? ws->d_ctr : nullptr;
     const bool timed = ws->timing && ws->n_timed < MAX_TIMED;
     hipEvent_t *ev = timed ? &ws->ev[(size_t)ws->n_timed * EV_PER_CALL] : nullptr;
-    HIPCHK(hipMemsetAsync(ws->d_qctl, 0, 64, st));
+    HIPCHK(hipMemsetAsync(ws->d_qctl, 0, (size_t)QCTL_WORDS * 4, st));
     if (timed) HIPCHK(hipEventRecord(ev[0], st));
     launch_pack(pg, n_reads, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_pm, ws->d_tb, st);
     if (timed) HIPCHK(hipEventRecord(ev[1], st));
@@ -423,10 +423,11 @@ static int align_resident_impl(salt_gpu_ws_t *ws, const salt_aln_opt_t *o, uint3
     if (!ap.all_heavy)
         launch_light(ws->ix->view, ap, ws->d_pm, static_cast<const uint8_t *>(d_seqs), static_cast<const uint32_t *>(d_offs), ws->d_sai_c, ws->d_sai_r,
                      static_cast<salt_result_t *>(d_results), ws->d_queue, ws->d_qctl, ws->d_queue + 2 * (size_t)ws->max_reads, ws->d_qsub, ctr, st);
+    else HIPCHK(hipMemsetAsync(ws->d_qsub, 0, (size_t)queue_sub_words() * 4, st));          // (launch_light does it otherwise: k_heavy's queue heads live there)
     if (timed) HIPCHK(hipEventRecord(ev[3], st));
     launch_heavy(ws->ix->view, ap, ws->d_pm, ws->d_sai_c, ws->d_sai_r,
                  static_cast<salt_result_t *>(d_results), ws->d_queue, ctr, ws->heavy_blocks, ws->gap_blocks, ws->d_lvtab,
-                 gap_bufs_layout(ws->d_gap, ws->gcap, ws->d_qctl, nullptr), ws->d_queue + ws->max_reads, glob_loci ? ws->d_pe_scr : nullptr, timed ? ev + 4 : nullptr, st);
+                 gap_bufs_layout(ws->d_gap, ws->gcap, ws->d_qctl, nullptr), ws->d_queue + ws->max_reads, ws->d_qsub + queue_heads_offset(), glob_loci ? ws->d_pe_scr : nullptr, timed ? ev + 4 : nullptr, st);
     if (timed) { HIPCHK(hipEventRecord(ev[7], st)); ws->ev_pe[ws->n_timed] = 0; ++ws->n_timed; }
     HIPCHK(hipGetLastError());
     return SALT_OK;
@@ -1219,7 +1220,9 @@ extern "C" int salt_gpu_ws_queue_counts(salt_gpu_ws_t *ws, uint32_t out[8])
     if (!ws || !out) return fail(SALT_E_INVAL, "null argument");
     HIPCHK(hipSetDevice(ws->ix->device));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, ws->d_qctl, 32, hipMemcpyDeviceToHost));
+    uint32_t all[QCTL_WORDS];
+    HIPCHK(hipMemcpy(all, ws->d_qctl, sizeof all, hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < 8; ++k) out[k] = all[QC(k)];
     return SALT_OK;
 }
 
@@ -1228,8 +1231,8 @@ extern "C" int salt_gpu_ws_heavy_reads(salt_gpu_ws_t *ws, uint32_t *ids, uint32_
     if (!ws || !n) return fail(SALT_E_INVAL, "null argument");
     HIPCHK(hipSetDevice(ws->ix->device));
     HIPCHK(hipDeviceSynchronize());
-    uint32_t ctl[8];
-    HIPCHK(hipMemcpy(ctl, ws->d_qctl, 32, hipMemcpyDeviceToHost));
+    uint32_t ctl[1];
+    HIPCHK(hipMemcpy(ctl, ws->d_qctl + QC(0), 4, hipMemcpyDeviceToHost));
     *n = ctl[0];
     if (ids && cap) HIPCHK(hipMemcpy(ids, ws->d_queue, (uint64_t)(ctl[0] < cap ? ctl[0] : cap) * 4, hipMemcpyDeviceToHost));
     return SALT_OK;

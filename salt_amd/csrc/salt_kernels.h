@@ -65,8 +65,13 @@ uint32_t seed_wq_cnt_words();
 void launch_light(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint8_t *seqs, const uint32_t *offs, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, uint32_t *queue, uint32_t *qctl, uint32_t *qseg, uint32_t *qsub, unsigned long long *ctr, hipStream_t st);
 size_t queue_words(uint32_t max_reads);                      // d_queue: the flat queue, k_heavy's overflow queue, k_light's segments
+uint32_t queue_heads_offset();                              // k_heavy's queue heads inside the same array: word offset of head 0 (zeroed with the counters)
 uint32_t queue_sub_words();                                 // the segments' counters
-// Deferred gapped passes (k_heavy -> k_gap -> k_gapfin -> k_cigar), `cap` slots; gctl = the workspace's qctl[8]
+// Control word k of a workspace (qctl / GapBufs::gctl) lives at word QC(k): a cache line each.  Atomics on one line are served one after the
+// other (~14 ns each) however many waves issue them, and k_heavy's gapped reads push through three of these words.
+#define QC(k) ((k) * 32u)
+static const uint32_t QCTL_WORDS = 16 * 32;
+// Deferred gapped passes (k_heavy -> k_gap -> k_gapfin -> k_cigar), `cap` slots; gctl = the workspace's qctl
 struct GapBufs {
     uint32_t *gq;        // [cap] read index of the slot (0xFFFFFFFF: not used after all)
     uint32_t *gn;        // [cap][2] located rows per strand
@@ -78,11 +83,12 @@ struct GapBufs {
     uint32_t *gctl;
     uint32_t cap, pool, items_cap;
     uint32_t *ovq;       // reads k_heavy's small shape could not finish (launch_heavy); count gctl[9], head gctl[10]
+    uint32_t *qheads;    // k_heavy's queue heads (launch_heavy): one per range of the queue, 256 bytes apart, zero at launch
 };
 GapBufs gap_bufs_layout(uint8_t *base, uint32_t cap, uint32_t *gctl, size_t *bytes);   // base = nullptr: size only
 void launch_heavy(const IndexView &ix, const AlignParams &ap, const uint32_t *pm, const uint4 *sai_c,
                   const uint4 *sai_r, salt_result_t *results, const uint32_t *queue, unsigned long long *ctr,
-                  uint32_t n_blocks, uint32_t gap_blocks, void *lvtab, const GapBufs &g, uint32_t *ovq, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st);
+                  uint32_t n_blocks, uint32_t gap_blocks, void *lvtab, const GapBufs &g, uint32_t *ovq, uint32_t *qheads, uint8_t *pe_scr, hipEvent_t *ev3, hipStream_t st);
 size_t lv_table_bytes();                // per-block LV traceback table (global memory)
 
 // ---- paired end (salt_pe.hip) ----
