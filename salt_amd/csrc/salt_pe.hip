@@ -346,6 +346,16 @@ __device__ __forceinline__ uint32_t dpp_pk_max8(uint32_t x)
     t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true); x = pk_max(x, t);
     t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true); return pk_max(x, t);
 }
+// The queues of the Smith-Waterman kernels.  All pulls of a launch on one counter are served one after the other (~14 ns each): when
+// every group of the device asks for its first item at the same moment the last one has waited a third of a millisecond, and again when
+// they all come back to find the queue empty.  So the FIRST item of a puller is its own index (no atomic), the counter hands out what
+// lies behind those, and a puller looks at the counter before it adds to it (the look is a plain load: no queue).
+// n_first: items the static first round covers (pullers x step).  Returns the item index, >= n_items when there is none.
+__device__ __forceinline__ uint32_t sw_pull(uint32_t *head, const uint32_t step, const uint32_t n_first, const uint32_t n_items)
+{
+    if (n_first >= n_items || n_first + __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_items) return 0xFFFFFFFFu;
+    return n_first + atomicAdd(head, step);
+}
 template <int SEG> struct Fwd2 {                                 // a pair's forward pass between two columns
     uint32_t H[SEG], E[SEG], shp[(SEG + 2) / 3];                 // shp: per stripe the 5-bit profile shifts of A and of B, three stripes per register
     RefStream rsA, rsB;                                          // (both streams turn their blocks at the same columns)
@@ -738,11 +748,12 @@ k_swf(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__
     uint32_t it0 = 0, ref0A = 0, ref0B = 0;
     int i = 0, nCols = 0, refLenA = 0, refLenB = 0, awA = 0, awB = 0;
     unsigned long long t0 = 0;
-    bool idle = true, done = false;
+    bool idle = true, done = false, first = true;
     for (;;) {
-        if (idle && !done) {                                        // the group's next pair
-            uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(head, 2u);
+        if (idle && !done) {                                        // the group's next pair (sw_pull: its own index first)
+            uint32_t t = 2u * (blockIdx.x * 8u + grp);
+            if (!first && lane == 0) t = sw_pull(head, 2u, 2u * 8u * gridDim.x, n_req);
+            first = false;
             it0 = (uint32_t)__shfl((int)t, 0, 8);
             if (it0 >= n_req) done = true;
             else {
@@ -814,9 +825,11 @@ k_swf1(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict_
     const uint32_t n_req = pctl[0];
     if (!all && head[3] == 0) return;                              // (head[3]: the requests k_swf left pending, behind the four queue heads)
     uint16_t *maxColumn = reinterpret_cast<uint16_t *>(scratch + ((size_t)blockIdx.x * 8 + grp) * 2u * maxcol_bytes);
+    bool first = true;
     for (;;) {                                                       // eight requests per pull, a uniform exit (see k_swr)
-        uint32_t base = 0;
-        if (threadIdx.x == 0) base = atomicAdd(head, 8u);
+        uint32_t base = 8u * blockIdx.x;
+        if (!first && threadIdx.x == 0) base = sw_pull(head, 8u, 8u * gridDim.x, n_req);
+        first = false;
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= n_req) break;
         const uint32_t it = base + grp;
@@ -870,9 +883,11 @@ k_swr(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict__
     }
     uint32_t *lw = reinterpret_cast<uint32_t *>(sw_lds + sw_lds_words_at(seg, SEG, false)) + grp * 8u;
     const uint32_t n_req = pctl[0];
+    bool first = true;
     for (;;) {
-        uint32_t base = 0;
-        if (threadIdx.x == 0) base = atomicAdd(head, 8u);
+        uint32_t base = 8u * blockIdx.x;
+        if (!first && threadIdx.x == 0) base = sw_pull(head, 8u, 8u * gridDim.x, n_req);
+        first = false;
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= n_req) break;
         const uint32_t it = base + grp;
@@ -917,9 +932,11 @@ k_swtb(IndexView ix, const uint8_t *__restrict__ pac, const uint8_t *__restrict_
     uint8_t *const gdir = my + 3u * SW_BAND_W * 4u;
     const uint64_t gdir_cap = group_bytes > 3u * SW_BAND_W * 4u ? group_bytes - 3u * SW_BAND_W * 4u : 0u;
     const uint32_t n_req = pctl[0];
+    bool first = true;
     for (;;) {                                                       // eight requests per pull, a uniform exit (see k_swr)
-        uint32_t base = 0;
-        if (threadIdx.x == 0) base = atomicAdd(head, 8u);
+        uint32_t base = 8u * blockIdx.x;
+        if (!first && threadIdx.x == 0) base = sw_pull(head, 8u, 8u * gridDim.x, n_req);
+        first = false;
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= n_req) break;
         const uint32_t it = base + grp;
