@@ -330,9 +330,17 @@ def main():
                          "whole_step_GBps_wall": round(sum(db.values()) / (dt / args.steps) / 1e9, 1),
                          "bytes_model": "device layout: 64 B per W-mer gather, 32/64 B per C/R Occ block fetched, 4 B per SA / R-position load, 8 B per text "
                                         "word pair, 16 B per verify lane-load, packed read records, 32 B per seed interval pair, result rows; counted by the kernels"})
-        tr = prof.get("hbm_bytes_per_launch", {}).get(pkey(dom))
+        # k_seed's timing slot is two kernels (k_seed: table gather + the seeds it finishes itself; k_seed_walk: the queued walks): when it
+        # is the dominant one every profile figure below is the sum over both, and the rocprofv3 durations to compare with are both rows
+        parts = lambda k: ("k_seed", "k_seed_walk") if k == "k_seed" else (pkey(k),)
+        if dom == "k_seed":
+            roof["kernel"] = "k_seed (k_seed + k_seed_walk: one timing slot, back to back on the stream)"
+        tr = sum(prof.get("hbm_bytes_per_launch", {}).get(q, 0) for q in parts(dom)) or None
         roof["traffic"] = tr
-        pk = prof.get("per_kernel_mean", {})
+        pk0 = prof.get("per_kernel_mean", {})
+        pk = dict(pk0)
+        if "k_seed" in pk0 and "k_seed_walk" in pk0:                    # (per-kernel counters of the slot added; issue fractions are not additive and stay per kernel)
+            pk["k_seed"] = {c: pk0["k_seed"].get(c, 0.0) + pk0["k_seed_walk"].get(c, 0.0) for c in set(pk0["k_seed"]) | set(pk0["k_seed_walk"])}
         if tr:
             roof["traffic_GBps"] = round(tr / (serial_kms[dom] / 1e3) / 1e9, 1)
             roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE of %s (separate --pmc passes)" % prof_dir + ", raw: tools/ubench/gather shows FETCH_SIZE = 64.0 B per random "
@@ -352,25 +360,22 @@ def main():
                                        "all_kernels": {k: req_rates(k, serial_kms.get(k, 0.0)) for k in ("k_seed", "k_light", "k_heavy", "k_gap") if serial_kms.get(k)},
                                        "ceilings_by_shape_G_per_s": {"4-byte": 48, "16-byte": 38, "32-byte": 38, "64-byte (4 lanes x 16 B)": 47,
                                                                      "source": "tools/ubench/gather, the same from 16 ... 240 GiB tables and from 65 000 ... 2 000 000 loads in flight (profiles/r03/gather_rate*.log)"},
-                                       "whole_step_G_per_s_wall": round(sum(v.get("TCC_EA0_RDREQ_sum", 0) for v in pk.values()) / (dt / args.steps) / 1e9, 1),
+                                       "whole_step_G_per_s_wall": round(sum(v.get("TCC_EA0_RDREQ_sum", 0) for v in pk0.values()) / (dt / args.steps) / 1e9, 1),
                                        "source": "TCC_EA0_RDREQ_sum (+ WRITE_SIZE / 64 B) per launch (%s/pmc_tcc_*.csv, pmc_write_*.csv) / this run's HIP-event time; ceiling: tools/ubench/gather; "
                                                  "k_seed in all_kernels is k_seed + k_seed_walk (one timing slot: their counters are added)" % prof_dir}
-            if "k_seed" in roof["random_requests"]["all_kernels"]:
-                a, b = pk.get("k_seed", {}), pk.get("k_seed_walk", {})
-                rd = a.get("TCC_EA0_RDREQ_sum", 0.0) + b.get("TCC_EA0_RDREQ_sum", 0.0); wr2 = (a.get("WRITE_SIZE", 0.0) + b.get("WRITE_SIZE", 0.0)) * 1024.0 / SECTOR
-                roof["random_requests"]["all_kernels"]["k_seed"] = {"read_requests": int(rd), "write_requests": int(wr2), "G_per_s": round((rd + wr2) / (serial_kms["k_seed"] / 1e3) / 1e9, 1)}
         alltr = prof.get("hbm_bytes_per_launch", {})
         if alltr:
             roof["whole_step_traffic_GBps_wall"] = round(sum(alltr.values()) / (dt / args.steps) / 1e9, 1)
-        ir = prof.get("issue", {}).get(pkey(dom))
+        ir = {q: prof.get("issue", {}).get(q) for q in parts(dom) if prof.get("issue", {}).get(q)}
         if ir:
-            roof["issue_bound"] = ir
-        roof["limiter"] = ("the rate at which the memory system serves dependent, sector-sized random requests into a 195 GiB image, not its byte bandwidth: with the write requests "
-                           "counted k_seed makes its requests at 41 G/s (the micro-benchmark's ceiling for its shape), k_seed_walk at 30 G/s (0.8 of the 38 G/s its 32-byte blocks reach), "
-                           "k_heavy at 26 G/s -- and k_heavy does not move with more resident waves (8 / 12 / 16 one-wave blocks per CU: the same time, every wave 1.5 - 2 x slower: the L1's "
-                           "own latency and its return path stall, profiles/r03/heavy_mem_counters_8_vs_12_per_cu.log) nor with more loads in flight per wave "
-                           "(profiles/r03/ab_heavy_locate_mlp.log).  random_requests.with_writes.ms_at_the_ceiling is what the kernel's requests would take at the gather ceiling; "
-                           "what moves the step from here is fewer requests per read (the context tables did that: DESIGN 3, 4.2, 5.0)")
+            roof["issue_bound"] = ir if len(ir) > 1 else list(ir.values())[0]
+        roof["limiter"] = ("the rate at which the memory system serves sector-sized random requests into a 195 GiB image, not its byte bandwidth (random_requests): with the write "
+                           "requests counted k_heavy now makes its requests at ~42 G/s and k_seed + k_seed_walk at ~34 G/s, against the 38 - 48 G/s tools/ubench/gather reaches for "
+                           "their shapes.  Until this round k_heavy stood at 26 G/s whatever its occupancy or its code: its waves took their reads through ONE atomic counter, which "
+                           "serves a pop every ~14 ns (time = 0.08 ms + 14.4 ns x queued reads from 9 000 to 150 000 reads, profiles/r03/heavy_vs_batch.log); with 64 ranged heads the "
+                           "kernel follows its waves again (1.165 -> 0.73 ms at 16 blocks per CU, profiles/r03/ab_heavy_ranged_pops.log; DESIGN 5.0).  "
+                           "random_requests.with_writes.ms_at_the_ceiling is what the dominant slot's requests would take at the gather ceiling; what moves the step from here is "
+                           "fewer requests per read (the context tables did that: DESIGN 3, 4.2, 5.0)")
         roof["counters"] = {k: int(v) for k, v in ctr.items() if k.startswith("d_")}
         out["roofline"] = roof
 
