@@ -417,6 +417,49 @@ def test_gpu_rule_on_unsorted_lists_equals_the_sequential_rule(mode):
         assert got == want, (mode, c, got, want, pos[c][:10], val[c][:10], bounds[c])
 
 
+@pytest.mark.parametrize("env", [{"SALT_GPU_HEAVY_PER_CU": "1"}, {"SALT_GPU_ALL_HEAVY": "1"}, {"SALT_GPU_ALL_HEAVY": "1", "SALT_GPU_HEAVY_PER_CU": "3"},
+                                 {"SALT_GPU_GAP_PER_CU": "1"}])
+def test_gpu_ranged_queue_heads_hand_out_every_item_once(tiny, monkeypatch, env):
+    """The persistent kernels take their items through 64 ranged heads (pop_ranged): with one block per CU every block walks through all
+    the ranges, with SALT_GPU_ALL_HEAVY the queue is the whole batch (and k_light never zeroes the heads), with one k_gap block per CU the
+    gapped items go the same way.  Rows equal to the default workspace's, which the other tests hold against the oracle."""
+    import salt_amd
+
+    def differing(a, b):                                     # the fields that mean something (not the stale bytes behind n_hits / n_cigar)
+        bad = np.zeros(len(a), dtype=bool)
+        for f in ("pos", "strand", "n_diff", "is_gap", "mapq", "b0", "b1", "n_cigar", "skipped"):
+            bad |= a[f] != b[f]
+        bad |= (a["n_hits"] != b["n_hits"]).any(axis=1)
+        for s in range(2):
+            for j in range(a["hits"].shape[2]):
+                live = (a["n_hits"][:, s] > j) & ~bad
+                for f in ("pos", "n_diff", "is_gap"):
+                    bad |= live & (a["hits"][f][:, s, j] != b["hits"][f][:, s, j])
+        for i in np.nonzero(~bad & (a["pos"] != 0xFFFFFFFF))[0]:
+            n = int(a["n_cigar"][i])
+            if (a["cigar"][i][:n] != b["cigar"][i][:n]).any():
+                bad[i] = True
+        return np.nonzero(bad)[0]
+
+    w, seqs, offs = tiny
+    idx = salt_amd.Index.reload(w["prefix"], rebuild_lkt=False)
+    opt, _ = salt_amd.AlnOpt.from_argv(["-m", "200"], idx.l_seed)
+    base = salt_amd.GpuAligner(idx, device=0, max_reads=len(offs) - 1)
+    want = base.alnse_core1(opt, seqs, offs).copy()
+    base.close()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = salt_amd.GpuAligner(idx, device=0, max_reads=len(offs) - 1)
+    try:
+        for _ in range(2):                                   # twice: the heads are zeroed per call
+            got = other.alnse_core1(opt, seqs, offs)
+            bad = differing(got, want)
+            assert len(bad) == 0, (env, bad[:10])
+    finally:
+        other.close()
+        idx.destroy()
+
+
 def test_gpu_attach_to_a_copied_image_gives_the_same_rows(lam):
     """The multi-GPU path on one GPU: the packed device image is copied into another buffer (what the RCCL broadcast in
     bench.py / salt_gpu_index_replicate delivers to the other ranks) and a second aligner attaches to the copy."""
